@@ -1,0 +1,108 @@
+/*
+ * pom_batch.h — C-ABI of the MI355X batched Pommerman stepper (libpom_batch.so).
+ *
+ * Drop-in boundary for ONE path of dist1ll/pomcpp: the simulation tick
+ *     void bboard::Step(State* state, Move* moves);          include/bboard.hpp:668, src/bboard/step.cpp:9
+ * and the bookkeeping Environment::Step wraps around it      src/bboard/environment.cpp:123-169
+ * re-laid out over n concurrent boards on one GPU.  States cross the boundary
+ * as the reference's own 1004-byte `bboard::State` (pom_state.h), moves as the
+ * reference's `Move` ints (0 IDLE, 1 UP, 2 DOWN, 3 LEFT, 4 RIGHT, 5 BOMB),
+ * four per env INCLUDING dead agents (their entries are read by FillDestPos /
+ * FixSwitchMove, step_utility.cpp:138-170 — SURVEY.md Q9).
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Every call returns a
+ * PomError (the reference returns void and has UB on misuse; see pom_state.h
+ * POM_UB_* for what the stepper does instead).  A handle is bound to one
+ * device and one HIP stream; calls on one handle are not thread-safe, distinct
+ * handles are independent.  Stepping is asynchronous on the handle's stream;
+ * upload / download / status / counters synchronise it.
+ *
+ * There is deliberately no CPU fallback: without a HIP device every entry
+ * point fails with POM_E_HIP.
+ */
+#ifndef POM_BATCH_H_
+#define POM_BATCH_H_
+
+#include <stdint.h>
+
+#include "pom_rng.h"
+#include "pom_state.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum PomError {
+    POM_OK = 0,
+    POM_E_ARG = 1,             /* null handle, range outside [0, n_envs), bad option */
+    POM_E_HIP = 2,             /* HIP runtime error or no device; pom_last_error() has the text */
+    POM_E_UNREPRESENTABLE = 3, /* an uploaded State holds a value no reachable game state has (pom_packed.h) */
+    POM_E_NOMEM = 4
+} PomError;
+
+/* stepping semantics */
+enum {
+    POM_MODE_RAW = 0, /* bare bboard::Step: no timeStep++, finished envs keep stepping (what the reference's tests call) */
+    POM_MODE_ENV = 1  /* Environment::Step: skip finished envs, Step, timeStep++, done / winner / draw */
+};
+
+typedef struct PomBatchOptions {
+    int32_t struct_size;  /* = sizeof(PomBatchOptions), for ABI growth */
+    int32_t device;       /* HIP device ordinal */
+    void*   stream;       /* hipStream_t to run on, or NULL: the library creates one */
+    int32_t mode;         /* POM_MODE_RAW / POM_MODE_ENV */
+    int32_t auto_reset;   /* ENV mode: a finished env is reloaded from its snapshot and stepped in the same tick */
+    int32_t max_steps;    /* ENV mode: env is done once timeStep reaches this (0 = no limit); StartGame's bound, environment.cpp:71 */
+    int64_t env_offset;   /* global index of env 0, keys the synthetic move stream when a job is sharded over GPUs */
+} PomBatchOptions;
+
+typedef struct PomBatch PomBatch;
+
+/* counters accumulated since creation / pom_batch_reset_counters */
+enum { POM_CNT_STEPS = 0, POM_CNT_EPISODES = 1, POM_CNT_RESETS = 2, POM_CNT_UB_TICKS = 3, POM_CNT_N = 4 };
+
+const char* pom_last_error(void);
+int pom_device_count(void);
+
+int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts);
+int pom_batch_destroy(PomBatch* h);
+int64_t pom_batch_size(const PomBatch* h);
+
+/* host AoS (count x 1004 B) -> device; also becomes the envs' reset snapshot and clears their status */
+int pom_batch_upload(PomBatch* h, const void* states, int64_t first, int64_t count);
+/* device -> host AoS (count x 1004 B); agent padding bytes come back 0 */
+int pom_batch_download(PomBatch* h, void* states, int64_t first, int64_t count);
+/* make the current device state the reset snapshot */
+int pom_batch_snapshot(PomBatch* h);
+
+/* one tick with explicit moves: int32[n_envs][4], host or device memory */
+int pom_batch_step(PomBatch* h, const int32_t* moves_host);
+int pom_batch_step_device(PomBatch* h, const int32_t* moves_dev);
+/* `ticks` ticks with the pom_rng.h move stream (seed, env_offset+env, tick); ticks_per_launch >= 1 keeps
+ * the env tile resident in LDS for that many ticks per kernel launch (1 = state round-trips HBM each tick) */
+int pom_batch_step_random(PomBatch* h, uint64_t seed, int32_t dist, int32_t ticks, int32_t ticks_per_launch);
+/* the tick counter that keys the synthetic stream (advanced by step_random) */
+int pom_batch_set_tick(PomBatch* h, int64_t tick);
+
+/* per-env results for [first, first+count): any output pointer may be NULL.
+ * done/draw are 0/1, winner is -1 or the agent id (Environment::IsDone/IsDraw/GetWinner, environment.cpp:195-208) */
+int pom_batch_status(PomBatch* h, int64_t first, int64_t count, int32_t* done, int32_t* winner, int32_t* draw,
+                     int32_t* alive, int32_t* time_step, uint32_t* ubflags);
+
+int pom_batch_counters(PomBatch* h, int64_t out[POM_CNT_N]);
+/* same totals left in device memory (int64[POM_CNT_N]) on the handle's stream, e.g. for an RCCL all-reduce */
+int pom_batch_counters_device(PomBatch* h, void* dev_int64x4);
+int pom_batch_reset_counters(PomBatch* h);
+int pom_batch_sync(PomBatch* h);
+
+/* zero-copy view for device-side consumers (policies, observation kernels): SoA records,
+ * dword d of env e at base[d * n_pad + e]; layout in pomcpp_amd/csrc/pom_packed.h */
+int pom_batch_device_view(PomBatch* h, void** base, int64_t* n_pad, int32_t* rec_dwords);
+
+/* bboard::Step for a single host State on the GPU (a batch of one, device 0): the literal drop-in */
+int pom_step(void* state_1004, const int32_t moves[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POM_BATCH_H_ */

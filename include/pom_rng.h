@@ -17,6 +17,8 @@
 
 #if defined(__HIPCC__)
 #define POM_HD __host__ __device__ inline
+#elif defined(__cplusplus)
+#define POM_HD inline
 #else
 #define POM_HD static inline
 #endif

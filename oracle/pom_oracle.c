@@ -641,6 +641,58 @@ void pom_oracle_kill(void *state, int id)
     kill_agent((PomState *)state, id, &ub);
 }
 
+/* ---- the helpers pinned by unit_test/bboard/step_utility_test.cpp, exported for the
+ *      restated [step utilities] tests (same code the tick above runs inline) -------------- */
+void pom_oracle_dest_pos(const void *state, const int32_t *moves, int32_t *out_xy) /* FillDestPos, step_utility.cpp:138-144 */
+{
+    const PomState *s = (const PomState *)state;
+    for (int i = 0; i < POM_AGENT_COUNT; i++) {
+        Pos p = desired(s->agents[i].x, s->agents[i].y, moves[i]);
+        out_xy[2 * i] = p.x;
+        out_xy[2 * i + 1] = p.y;
+    }
+}
+
+void pom_oracle_fix_switch_move(const void *state, int32_t *xy) /* FixSwitchMove, step_utility.cpp:154-170 */
+{
+    const PomState *s = (const PomState *)state;
+    for (int i = 0; i < POM_AGENT_COUNT; i++) {
+        for (int j = i; j < POM_AGENT_COUNT; j++) {
+            if (xy[2 * i] == s->agents[j].x && xy[2 * i + 1] == s->agents[j].y &&
+                xy[2 * j] == s->agents[i].x && xy[2 * j + 1] == s->agents[i].y) {
+                xy[2 * i] = s->agents[i].x;
+                xy[2 * i + 1] = s->agents[i].y;
+                xy[2 * j] = s->agents[j].x;
+                xy[2 * j + 1] = s->agents[j].y;
+            }
+        }
+    }
+}
+
+int pom_oracle_resolve_dependencies(const void *state, const int32_t *xy, int32_t *dependency, int32_t *chain) /* step_utility.cpp:172-205 */
+{
+    const PomState *s = (const PomState *)state;
+    int root_count = 0;
+    for (int i = 0; i < POM_AGENT_COUNT; i++) {
+        if (s->agents[i].dead) {
+            chain[root_count++] = i;
+            continue;
+        }
+        int is_root = 1;
+        for (int j = 0; j < POM_AGENT_COUNT; j++) {
+            if (i == j || s->agents[j].dead) continue;
+            if (xy[2 * i] == s->agents[j].x && xy[2 * i + 1] == s->agents[j].y) {
+                dependency[j] = i;
+                is_root = 0;
+                break;
+            }
+        }
+        if (is_root)
+            chain[root_count++] = i;
+    }
+    return root_count;
+}
+
 /* bounded batch driver for the CPU baseline leg of bench.py: steps `n` envs
  * `ticks` times with the same counter-based move stream as the device
  * (pom_rng.h) and the same auto-reset rule; returns env-steps executed */

@@ -31,6 +31,11 @@ void pom_oracle_kill(void *state, int id);
 void pom_oracle_plant_bomb(void *state, int x, int y, int id, int life_time, int set_item);
 void pom_oracle_spawn_flame(void *state, int x, int y, int strength);
 
+/* step utilities pinned by the reference's [step utilities] tests; xy = {x0,y0,...,x3,y3} */
+void pom_oracle_dest_pos(const void *state, const int32_t *moves, int32_t *out_xy);
+void pom_oracle_fix_switch_move(const void *state, int32_t *xy);
+int pom_oracle_resolve_dependencies(const void *state, const int32_t *xy, int32_t *dependency, int32_t *chain);
+
 /* CPU-baseline driver: n envs x ticks with the pom_rng.h move stream and auto-reset */
 int64_t pom_oracle_run_random(void *states, const void *initial, int n, int ticks, uint64_t seed, int first_env,
                               int tick0, int dist, int max_steps);

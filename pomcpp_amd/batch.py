@@ -1,0 +1,204 @@
+"""ctypes binding of libpom_batch.so (include/pom_batch.h) and `BatchEnvironment`.
+
+`BatchEnvironment` mirrors `bboard::Environment` (/root/reference/include/bboard.hpp:541-644,
+src/bboard/environment.cpp:48-213) for n concurrent games on one MI355X:
+
+    reference (one game)                 here (n games)
+    env.MakeGame(agents)                 env.make_game(states)            # states: STATE_DTYPE[n]
+    env.Step()  -> act x4, bboard::Step  env.step(moves)                  # moves: int32[n,4], dead agents included
+    env.IsDone() / IsDraw() / GetWinner  env.is_done() / is_draw() / get_winner()   # arrays of n
+    env.GetState()                       env.get_state(first, count)      # STATE_DTYPE[count]
+
+The library is the only stepper.  If it is missing or no HIP device is present, loading or
+creating a batch raises — nothing falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .state import STATE_DTYPE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MODE_RAW, MODE_ENV = 0, 1
+DIST_HARMLESS, DIST_RANDOM, DIST_STRESS = 0, 1, 2
+CNT_STEPS, CNT_EPISODES, CNT_RESETS, CNT_UB_TICKS = 0, 1, 2, 3
+UB_LOST_AGENT, UB_NULL_BOMB, UB_QUEUE_OVERFLOW, UB_REVERT_LOOP, UB_BAD_INDEX = 1, 2, 4, 8, 16
+
+
+class PomError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        super().__init__(f"pom_batch error {code}: {text}")
+        self.code = code
+
+
+class _Options(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p),
+        ("mode", C.c_int32), ("auto_reset", C.c_int32), ("max_steps", C.c_int32),
+        ("env_offset", C.c_int64),
+    ]
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libpom_batch.so")
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load the HIP extension built in-tree by `__graft_entry__.build()`; fail loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build the gfx950 extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "pomcpp_amd has no CPU stepper to fall back to.")
+    lib = C.CDLL(path)
+    P, I32, I64, U64, VP = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
+    lib.pom_last_error.restype = C.c_char_p
+    lib.pom_device_count.restype = C.c_int
+    lib.pom_batch_create.argtypes = [C.POINTER(P), I64, C.POINTER(_Options)]
+    lib.pom_batch_destroy.argtypes = [P]
+    lib.pom_batch_size.argtypes = [P]
+    lib.pom_batch_size.restype = I64
+    lib.pom_batch_upload.argtypes = [P, VP, I64, I64]
+    lib.pom_batch_download.argtypes = [P, VP, I64, I64]
+    lib.pom_batch_snapshot.argtypes = [P]
+    lib.pom_batch_step.argtypes = [P, VP]
+    lib.pom_batch_step_device.argtypes = [P, VP]
+    lib.pom_batch_step_random.argtypes = [P, U64, I32, I32, I32]
+    lib.pom_batch_set_tick.argtypes = [P, I64]
+    lib.pom_batch_status.argtypes = [P, I64, I64, VP, VP, VP, VP, VP, VP]
+    lib.pom_batch_counters.argtypes = [P, VP]
+    lib.pom_batch_counters_device.argtypes = [P, VP]
+    lib.pom_batch_reset_counters.argtypes = [P]
+    lib.pom_batch_sync.argtypes = [P]
+    lib.pom_batch_device_view.argtypes = [P, C.POINTER(VP), C.POINTER(I64), C.POINTER(I32)]
+    lib.pom_step.argtypes = [VP, VP]
+    _lib = lib
+    return lib
+
+
+def _check(lib, rc: int) -> None:
+    if rc != 0:
+        raise PomError(rc, lib.pom_last_error().decode(errors="replace"))
+
+
+def step_one(state: np.ndarray, moves) -> None:
+    """`bboard::Step(State*, Move*)` on one host State, executed on the GPU (pom_step)."""
+    lib = load_library()
+    assert state.dtype == STATE_DTYPE and state.size == 1
+    mv = np.ascontiguousarray(moves, dtype=np.int32)
+    assert mv.shape == (4,)
+    buf = np.ascontiguousarray(state).reshape(1)
+    _check(lib, lib.pom_step(buf.ctypes.data, mv.ctypes.data))
+    state[...] = buf.reshape(state.shape)
+
+
+class BatchEnvironment:
+    def __init__(self, n_envs: int, device: int = 0, mode: int = MODE_ENV, auto_reset: bool = False,
+                 max_steps: int = 0, env_offset: int = 0, stream: Optional[int] = None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.n = int(n_envs)
+        o = _Options(C.sizeof(_Options), device, stream, mode, int(auto_reset), max_steps, env_offset)
+        _check(self._lib, self._lib.pom_batch_create(C.byref(self._h), self.n, C.byref(o)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pom_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- Environment::MakeGame / GetState ---------------------------------------------------
+    def make_game(self, states: np.ndarray, first: int = 0) -> None:
+        """Upload start states; they also become the reset snapshot (MakeGame, environment.cpp:53-66)."""
+        st = np.ascontiguousarray(states, dtype=STATE_DTYPE)
+        _check(self._lib, self._lib.pom_batch_upload(self._h, st.ctypes.data, first, st.size))
+
+    upload = make_game
+
+    def get_state(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        count = self.n - first if count is None else count
+        out = np.zeros(count, dtype=STATE_DTYPE)
+        _check(self._lib, self._lib.pom_batch_download(self._h, out.ctypes.data, first, count))
+        return out
+
+    download = get_state
+
+    def snapshot(self) -> None:
+        _check(self._lib, self._lib.pom_batch_snapshot(self._h))
+
+    # ---- Environment::Step --------------------------------------------------------------------
+    def step(self, moves: np.ndarray) -> None:
+        mv = np.ascontiguousarray(moves, dtype=np.int32)
+        if mv.shape != (self.n, 4):
+            raise ValueError(f"moves must be int32[{self.n}, 4] (dead agents included), got {mv.shape}")
+        _check(self._lib, self._lib.pom_batch_step(self._h, mv.ctypes.data))
+
+    def step_device(self, moves_ptr: int) -> None:
+        """moves_ptr: device address of int32[n,4] (e.g. torch_tensor.data_ptr())."""
+        _check(self._lib, self._lib.pom_batch_step_device(self._h, moves_ptr))
+
+    def step_random(self, seed: int, dist: int = DIST_RANDOM, ticks: int = 1, ticks_per_launch: int = 1) -> None:
+        _check(self._lib, self._lib.pom_batch_step_random(self._h, seed, dist, ticks, ticks_per_launch))
+
+    def set_tick(self, tick: int) -> None:
+        _check(self._lib, self._lib.pom_batch_set_tick(self._h, tick))
+
+    # ---- IsDone / IsDraw / GetWinner ------------------------------------------------------------
+    def status(self, first: int = 0, count: Optional[int] = None) -> dict:
+        count = self.n - first if count is None else count
+        names = ["done", "winner", "draw", "alive", "time_step", "ubflags"]
+        arrs = [np.zeros(count, dtype=np.int32) for _ in names]
+        _check(self._lib, self._lib.pom_batch_status(self._h, first, count, *[a.ctypes.data for a in arrs]))
+        out = dict(zip(names, arrs))
+        out["ubflags"] = out["ubflags"].view(np.uint32)
+        return out
+
+    def is_done(self) -> np.ndarray:
+        return self.status()["done"].astype(bool)
+
+    def is_draw(self) -> np.ndarray:
+        return self.status()["draw"].astype(bool)
+
+    def get_winner(self) -> np.ndarray:
+        return self.status()["winner"]
+
+    # ---- counters / plumbing ------------------------------------------------------------------------
+    def counters(self) -> np.ndarray:
+        out = np.zeros(4, dtype=np.int64)
+        _check(self._lib, self._lib.pom_batch_counters(self._h, out.ctypes.data))
+        return out
+
+    def counters_into(self, dev_ptr: int) -> None:
+        _check(self._lib, self._lib.pom_batch_counters_device(self._h, dev_ptr))
+
+    def reset_counters(self) -> None:
+        _check(self._lib, self._lib.pom_batch_reset_counters(self._h))
+
+    def sync(self) -> None:
+        _check(self._lib, self._lib.pom_batch_sync(self._h))
+
+    def device_view(self):
+        base, n_pad, rec = C.c_void_p(), C.c_int64(), C.c_int32()
+        _check(self._lib, self._lib.pom_batch_device_view(self._h, C.byref(base), C.byref(n_pad), C.byref(rec)))
+        return base.value, n_pad.value, rec.value

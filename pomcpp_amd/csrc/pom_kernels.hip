@@ -1,0 +1,604 @@
+/*
+ * pom_kernels.hip — gfx950 kernels and the C-ABI (include/pom_batch.h) of the batched
+ * Pommerman stepper.  Written for MI355X only: 64-lane wavefronts, one wavefront per
+ * workgroup, each lane owning one env whose board / bomb queue / flame queue sit in a
+ * column of the workgroup's LDS tile ([row][lane], so every per-lane dynamic index is
+ * bank-conflict-free: bank = lane mod 32 for all rows).
+ *
+ * The tick itself is pom_step_body.h; this file is the data movement around it:
+ *   HBM (SoA records, pom_packed.h) -> LDS tile + VGPRs -> tick(s) -> HBM,
+ * the AoS<->SoA pack / unpack at the boundary, status extraction and counters.
+ */
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "pom_batch.h"
+#include "pom_packed.h"
+#include "pom_step_body.h"
+
+/* ---------------------------------------------------------------------------------------------
+ * LDS tile of one wavefront: 127 rows x 64 lanes x 4 B = 32,512 B  (5 wavefronts per CU)
+ * ------------------------------------------------------------------------------------------- */
+enum {
+    ROW_BOARD = 0,    /* 61 rows: two 16-bit cells per dword            */
+    ROW_BOMBS = 61,   /* 20 rows: raw bomb words, physical queue slots  */
+    ROW_FLAMES = 81,  /* 20 rows                                        */
+    ROW_BDEST = 101,  /*  5 rows: 20 bytes, bomb destination snapshot   */
+    ROW_STACK = 106,  /* 21 rows: explosion frames                      */
+    LDS_ROWS = 127
+};
+
+
+struct LdsEnv {
+    uint32_t* t; /* &tile[lane] */
+    __device__ int cell(int c) const { return reinterpret_cast<const uint16_t*>(t)[(c >> 1) * 128 + (c & 1)]; }
+    __device__ void set_cell(int c, int v) { reinterpret_cast<uint16_t*>(t)[(c >> 1) * 128 + (c & 1)] = (uint16_t)v; }
+    __device__ int bomb(int s) const { return (int)t[(ROW_BOMBS + s) * 64]; }
+    __device__ void set_bomb(int s, int v) { t[(ROW_BOMBS + s) * 64] = (uint32_t)v; }
+    __device__ int flame(int s) const { return (int)t[(ROW_FLAMES + s) * 64]; }
+    __device__ void set_flame(int s, int v) { t[(ROW_FLAMES + s) * 64] = (uint32_t)v; }
+    __device__ int bdest(int i) const { return reinterpret_cast<const uint8_t*>(t + ROW_BDEST * 64)[(i >> 2) * 256 + (i & 3)]; }
+    __device__ void set_bdest(int i, int v) { reinterpret_cast<uint8_t*>(t + ROW_BDEST * 64)[(i >> 2) * 256 + (i & 3)] = (uint8_t)v; }
+    __device__ int frame(int d) const { return (int)t[(ROW_STACK + d) * 64]; }
+    __device__ void set_frame(int d, int v) { t[(ROW_STACK + d) * 64] = (uint32_t)v; }
+};
+
+struct StepParams {
+    uint32_t* state;
+    const uint32_t* snap;
+    const int32_t* moves; /* device int32[n][4], or nullptr: synthetic stream */
+    int64_t* wave_counters;
+    int64_t n, n_pad, env_offset;
+    uint64_t seed;
+    uint32_t tick0;
+    int32_t dist, ticks, mode, auto_reset, max_steps;
+};
+
+/* rows of the HBM record that go to LDS: board, bombs, flames */
+__device__ __forceinline__ void load_tile(const uint32_t* __restrict__ col, int64_t np, uint32_t* t)
+{
+#pragma unroll 8
+    for (int r = 0; r < 61; r++) t[(ROW_BOARD + r) * 64] = col[(POM_REC_BOARD + r) * np];
+#pragma unroll 10
+    for (int r = 0; r < 20; r++) t[(ROW_BOMBS + r) * 64] = col[(POM_REC_BOMBS + r) * np];
+#pragma unroll 10
+    for (int r = 0; r < 20; r++) t[(ROW_FLAMES + r) * 64] = col[(POM_REC_FLAMES + r) * np];
+}
+
+__global__ __launch_bounds__(64) void pom_step_kernel(StepParams p)
+{
+    __shared__ uint32_t tile[LDS_ROWS * 64];
+    const int lane = threadIdx.x;
+    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t np = p.n_pad;
+    const bool valid = e < p.n;
+    const bool env_mode = p.mode == POM_MODE_ENV;
+    uint32_t* t = tile + lane;
+    uint32_t* col = p.state + e;           /* buffers hold n_pad columns: in range for every lane */
+    const uint32_t* scol = p.snap + e;
+
+    uint32_t status = (col[POM_REC_META2 * np] >> 8) & 0xFF;
+    long long c_steps = 0, c_episodes = 0, c_resets = 0, c_ub = 0;
+
+    /* a finished env restarts from its snapshot: pick the source column per lane, one pass */
+    bool reload = valid && env_mode && p.auto_reset && (status & POM_ST_DONE);
+    const uint32_t* src = reload ? scol : col;
+    load_tile(src, np, t);
+    int time_step = (int)src[POM_REC_TIMESTEP * np];
+    uint32_t ag[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) ag[k] = src[(POM_REC_AGENTS + k) * np];
+    PomLane L;
+    {
+        const uint32_t m2 = src[POM_REC_META2 * np];
+        pom_lane_load(L, src[POM_REC_META * np], m2, ag);
+        status = (m2 >> 8) & 0xFF;
+    }
+    c_resets += __popcll(__ballot(reload));
+
+    LdsEnv acc{t};
+    PomStepper<LdsEnv> stepper(acc, L);
+
+    for (int tk = 0; tk < p.ticks; tk++) {
+        if (tk > 0) {
+            reload = valid && env_mode && p.auto_reset && (status & POM_ST_DONE);
+            if (reload) {
+                load_tile(scol, np, t);
+                time_step = (int)scol[POM_REC_TIMESTEP * np];
+#pragma unroll
+                for (int k = 0; k < 8; k++) ag[k] = scol[(POM_REC_AGENTS + k) * np];
+                const uint32_t m2 = scol[POM_REC_META2 * np];
+                pom_lane_load(L, scol[POM_REC_META * np], m2, ag);
+                status = (m2 >> 8) & 0xFF;
+            }
+            c_resets += __popcll(__ballot(reload));
+        }
+        const bool active = valid && !(env_mode && (status & POM_ST_DONE));
+        bool newly_done = false, new_ub = false;
+        if (active) {
+            int mv[4];
+            if (p.moves) {
+                const int4 m = reinterpret_cast<const int4*>(p.moves)[e];
+                mv[0] = m.x; mv[1] = m.y; mv[2] = m.z; mv[3] = m.w;
+            } else {
+                pom_rng_moves(p.seed, (uint32_t)(p.env_offset + e), p.tick0 + (uint32_t)tk, p.dist, mv);
+            }
+            const uint32_t ub_before = L.ub;
+            L.ub = 0;
+            stepper.step(mv);
+            new_ub = L.ub != 0;
+            L.ub |= ub_before;
+            if (env_mode) {
+                time_step++;
+                status = pom_env_epilogue(L, time_step, p.max_steps, status);
+                newly_done = (status & POM_ST_DONE) != 0;
+            }
+        }
+        c_steps += __popcll(__ballot(active));
+        c_episodes += __popcll(__ballot(newly_done));
+        c_ub += __popcll(__ballot(new_ub));
+    }
+
+    /* write back */
+#pragma unroll 8
+    for (int r = 0; r < 61; r++) col[(POM_REC_BOARD + r) * np] = t[(ROW_BOARD + r) * 64];
+    col[POM_REC_TIMESTEP * np] = (uint32_t)time_step;
+    col[POM_REC_META * np] = pom_lane_meta(L);
+    col[POM_REC_META2 * np] = pom_lane_meta2(L, status);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        col[(POM_REC_AGENTS + 2 * i) * np] = (uint32_t)L.a0[i];
+        col[(POM_REC_AGENTS + 2 * i + 1) * np] = (uint32_t)L.a1[i];
+    }
+#pragma unroll 10
+    for (int r = 0; r < 20; r++) col[(POM_REC_BOMBS + r) * np] = t[(ROW_BOMBS + r) * 64];
+#pragma unroll 10
+    for (int r = 0; r < 20; r++) col[(POM_REC_FLAMES + r) * np] = t[(ROW_FLAMES + r) * 64];
+
+    if (lane == 0) { /* each wavefront owns its slot: no atomics on the tick path */
+        int64_t* wc = p.wave_counters + (int64_t)blockIdx.x * POM_CNT_N;
+        wc[POM_CNT_STEPS] += c_steps;
+        wc[POM_CNT_EPISODES] += c_episodes;
+        wc[POM_CNT_RESETS] += c_resets;
+        wc[POM_CNT_UB_TICKS] += c_ub;
+    }
+}
+
+/* ---- boundary kernels ----------------------------------------------------------------------- */
+__global__ void pom_pack_kernel(const int32_t* __restrict__ aos, int64_t first, int64_t count, uint32_t* state, uint32_t* snap,
+                                int64_t np, int* first_bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t* col = state + first + i;
+    int bad = pom_pack_state(aos + i * (POM_STATE_BYTES / 4), col, np);
+    /* live bombs must sit on the board and belong to a real agent: they index cells and agents */
+    {
+        const uint32_t m = col[POM_REC_META * np];
+        const int bIdx = (m >> 8) & 0xFF, bCnt = (m >> 16) & 0xFF;
+        if (!bad) {
+            for (int k = 0; k < bCnt; k++) {
+                const int b = (int)col[(POM_REC_BOMBS + (bIdx + k) % POM_Q) * np];
+                bad |= (pb_x(b) >= POM_N) | (pb_y(b) >= POM_N) | (pb_id(b) >= POM_AGENT_COUNT);
+            }
+        }
+    }
+    if (bad) {
+        atomicMin(first_bad, (int)(i > INT_MAX - 1 ? INT_MAX - 1 : i));
+        for (int d = 0; d < POM_REC_DWORDS; d++) col[d * np] = 0; /* inert blank board ... */
+        col[POM_REC_META2 * np] = (uint32_t)POM_ST_DONE << 8;     /* ... that is never stepped in ENV mode */
+    }
+    uint32_t* s = snap + first + i;
+    for (int d = 0; d < POM_REC_DWORDS; d++) s[d * np] = col[d * np];
+}
+
+__global__ void pom_unpack_kernel(const uint32_t* __restrict__ state, int64_t first, int64_t count, int64_t np, int32_t* aos)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    pom_unpack_state(state + first + i, np, aos + i * (POM_STATE_BYTES / 4));
+}
+
+/* out: 6 arrays of `count` int32: done, winner, draw, alive, timeStep, ubflags */
+__global__ void pom_status_kernel(const uint32_t* __restrict__ state, int64_t first, int64_t count, int64_t np, int32_t* out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t* col = state + first + i;
+    const uint32_t m = col[POM_REC_META * np], m2 = col[POM_REC_META2 * np];
+    const uint32_t st = (m2 >> 8) & 0xFF;
+    out[0 * count + i] = (st & POM_ST_DONE) ? 1 : 0;
+    out[1 * count + i] = (int)((st >> POM_ST_WINNER_SHIFT) & 7) - 1;
+    out[2 * count + i] = (st & POM_ST_DRAW) ? 1 : 0;
+    out[3 * count + i] = pom_sext8(m);
+    out[4 * count + i] = (int32_t)col[POM_REC_TIMESTEP * np];
+    out[5 * count + i] = (int32_t)(m2 >> 16);
+}
+
+__global__ void pom_snapshot_kernel(const uint32_t* __restrict__ state, uint32_t* snap, int64_t np)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= np) return;
+    for (int d = 0; d < POM_REC_DWORDS; d++) {
+        uint32_t v = state[d * np + e];
+        if (d == POM_REC_META2) v &= 0xFFu; /* a snapshot starts an episode: status and flags clear */
+        snap[d * np + e] = v;
+    }
+}
+
+__global__ void pom_reduce_counters_kernel(const int64_t* __restrict__ wc, int64_t n_waves, int64_t* out)
+{
+    __shared__ long long part[POM_CNT_N][256];
+    long long acc[POM_CNT_N] = {0, 0, 0, 0};
+    for (int64_t w = threadIdx.x; w < n_waves; w += blockDim.x)
+        for (int k = 0; k < POM_CNT_N; k++) acc[k] += wc[w * POM_CNT_N + k];
+    for (int k = 0; k < POM_CNT_N; k++) part[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int k = 0; k < POM_CNT_N; k++) part[k][threadIdx.x] += part[k][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < POM_CNT_N) out[threadIdx.x] = part[threadIdx.x][0];
+}
+
+/* ---- host side: the C-ABI --------------------------------------------------------------------- */
+static thread_local char g_err[256] = "";
+static void set_err(const char* what, hipError_t e)
+{
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+}
+#define HIPCHK(call)                      \
+    do {                                  \
+        hipError_t e_ = (call);           \
+        if (e_ != hipSuccess) {           \
+            set_err(#call, e_);           \
+            return POM_E_HIP;             \
+        }                                 \
+    } while (0)
+
+struct PomBatch {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n = 0, n_pad = 0, n_waves = 0, env_offset = 0;
+    int mode = POM_MODE_ENV, auto_reset = 0, max_steps = 0;
+    uint32_t* state = nullptr;
+    uint32_t* snap = nullptr;
+    int32_t* moves_dev = nullptr;   /* n_pad x 4 */
+    int32_t* staging = nullptr;     /* staging_envs x 251 dwords (AoS), also status scratch */
+    int64_t staging_envs = 0;
+    int64_t* wave_counters = nullptr;
+    int64_t* totals_dev = nullptr;
+    int* first_bad = nullptr;
+    uint64_t tick = 0;
+};
+
+extern "C" {
+
+const char* pom_last_error(void) { return g_err; }
+
+int pom_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pom_batch_destroy(PomBatch* h)
+{
+    if (!h) return POM_E_ARG;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->state);
+    (void)hipFree(h->snap);
+    (void)hipFree(h->moves_dev);
+    (void)hipFree(h->staging);
+    (void)hipFree(h->wave_counters);
+    (void)hipFree(h->totals_dev);
+    (void)hipFree(h->first_bad);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return POM_OK;
+}
+
+int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts)
+{
+    if (!out || n_envs <= 0 || n_envs > (int64_t)1 << 30) {
+        snprintf(g_err, sizeof g_err, "pom_batch_create: bad arguments");
+        return POM_E_ARG;
+    }
+    *out = nullptr;
+    PomBatchOptions o;
+    memset(&o, 0, sizeof o);
+    o.mode = POM_MODE_ENV;
+    if (opts) {
+        if (opts->struct_size <= 0 || opts->struct_size > (int)sizeof o) {
+            snprintf(g_err, sizeof g_err, "pom_batch_create: options struct_size %d not understood", opts->struct_size);
+            return POM_E_ARG;
+        }
+        memcpy(&o, opts, (size_t)opts->struct_size);
+    }
+    if (o.mode != POM_MODE_RAW && o.mode != POM_MODE_ENV) {
+        snprintf(g_err, sizeof g_err, "pom_batch_create: bad mode %d", o.mode);
+        return POM_E_ARG;
+    }
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (o.device < 0 || o.device >= ndev) {
+        snprintf(g_err, sizeof g_err, "pom_batch_create: device %d of %d", o.device, ndev);
+        return POM_E_HIP;
+    }
+    HIPCHK(hipSetDevice(o.device));
+    PomBatch* h = new (std::nothrow) PomBatch();
+    if (!h) return POM_E_NOMEM;
+    h->device = o.device;
+    h->n = n_envs;
+    h->n_pad = (n_envs + 63) / 64 * 64;
+    h->n_waves = h->n_pad / 64;
+    h->mode = o.mode;
+    h->auto_reset = o.auto_reset;
+    h->max_steps = o.max_steps;
+    h->env_offset = o.env_offset;
+    h->staging_envs = h->n_pad < 16384 ? h->n_pad : 16384;
+#define ALLOC(ptr, bytes)                                              \
+    do {                                                               \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (size_t)(bytes));    \
+        if (e_ != hipSuccess) {                                        \
+            set_err("hipMalloc", e_);                                  \
+            pom_batch_destroy(h);                                      \
+            return e_ == hipErrorOutOfMemory ? POM_E_NOMEM : POM_E_HIP; \
+        }                                                              \
+    } while (0)
+    if (o.stream) {
+        h->stream = (hipStream_t)o.stream;
+    } else {
+        hipError_t e_ = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e_ != hipSuccess) {
+            set_err("hipStreamCreate", e_);
+            delete h;
+            return POM_E_HIP;
+        }
+        h->own_stream = true;
+    }
+    const size_t rec_bytes = (size_t)POM_REC_DWORDS * 4 * (size_t)h->n_pad;
+    ALLOC(h->state, rec_bytes);
+    ALLOC(h->snap, rec_bytes);
+    ALLOC(h->moves_dev, (size_t)h->n_pad * 16);
+    ALLOC(h->staging, (size_t)h->staging_envs * POM_STATE_BYTES);
+    ALLOC(h->wave_counters, (size_t)h->n_waves * POM_CNT_N * 8);
+    ALLOC(h->totals_dev, POM_CNT_N * 8);
+    ALLOC(h->first_bad, sizeof(int));
+#undef ALLOC
+    /* all-zero records are inert blank boards; padded envs are marked finished */
+    hipError_t e1 = hipMemsetAsync(h->state, 0, rec_bytes, h->stream);
+    hipError_t e2 = hipMemsetAsync(h->snap, 0, rec_bytes, h->stream);
+    hipError_t e3 = hipMemsetAsync(h->moves_dev, 0, (size_t)h->n_pad * 16, h->stream);
+    hipError_t e4 = hipMemsetAsync(h->wave_counters, 0, (size_t)h->n_waves * POM_CNT_N * 8, h->stream);
+    hipError_t e5 = hipStreamSynchronize(h->stream);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
+        set_err("initial memset", e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4 != hipSuccess ? e4 : e5);
+        pom_batch_destroy(h);
+        return POM_E_HIP;
+    }
+    *out = h;
+    return POM_OK;
+}
+
+int64_t pom_batch_size(const PomBatch* h) { return h ? h->n : -1; }
+
+static int check_range(const PomBatch* h, int64_t first, int64_t count)
+{
+    if (!h || first < 0 || count < 0 || first + count > h->n) {
+        snprintf(g_err, sizeof g_err, "range [%lld, %lld) outside batch", (long long)first, (long long)(first + count));
+        return POM_E_ARG;
+    }
+    return POM_OK;
+}
+
+int pom_batch_upload(PomBatch* h, const void* states, int64_t first, int64_t count)
+{
+    int rc = check_range(h, first, count);
+    if (rc || !states) return rc ? rc : POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    const int big = INT_MAX;
+    HIPCHK(hipMemcpyAsync(h->first_bad, &big, sizeof big, hipMemcpyHostToDevice, h->stream));
+    int64_t bad_env = -1;
+    for (int64_t off = 0; off < count; off += h->staging_envs) {
+        const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
+        HIPCHK(hipMemcpyAsync(h->staging, (const char*)states + off * POM_STATE_BYTES, (size_t)c * POM_STATE_BYTES,
+                              hipMemcpyHostToDevice, h->stream));
+        pom_pack_kernel<<<dim3((unsigned)((c + 63) / 64)), dim3(64), 0, h->stream>>>(h->staging, first + off, c, h->state, h->snap,
+                                                                                     h->n_pad, h->first_bad);
+        HIPCHK(hipGetLastError());
+        int fb = 0;
+        HIPCHK(hipMemcpyAsync(&fb, h->first_bad, sizeof fb, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream)); /* staging is reused by the next chunk */
+        if (fb != big && bad_env < 0) {
+            bad_env = first + off + fb;
+            HIPCHK(hipMemcpyAsync(h->first_bad, &big, sizeof big, hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    if (bad_env >= 0) {
+        snprintf(g_err, sizeof g_err, "pom_batch_upload: env %lld holds a value outside the representable game states "
+                 "(it was replaced by a finished blank board)", (long long)bad_env);
+        return POM_E_UNREPRESENTABLE;
+    }
+    return POM_OK;
+}
+
+int pom_batch_download(PomBatch* h, void* states, int64_t first, int64_t count)
+{
+    int rc = check_range(h, first, count);
+    if (rc || !states) return rc ? rc : POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    for (int64_t off = 0; off < count; off += h->staging_envs) {
+        const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
+        HIPCHK(hipMemsetAsync(h->staging, 0, (size_t)c * POM_STATE_BYTES, h->stream));
+        pom_unpack_kernel<<<dim3((unsigned)((c + 63) / 64)), dim3(64), 0, h->stream>>>(h->state, first + off, c, h->n_pad, h->staging);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync((char*)states + off * POM_STATE_BYTES, h->staging, (size_t)c * POM_STATE_BYTES, hipMemcpyDeviceToHost,
+                              h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return POM_OK;
+}
+
+int pom_batch_snapshot(PomBatch* h)
+{
+    if (!h) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    pom_snapshot_kernel<<<dim3((unsigned)((h->n_pad + 255) / 256)), dim3(256), 0, h->stream>>>(h->state, h->snap, h->n_pad);
+    HIPCHK(hipGetLastError());
+    return POM_OK;
+}
+
+static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int dist, int ticks)
+{
+    StepParams p;
+    p.state = h->state;
+    p.snap = h->snap;
+    p.moves = moves_dev;
+    p.wave_counters = h->wave_counters;
+    p.n = h->n;
+    p.n_pad = h->n_pad;
+    p.env_offset = h->env_offset;
+    p.seed = seed;
+    p.tick0 = (uint32_t)h->tick;
+    p.dist = dist;
+    p.ticks = ticks;
+    p.mode = h->mode;
+    p.auto_reset = h->auto_reset;
+    p.max_steps = h->max_steps;
+    pom_step_kernel<<<dim3((unsigned)h->n_waves), dim3(64), 0, h->stream>>>(p);
+    HIPCHK(hipGetLastError());
+    return POM_OK;
+}
+
+int pom_batch_step_device(PomBatch* h, const int32_t* moves_dev)
+{
+    if (!h || !moves_dev) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    return launch_step(h, moves_dev, 0, 0, 1);
+}
+
+int pom_batch_step(PomBatch* h, const int32_t* moves_host)
+{
+    if (!h || !moves_host) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->moves_dev, moves_host, (size_t)h->n * 16, hipMemcpyHostToDevice, h->stream));
+    return launch_step(h, h->moves_dev, 0, 0, 1);
+}
+
+int pom_batch_step_random(PomBatch* h, uint64_t seed, int32_t dist, int32_t ticks, int32_t ticks_per_launch)
+{
+    if (!h || ticks < 0 || ticks_per_launch < 1 || dist < POM_DIST_HARMLESS || dist > POM_DIST_STRESS) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    for (int32_t done = 0; done < ticks;) {
+        const int32_t t = ticks - done < ticks_per_launch ? ticks - done : ticks_per_launch;
+        int rc = launch_step(h, nullptr, seed, dist, t);
+        if (rc) return rc;
+        h->tick += (uint64_t)t;
+        done += t;
+    }
+    return POM_OK;
+}
+
+int pom_batch_set_tick(PomBatch* h, int64_t tick)
+{
+    if (!h || tick < 0) return POM_E_ARG;
+    h->tick = (uint64_t)tick;
+    return POM_OK;
+}
+
+int pom_batch_status(PomBatch* h, int64_t first, int64_t count, int32_t* done, int32_t* winner, int32_t* draw, int32_t* alive,
+                     int32_t* time_step, uint32_t* ubflags)
+{
+    int rc = check_range(h, first, count);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    void* outs[6] = {done, winner, draw, alive, time_step, ubflags};
+    /* the AoS staging buffer doubles as scratch: 6 ints per env << 251 */
+    for (int64_t off = 0; off < count; off += h->staging_envs) {
+        const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
+        pom_status_kernel<<<dim3((unsigned)((c + 255) / 256)), dim3(256), 0, h->stream>>>(h->state, first + off, c, h->n_pad, h->staging);
+        HIPCHK(hipGetLastError());
+        for (int k = 0; k < 6; k++)
+            if (outs[k])
+                HIPCHK(hipMemcpyAsync((int32_t*)outs[k] + off, h->staging + (int64_t)k * c, (size_t)c * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return POM_OK;
+}
+
+int pom_batch_counters_device(PomBatch* h, void* dev_int64x4)
+{
+    if (!h || !dev_int64x4) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    pom_reduce_counters_kernel<<<dim3(1), dim3(256), 0, h->stream>>>(h->wave_counters, h->n_waves, (int64_t*)dev_int64x4);
+    HIPCHK(hipGetLastError());
+    return POM_OK;
+}
+
+int pom_batch_counters(PomBatch* h, int64_t out[POM_CNT_N])
+{
+    if (!h || !out) return POM_E_ARG;
+    int rc = pom_batch_counters_device(h, h->totals_dev);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, h->totals_dev, POM_CNT_N * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return POM_OK;
+}
+
+int pom_batch_reset_counters(PomBatch* h)
+{
+    if (!h) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemsetAsync(h->wave_counters, 0, (size_t)h->n_waves * POM_CNT_N * 8, h->stream));
+    return POM_OK;
+}
+
+int pom_batch_sync(PomBatch* h)
+{
+    if (!h) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return POM_OK;
+}
+
+int pom_batch_device_view(PomBatch* h, void** base, int64_t* n_pad, int32_t* rec_dwords)
+{
+    if (!h) return POM_E_ARG;
+    if (base) *base = h->state;
+    if (n_pad) *n_pad = h->n_pad;
+    if (rec_dwords) *rec_dwords = POM_REC_DWORDS;
+    return POM_OK;
+}
+
+int pom_step(void* state_1004, const int32_t moves[4])
+{
+    static std::mutex mu;
+    static PomBatch* one = nullptr;
+    if (!state_1004 || !moves) return POM_E_ARG;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!one) {
+        PomBatchOptions o;
+        memset(&o, 0, sizeof o);
+        o.struct_size = sizeof o;
+        o.mode = POM_MODE_RAW;
+        int rc = pom_batch_create(&one, 1, &o);
+        if (rc) return rc;
+    }
+    int rc = pom_batch_upload(one, state_1004, 0, 1);
+    if (rc) return rc;
+    rc = pom_batch_step(one, moves);
+    if (rc) return rc;
+    return pom_batch_download(one, state_1004, 0, 1);
+}
+
+} /* extern "C" */

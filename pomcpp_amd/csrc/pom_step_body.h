@@ -1,0 +1,651 @@
+/*
+ * pom_step_body.h — one simulation tick for ONE env, written against an
+ * abstract per-lane store `A` so the identical source runs
+ *   - on gfx950 with A = a column of the wavefront's LDS tile (pom_kernels.hip), and
+ *   - on the host with A = a plain array, ONLY inside tests/ (tests/emul), to fuzz
+ *     the kernel's logic against the oracle without a GPU.  It is never a product
+ *     CPU path: the shipped library has no host stepper.
+ *
+ * Semantics = the reference's `bboard::Step` (/root/reference/src/bboard/step.cpp:9-284)
+ * with its helpers (step_utility.cpp, bboard.cpp State methods); every function
+ * cites what it reproduces.  The design is MI355X-shaped rather than a translation:
+ *   - lane = env; the wavefront executes the sequential tick 64 envs wide, loops run to
+ *     the wave-wide maximum trip count under EXEC masking and whole phases are skipped
+ *     when no lane needs them (hipcc emits s_cbranch_execz for the `if`s below);
+ *   - the 4 agents live in VGPRs (A0/A1 words, accessed by 4-way selects, never by a
+ *     runtime-indexed array, which would go to scratch);
+ *   - destinations, moves and the dependency chain are nibble-packed into single
+ *     registers so that "dynamic indexing" is a shift;
+ *   - the recursive chain explosion (bboard.cpp:24-57,111-118,198-263) is an explicit
+ *     frame stack in LDS (<= 21 frames), the tail-recursive bounce-back chain
+ *     (step_utility.cpp:62-128) a bounded loop;
+ *   - board cells are the 16-bit codes of pom_packed.h, bombs the reference's raw
+ *     bit-packed ints, flames one dword each.
+ *
+ * Store interface A (all indices per lane):
+ *   int  cell(int c) / void set_cell(int c, int code)      c = y*11+x, 16-bit codes
+ *   int  bomb(int slot) / void set_bomb(int slot, int v)    physical queue slot 0..19
+ *   int  flame(int slot) / void set_flame(int slot, int v)  packed x|y<<8|time<<16|strength<<24
+ *   int  bdest(int i) / void set_bdest(int i, int v)        byte: snapshot of bomb destinations
+ *   int  frame(int d) / void set_frame(int d, int v)        explosion stack
+ */
+#ifndef POM_STEP_BODY_H_
+#define POM_STEP_BODY_H_
+
+#include "pom_packed.h"
+
+#define POM_N 11
+#define POM_Q 20
+#define POM_STACK_DEPTH 21 /* one frame per queued bomb + the initiating flame */
+
+struct PomLane { /* the register-resident part of one env */
+    int a0[4];   /* x:8 | y:8 | bombCount:8 | canKick@24 | dead@25 — only ever indexed statically */
+    int a1[4];   /* maxBombCount:16 | bombStrength:16 */
+    int alive, bIdx, bCnt, fIdx, fCnt;
+    uint32_t ub;
+};
+
+/* ---- cell-code predicates (Item helpers, bboard.hpp:73-109, on 16-bit codes) */
+POM_HD int pc_is_wood(int e) { return (e >> 8) == 2; }
+POM_HD int pc_is_powerup(int e) { return e > 5 && e < 9; }
+POM_HD int pc_is_walkable(int e) { return pc_is_powerup(e) || e == 0; }
+POM_HD int pc_is_flame(int e) { return (e & 0xC000) == POM_C_FLAME; }
+POM_HD int pc_is_agent(int e) { return e >= POM_C_AGENT; }
+POM_HD int pc_is_static_block(int e) { return pc_is_wood(e) || pc_is_powerup(e) || e == 1; }
+POM_HD int pc_flag_item(int f) { return f == 0 ? 0 : f + 5; } /* FlagItem, bboard.cpp:182-189: 1,2,3 -> 6,7,8 */
+
+/* ---- bomb word (bboard.hpp:261-335) */
+POM_HD int pb_x(int b) { return b & 0xF; }
+POM_HD int pb_y(int b) { return (b >> 4) & 0xF; }
+POM_HD int pb_pos(int b) { return b & 0xFF; }
+POM_HD int pb_id(int b) { return (b >> 8) & 0xF; }
+POM_HD int pb_strength(int b) { return (b >> 12) & 0xF; }
+POM_HD int pb_time(int b) { return (b >> 16) & 0xF; }
+POM_HD int pb_dir(int b) { return (b >> 20) & 0xF; }
+POM_HD int pb_set(int b, uint32_t mask, uint32_t v) { return (int)(((uint32_t)b & ~mask) + v); }
+
+/* ---- 4-way register selects for the agents */
+POM_HD int sel4(int i, const int v[4]) { return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3]; }
+POM_HD void put4(int i, int v[4], int x)
+{
+    v[0] = i == 0 ? x : v[0];
+    v[1] = i == 1 ? x : v[1];
+    v[2] = i == 2 ? x : v[2];
+    v[3] = i == 3 ? x : v[3];
+}
+POM_HD int ag_x(int a0) { return a0 & 0xFF; }
+POM_HD int ag_y(int a0) { return (a0 >> 8) & 0xFF; }
+POM_HD int ag_dead(int a0) { return (a0 >> 25) & 1; }
+POM_HD int ag_kick(int a0) { return (a0 >> 24) & 1; }
+POM_HD int ag_setpos(int a0, int x, int y) { return (a0 & ~0xFFFF) | x | (y << 8); }
+POM_HD int ag_bombcount_add(int a0, int d) { return (a0 & ~0xFF0000) | ((a0 + (d << 16)) & 0xFF0000); }
+
+POM_HD int wrap20(int p) { return p >= POM_Q ? p - POM_Q : p; } /* p < 40 */
+POM_HD int oob(int x, int y) { return (unsigned)x >= (unsigned)POM_N || (unsigned)y >= (unsigned)POM_N; }
+
+/* displacement of a Move / Direction (step_utility.cpp:9-31): 1 up(-y) 2 down(+y) 3 left(-x) 4 right(+x) */
+POM_HD int mv_dx(int m) { return m == 4 ? 1 : m == 3 ? -1 : 0; }
+POM_HD int mv_dy(int m) { return m == 2 ? 1 : m == 1 ? -1 : 0; }
+
+template <class A>
+struct PomStepper {
+    A& a;
+    PomLane& L;
+    POM_HD PomStepper(A& a_, PomLane& l_) : a(a_), L(l_) {}
+
+    POM_HD int bomb_at(int i) const { return a.bomb(wrap20(L.bIdx + i)); }
+    POM_HD void set_bomb_at(int i, int v) { a.set_bomb(wrap20(L.bIdx + i), v); }
+
+    /* first queue offset whose bomb sits on pos (x | y<<4), or -1:
+     * HasBomb / GetBomb / GetBombIndex, bboard.cpp:265-311 */
+    POM_HD int bomb_index(int pos) const
+    {
+        int r = -1;
+        for (int i = 0; i < L.bCnt; i++) {
+            if (pb_pos(bomb_at(i)) == pos) {
+                r = i;
+                break;
+            }
+        }
+        return r;
+    }
+
+    POM_HD int get_agent(int x, int y) const /* bboard.cpp:289-299 */
+    {
+        const int want = x | (y << 8);
+        int r = -1;
+#pragma unroll
+        for (int i = 3; i >= 0; i--)
+            r = (!ag_dead(L.a0[i]) && (L.a0[i] & 0xFFFF) == want) ? i : r;
+        return r;
+    }
+
+    POM_HD void kill(int id) /* State::Kill, bboard.hpp:474-481 */
+    {
+        if (id >= POM_AGENT_COUNT) {
+            L.ub |= POM_UB_BAD_INDEX;
+            return;
+        }
+        int v = sel4(id, L.a0);
+        if (!ag_dead(v)) {
+            put4(id, L.a0, v | (1 << 25));
+            L.alive--;
+        }
+    }
+
+    POM_HD void owner_bombcount_dec(int b)
+    {
+        int id = pb_id(b);
+        if (id >= POM_AGENT_COUNT) {
+            L.ub |= POM_UB_BAD_INDEX;
+            return;
+        }
+        put4(id, L.a0, ag_bombcount_add(sel4(id, L.a0), -1));
+    }
+
+    POM_HD void remove_at(int at) /* FixedQueue::RemoveAt, bboard.hpp:151-160 */
+    {
+        for (int i = at + 1; i < L.bCnt; i++)
+            set_bomb_at(i - 1, bomb_at(i));
+        L.bCnt--;
+    }
+
+    /* ------------------------------------------------------------------ *
+     * Explosions.  A frame is one SpawnFlame activation (bboard.cpp:198-263):
+     *   x:4 | y:4 | s:4 (ray length, clamped to 11) | dir:3 | i:4 | resume:1 | rem:6
+     * rem = queue offset handed to ExplodeBombAt (bboard.cpp:111-118) whose
+     * bookkeeping runs when the frame finishes, POM_REM_TOP for the queue top
+     * (ExplodeTopBomb + PopBomb, bboard.cpp:93-97,191-196).
+     * ------------------------------------------------------------------ */
+    enum { POM_REM_TOP = 62, POM_REM_NONE = 63 };
+
+    POM_HD static int fr_make(int x, int y, int s, int dir, int i, int resume, int rem)
+    {
+        return x | (y << 4) | (s << 8) | (dir << 12) | (i << 15) | (resume << 19) | (rem << 20);
+    }
+
+    /* SpawnFlame prologue (bboard.cpp:200-218) + push */
+    POM_HD int begin_flame(int sp, int x, int y, int strength, int rem)
+    {
+        if (sp >= POM_STACK_DEPTH) { /* cannot happen with <= 20 queued bombs; never overrun the frame rows */
+            L.ub |= POM_UB_BAD_INDEX;
+            return sp;
+        }
+        a.set_flame((L.fIdx + L.fCnt) % POM_Q, x | (y << 8) | (POM_FLAME_LIFETIME << 16) | ((strength & 0xFF) << 24));
+        L.fCnt++;
+        const int c = y * POM_N + x;
+        const int e = a.cell(c);
+        if (pc_is_agent(e)) kill(e & 0x3FFF);
+        a.set_cell(c, POM_C_FLAME | (c << 3));
+        const int s = strength < 0 ? 0 : strength > POM_N ? POM_N : strength;
+        a.set_frame(sp, fr_make(x, y, s, 0, 1, 0, rem));
+        return sp + 1;
+    }
+
+    POM_HD void run_explosions(int sp)
+    {
+        while (sp > 0) {
+            const int fr = a.frame(sp - 1);
+            const int x = fr & 0xF, y = (fr >> 4) & 0xF, s = (fr >> 8) & 0xF;
+            int dir = (fr >> 12) & 7, i = (fr >> 15) & 0xF;
+            const int resume = (fr >> 19) & 1, rem = (fr >> 20) & 63;
+            if (dir >= 4) { /* all four rays done: the caller's bookkeeping */
+                if (rem == POM_REM_TOP) {
+                    owner_bombcount_dec(bomb_at(0));
+                    L.bIdx = wrap20(L.bIdx + 1);
+                    L.bCnt--;
+                } else if (rem != POM_REM_NONE) {
+                    /* slot re-read after the nested chain: stale index, SURVEY Q2 */
+                    owner_bombcount_dec(bomb_at(rem));
+                    remove_at(rem);
+                }
+                sp--;
+                continue;
+            }
+            /* ray order +x, -x, +y, -y (bboard.cpp:220-262) */
+            const int cx = x + (dir == 0 ? i : dir == 1 ? -i : 0);
+            const int cy = y + (dir == 2 ? i : dir == 3 ? -i : 0);
+            if (i > s || oob(cx, cy)) {
+                a.set_frame(sp - 1, fr_make(x, y, s, dir + 1, 1, 0, rem));
+                continue;
+            }
+            const int c = cy * POM_N + cx;
+            if (!resume) { /* SpawnFlameItem head, bboard.cpp:26-40 */
+                const int e = a.cell(c);
+                if (pc_is_agent(e)) kill(e & 0x3FFF);
+                if (e == POM_C_BOMB || pc_is_agent(e)) {
+                    const int j = bomb_index(cx | (cy << 4));
+                    if (j >= 0) {
+                        a.set_frame(sp - 1, fr_make(x, y, s, dir, i, 1, rem));
+                        /* ExplodeBombAt: the owner's CURRENT strength */
+                        const int owner = pb_id(bomb_at(j));
+                        int strength = 0;
+                        if (owner < POM_AGENT_COUNT) strength = (sel4(owner, L.a1) >> 16) & 0xFFFF;
+                        else L.ub |= POM_UB_BAD_INDEX;
+                        sp = begin_flame(sp, cx, cy, strength, j);
+                        continue;
+                    }
+                }
+            }
+            /* SpawnFlameItem tail, bboard.cpp:42-56 (cell re-read after the nested chain) */
+            const int e = a.cell(c);
+            int go_on = 0;
+            if (e != POM_C_RIGID) {
+                const int was_wood = pc_is_wood(e);
+                a.set_cell(c, POM_C_FLAME | (((y * POM_N + x) << 3) + (was_wood ? (e & 3) : 0)));
+                go_on = !was_wood;
+            }
+            if (go_on) i++;
+            else { dir++; i = 1; }
+            a.set_frame(sp - 1, fr_make(x, y, s, dir, i, 0, rem));
+        }
+    }
+
+    /* ------------------------------------------------------------------ */
+    POM_HD void tick_flames() /* step_utility.cpp:208-222 + PopFlame bboard.cpp:148-180 */
+    {
+        if (L.fCnt <= 0) return;
+        for (int i = 0; i < L.fCnt; i++) {
+            const int p = (L.fIdx + i) % POM_Q;
+            const int f = a.flame(p);
+            a.set_flame(p, (f & ~0xFF0000) | ((f - 0x10000) & 0xFF0000));
+        }
+        const int n = L.fCnt;
+        for (int k = 0; k < n; k++) {
+            const int f = a.flame(L.fIdx);
+            if (((f >> 16) & 0xFF) != 0) continue;
+            const int x = f & 0xFF, y = (f >> 8) & 0xFF;
+            int s = (f >> 24) & 0xFF;
+            s = s > POM_N ? POM_N : s; /* cells further out are out of bounds anyway */
+            const int sig = x + POM_N * y;
+            for (int d = -s; d <= s; d++) {
+                if (!oob(x + d, y)) {
+                    const int c = y * POM_N + x + d, e = a.cell(c);
+                    if (pc_is_flame(e) && ((e & 0x3FFF) >> 3) == sig) a.set_cell(c, pc_flag_item(e & 3));
+                }
+                if (!oob(x, y + d)) {
+                    const int c = (y + d) * POM_N + x, e = a.cell(c);
+                    if (pc_is_flame(e) && ((e & 0x3FFF) >> 3) == sig) a.set_cell(c, pc_flag_item(e & 3));
+                }
+            }
+            L.fIdx = wrap20(L.fIdx + 1);
+            L.fCnt--;
+        }
+    }
+
+    /* AgentBombChainReversion, step_utility.cpp:62-128; mvp = moves, one nibble per agent */
+    POM_HD void chain_reversion(uint32_t mvp, int id)
+    {
+        for (int hop = 0;; hop++) {
+            if (hop >= 8) {
+                L.ub |= POM_UB_REVERT_LOOP;
+                return;
+            }
+            const int av = sel4(id, L.a0);
+            const int m = (mvp >> (4 * id)) & 0xF;
+            /* OriginPosition, step_utility.cpp:33-55: one step against the move */
+            const int ox = ag_x(av) - mv_dx(m), oy = ag_y(av) - mv_dy(m);
+            if (oob(ox, oy)) return;
+            const int origin_agent = get_agent(ox, oy);
+            const int okey = (ox + 1) | ((oy + 1) << 4);
+            int bd = -1;
+            for (int i = 0; i < L.bCnt; i++) {
+                if (a.bdest(i) == okey) {
+                    bd = i;
+                    break;
+                }
+            }
+            put4(id, L.a0, ag_setpos(av, ox, oy));
+            a.set_cell(oy * POM_N + ox, POM_C_AGENT | id);
+            if (origin_agent != -1) {
+                id = origin_agent;
+                continue;
+            }
+            if (bd != -1) {
+                const int b = bomb_at(bd);
+                const int dir = pb_dir(b);
+                if (mv_dx(dir) == 0 && mv_dy(dir) == 0) { /* bounced back onto a resting bomb */
+                    a.set_cell(oy * POM_N + ox, POM_C_AGENT | id);
+                    return;
+                }
+                const int bx = ox - mv_dx(dir), by = oy - mv_dy(dir);
+                if (oob(bx, by)) { /* reference would write outside the board (step_utility.cpp:111) */
+                    L.ub |= POM_UB_BAD_INDEX;
+                    return;
+                }
+                const int has_agent = get_agent(bx, by);
+                set_bomb_at(bd, pb_set(pb_set(b, 0xF00000u, 0), 0xFFu, (uint32_t)bx + ((uint32_t)by << 4)));
+                a.set_cell(by * POM_N + bx, POM_C_BOMB);
+                if (has_agent != -1) {
+                    id = has_agent;
+                    continue;
+                }
+            }
+            return;
+        }
+    }
+
+    POM_HD int bomb_target_key(int b) const /* DesiredPosition(Bomb), step_utility.cpp:57-60; (x+1)|(y+1)<<4 */
+    {
+        const int d = pb_dir(b);
+        return (pb_x(b) + mv_dx(d) + 1) | ((pb_y(b) + mv_dy(d) + 1) << 4);
+    }
+
+    /* HasBombCollision + ResolveBombCollision fused (step_utility.cpp:279-329): returns whether
+     * bomb k collided; if so the colliders (and k) are already idled and the kicker bounced */
+    POM_HD int bomb_collision(uint32_t mvp, int k)
+    {
+        const int b = bomb_at(k);
+        const int key = bomb_target_key(b);
+        int collided = 0;
+        for (int i = k; i < L.bCnt; i++) {
+            const int o = bomb_at(i);
+            if (o != b && bomb_target_key(o) == key) {
+                set_bomb_at(i, pb_set(o, 0xF00000u, 0));
+                collided = 1;
+            }
+        }
+        if (collided && pb_dir(b) != 0) {
+            const int nb = pb_set(b, 0xF00000u, 0);
+            set_bomb_at(k, nb);
+            const int ag = get_agent(pb_x(nb), pb_y(nb));
+            if (ag > -1) {
+                const int m = (mvp >> (4 * ag)) & 0xF;
+                if (m != POM_MOVE_IDLE && m != POM_MOVE_BOMB) {
+                    chain_reversion(mvp, ag);
+                    /* the bomb word is re-read: the chain may have moved this very bomb */
+                    const int cur = bomb_at(k);
+                    a.set_cell(pb_y(cur) * POM_N + pb_x(cur), POM_C_BOMB);
+                }
+            }
+        }
+        return collided;
+    }
+
+    /* ------------------------------------------------------------------ */
+    POM_HD void step(const int mv_in[4])
+    {
+        tick_flames(); /* step.cpp:15 */
+
+        /* moves: anything outside 0..5 acts as "no displacement, not IDLE, not BOMB" -> code 6 */
+        int mv[4];
+        uint32_t mvp = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            mv[i] = ((unsigned)mv_in[i] <= 5u) ? mv_in[i] : 6;
+            mvp |= (uint32_t)mv[i] << (4 * i);
+        }
+
+        /* FillPositions / FillDestPos / FixSwitchMove (step_utility.cpp:130-170); dead agents included */
+        int px[4], py[4], dx[4], dy[4];
+        uint32_t oldp = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            px[i] = ag_x(L.a0[i]);
+            py[i] = ag_y(L.a0[i]);
+            dx[i] = px[i] + mv_dx(mv[i]);
+            dy[i] = py[i] + mv_dy(mv[i]);
+            oldp |= (uint32_t)(px[i] | (py[i] << 4)) << (8 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int j = i; j < 4; j++) {
+                if (dx[i] == px[j] && dy[i] == py[j] && dx[j] == px[i] && dy[j] == py[i]) {
+                    dx[i] = px[i]; dy[i] = py[i];
+                    dx[j] = px[j]; dy[j] = py[j];
+                }
+            }
+        }
+        /* ResolveDependencies (step_utility.cpp:172-205); dependency / roots as nibbles, 0xF = -1 */
+        uint32_t dep = 0xFFFF, roots = 0xFFFF;
+        int nroots = 0;
+        int deadmask = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) deadmask |= ag_dead(L.a0[i]) << i;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int is_root = 1;
+            if (!((deadmask >> i) & 1)) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (j == i) continue;
+                    if (is_root && !((deadmask >> j) & 1) && dx[i] == px[j] && dy[i] == py[j]) {
+                        dep = (dep & ~(0xFu << (4 * j))) | ((uint32_t)i << (4 * j));
+                        is_root = 0;
+                    }
+                }
+            }
+            if (is_root) {
+                roots = (roots & ~(0xFu << (4 * nroots))) | ((uint32_t)i << (4 * nroots));
+                nroots++;
+            }
+        }
+        const int ouroboros = nroots == 0;
+        uint32_t dstp = 0; /* destinations as (x+1) | (y+1)<<4, one byte per agent */
+#pragma unroll
+        for (int i = 0; i < 4; i++) dstp |= (uint32_t)(((dx[i] + 1) & 0xF) | (((dy[i] + 1) & 0xF) << 4)) << (8 * i);
+
+        /* agent loop, step.cpp:35-185 */
+        {
+            int root_idx = 0;
+            int i = ouroboros ? 0 : (int)(roots & 0xF);
+            for (int n = 0; n < 4; n++) {
+                if (i == 0xF) {
+                    root_idx++;
+                    const int nx = root_idx < 4 ? (int)((roots >> (4 * root_idx)) & 0xF) : 0xF;
+                    if (nx == 0xF) { /* reference reads moves[-1] here: SURVEY Q-UB1 */
+                        L.ub |= POM_UB_LOST_AGENT;
+                        break;
+                    }
+                    i = nx;
+                }
+                const int m = (mvp >> (4 * i)) & 0xF;
+                const int av = sel4(i, L.a0);
+                const int next = (int)((dep >> (4 * i)) & 0xF);
+                if (ag_dead(av) || m == POM_MOVE_IDLE) {
+                    i = next;
+                    continue;
+                }
+                const int x = ag_x(av), y = ag_y(av);
+                if (m == POM_MOVE_BOMB) { /* PlantBombModifiedLife(x, y, i, 11), bboard.cpp:125-146 */
+                    const int a1v = sel4(i, L.a1);
+                    const int bomb_count = pom_sext8((uint32_t)av >> 16), max_bombs = pom_sext16((uint32_t)a1v);
+                    if (bomb_count < max_bombs) {
+                        if (L.bCnt >= POM_Q) {
+                            L.ub |= POM_UB_QUEUE_OVERFLOW; /* step.cpp:191 would overrun bombDestinations[20] */
+                        } else {
+                            const int slot = wrap20(L.bIdx + L.bCnt);
+                            int b = a.bomb(slot); /* stale bits of the slot survive: SURVEY Q1 */
+                            b = pb_set(b, 0xF00u, (uint32_t)i << 8);
+                            b = pb_set(b, 0xFFu, (uint32_t)x + ((uint32_t)y << 4));
+                            b = pb_set(b, 0xF000u, (uint32_t)((a1v >> 16) & 0xFFFF) << 12);
+                            b = pb_set(b, 0xF0000u, (uint32_t)(POM_BOMB_LIFETIME + 1) << 16);
+                            a.set_bomb(slot, b);
+                            put4(i, L.a0, ag_bombcount_add(av, 1));
+                            L.bCnt++;
+                        }
+                    }
+                    i = next;
+                    continue;
+                }
+                const int dkey = (dstp >> (8 * i)) & 0xFF;
+                const int ddx = (dkey & 0xF) - 1, ddy = (dkey >> 4) - 1;
+                if (oob(ddx, ddy)) {
+                    i = next;
+                    continue;
+                }
+                const int dc = ddy * POM_N + ddx;
+                int item = a.cell(dc);
+                if (ouroboros && bomb_index(ddx | (ddy << 4)) >= 0) item = POM_C_BOMB; /* step.cpp:71-82 */
+
+                if (pc_is_flame(item)) { /* step.cpp:84-99 */
+                    kill(i);
+                    deadmask |= 1 << i;
+                    const int oc = y * POM_N + x;
+                    if (a.cell(oc) == (POM_C_AGENT | i))
+                        a.set_cell(oc, bomb_index(x | (y << 4)) >= 0 ? POM_C_BOMB : POM_C_PASSAGE);
+                    i = next;
+                    continue;
+                }
+                /* HasDPCollision, step_utility.cpp:264-277 */
+                int collide = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    collide |= (j != i) & !((deadmask >> j) & 1) & (((dstp >> (8 * j)) & 0xFF) == (uint32_t)dkey);
+                if (collide) {
+                    i = next;
+                    continue;
+                }
+                if (pc_is_powerup(item)) { /* ConsumePowerup, step_utility.cpp:247-262 */
+                    if (item == POM_EXTRABOMB) {
+                        const int a1v = sel4(i, L.a1);
+                        put4(i, L.a1, (a1v & ~0xFFFF) | ((a1v + 1) & 0xFFFF));
+                    } else if (item == POM_INCRRANGE) {
+                        put4(i, L.a1, sel4(i, L.a1) + (1 << 16));
+                    } else {
+                        put4(i, L.a0, sel4(i, L.a0) | (1 << 24));
+                    }
+                    item = POM_C_PASSAGE;
+                }
+                const int oc = y * POM_N + x;
+                if (item == POM_C_PASSAGE || (ouroboros && pc_is_agent(item))) { /* step.cpp:120-140 */
+                    if (a.cell(oc) == (POM_C_AGENT | i))
+                        a.set_cell(oc, bomb_index(x | (y << 4)) >= 0 ? POM_C_BOMB : POM_C_PASSAGE);
+                    a.set_cell(dc, POM_C_AGENT | i);
+                    put4(i, L.a0, ag_setpos(sel4(i, L.a0), ddx, ddy));
+                } else if (item == POM_C_BOMB) { /* step.cpp:147-184: kicker and non-kicker both step on */
+                    a.set_cell(oc, bomb_index(x | (y << 4)) >= 0 ? POM_C_BOMB : POM_C_PASSAGE);
+                    a.set_cell(dc, POM_C_AGENT | i);
+                    const int cur = sel4(i, L.a0);
+                    put4(i, L.a0, ag_setpos(cur, ddx, ddy));
+                    if (ag_kick(cur)) {
+                        const int bi = bomb_index(ddx | (ddy << 4));
+                        if (bi < 0) L.ub |= POM_UB_NULL_BOMB; /* step.cpp:167 dereferences nullptr */
+                        else set_bomb_at(bi, pb_set(bomb_at(bi), 0xF00000u, (uint32_t)m << 20));
+                    }
+                }
+                i = next;
+            }
+        }
+
+        if (L.bCnt > 0) {
+            /* ResetBombFlags + FillBombDestPos, step_utility.cpp:331-337,146-152 */
+            for (int k = 0; k < L.bCnt; k++) {
+                const int b = pb_set(bomb_at(k), 0xF000000u, 0);
+                set_bomb_at(k, b);
+                a.set_bdest(k, bomb_target_key(b));
+            }
+            /* bomb loop A, step.cpp:195-227 */
+            for (int k = 0; k < L.bCnt; k++) {
+                const int b = bomb_at(k);
+                const int bx = pb_x(b), by = pb_y(b), d = pb_dir(b);
+                const int tx = bx + mv_dx(d), ty = by + mv_dy(d);
+                int blocked = oob(tx, ty);
+                if (!blocked) {
+                    const int e = a.cell(ty * POM_N + tx);
+                    blocked = pc_is_static_block(e) || pc_is_agent(e);
+                }
+                if (blocked) {
+                    set_bomb_at(k, pb_set(b, 0xF00000u, 0));
+                    const int ag = get_agent(bx, by);
+                    if (ag > -1) {
+                        const int m = (mvp >> (4 * ag)) & 0xF;
+                        const int av = sel4(ag, L.a0);
+                        const int was = (oldp >> (8 * ag)) & 0xFF;
+                        if (m != POM_MOVE_IDLE && m != POM_MOVE_BOMB && (ag_x(av) | (ag_y(av) << 4)) != was) {
+                            chain_reversion(mvp, ag);
+                            if (get_agent(bx, by) == -1) a.set_cell(by * POM_N + bx, POM_C_BOMB);
+                        }
+                    }
+                }
+            }
+            /* bomb loop B, step.cpp:230-278 */
+            for (int k = 0; k < L.bCnt; k++) {
+                int b = bomb_at(k);
+                if (pb_dir(b) == 0) {
+                    if (bomb_collision(mvp, k)) continue;
+                }
+                const int bx = pb_x(b), by = pb_y(b), d = pb_dir(b);
+                const int tx = bx + mv_dx(d), ty = by + mv_dy(d);
+                int free_way = !oob(tx, ty);
+                int tc = 0, te = 0;
+                if (free_way) {
+                    tc = ty * POM_N + tx;
+                    te = a.cell(tc);
+                    free_way = !pc_is_static_block(te);
+                }
+                if (free_way) {
+                    if (bomb_collision(mvp, k)) continue;
+                    b = bomb_at(k);
+                    set_bomb_at(k, pb_set(b, 0xFFu, (uint32_t)tx + ((uint32_t)ty << 4)));
+                    if (bomb_index(bx | (by << 4)) < 0 && a.cell(by * POM_N + bx) == POM_C_BOMB)
+                        a.set_cell(by * POM_N + bx, POM_C_PASSAGE);
+                    te = a.cell(tc);
+                    if (pc_is_walkable(te)) {
+                        a.set_cell(tc, POM_C_BOMB);
+                    } else if (pc_is_flame(te)) {
+                        /* ExplodeBombAt(GetBombIndex(target)), bboard.cpp:111-118 */
+                        const int j = bomb_index(tx | (ty << 4));
+                        const int jb = bomb_at(j);
+                        const int owner = pb_id(jb);
+                        int strength = 0;
+                        if (owner < POM_AGENT_COUNT) strength = (sel4(owner, L.a1) >> 16) & 0xFFFF;
+                        else L.ub |= POM_UB_BAD_INDEX;
+                        run_explosions(begin_flame(0, pb_x(jb), pb_y(jb), strength, j));
+                    }
+                } else {
+                    set_bomb_at(k, pb_set(b, 0xF00000u, 0));
+                }
+            }
+            /* TickBombs, step_utility.cpp:224-245 */
+            for (int k = 0; k < L.bCnt; k++)
+                set_bomb_at(k, (int)((uint32_t)bomb_at(k) - (1u << 16)));
+            const int n = L.bCnt;
+            for (int k = 0; k < n && L.bCnt > 0; k++) {
+                const int c = bomb_at(0);
+                if (pb_time(c) != 0) break;
+                run_explosions(begin_flame(0, pb_x(c), pb_y(c), pb_strength(c), POM_REM_TOP));
+            }
+        }
+    }
+};
+
+/* ---- record <-> lane registers ----------------------------------------- */
+POM_HD void pom_lane_load(PomLane& L, const uint32_t meta, const uint32_t meta2, const uint32_t* ag /* 8 dwords */)
+{
+    L.alive = pom_sext8(meta);
+    L.bIdx = (int)((meta >> 8) & 0xFF);
+    L.bCnt = (int)((meta >> 16) & 0xFF);
+    L.fIdx = (int)(meta >> 24);
+    L.fCnt = (int)(meta2 & 0xFF);
+    L.ub = meta2 >> 16;
+    for (int i = 0; i < 4; i++) {
+        L.a0[i] = (int)ag[2 * i];
+        L.a1[i] = (int)ag[2 * i + 1];
+    }
+}
+POM_HD uint32_t pom_lane_meta(const PomLane& L)
+{
+    return ((uint32_t)L.alive & 0xFF) | ((uint32_t)L.bIdx << 8) | ((uint32_t)L.bCnt << 16) | ((uint32_t)L.fIdx << 24);
+}
+POM_HD uint32_t pom_lane_meta2(const PomLane& L, uint32_t status)
+{
+    return ((uint32_t)L.fCnt & 0xFF) | ((status & 0xFF) << 8) | ((L.ub & 0xFFFF) << 16);
+}
+
+/* Environment::Step's bookkeeping after bboard::Step (environment.cpp:150-168); returns the new status byte */
+POM_HD uint32_t pom_env_epilogue(const PomLane& L, int time_step_after, int max_steps, uint32_t status)
+{
+    if (L.alive == 1) {
+        int w = 0;
+        for (int i = 0; i < 4; i++)
+            if (!ag_dead(L.a0[i])) w = i; /* last alive index wins, as the reference's loop leaves it */
+        status |= POM_ST_DONE | ((uint32_t)(w + 1) << POM_ST_WINNER_SHIFT);
+    }
+    if (L.alive == 0) status |= POM_ST_DONE | POM_ST_DRAW;
+    if (max_steps > 0 && time_step_after >= max_steps) status |= POM_ST_DONE | POM_ST_TIMEOUT;
+    return status;
+}
+
+#endif /* POM_STEP_BODY_H_ */

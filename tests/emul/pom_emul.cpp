@@ -1,0 +1,79 @@
+/*
+ * pom_emul.cpp — TEST-ONLY host build of the device tick (pomcpp_amd/csrc/pom_step_body.h)
+ * over a plain-array store, so the kernel's logic can be fuzzed against the oracle in a
+ * container without a GPU.  Lives under tests/ and is never linked into libpom_batch.so:
+ * the product has no CPU stepper.
+ */
+#include <cstring>
+
+#include "pom_packed.h"
+#include "pom_step_body.h"
+
+struct ArrayEnv {
+    uint16_t cells[122];
+    int bombs[20], flames[20], stack[POM_STACK_DEPTH];
+    uint8_t bd[20];
+    int cell(int c) const { return cells[c]; }
+    void set_cell(int c, int v) { cells[c] = (uint16_t)v; }
+    int bomb(int s) const { return bombs[s]; }
+    void set_bomb(int s, int v) { bombs[s] = v; }
+    int flame(int s) const { return flames[s]; }
+    void set_flame(int s, int v) { flames[s] = v; }
+    int bdest(int i) const { return bd[i]; }
+    void set_bdest(int i, int v) { bd[i] = (uint8_t)v; }
+    int frame(int d) const { return stack[d]; }
+    void set_frame(int d, int v) { stack[d] = v; }
+};
+
+extern "C" {
+
+/* one tick through pack -> device body -> unpack.  status_io: the env's status byte (ENV mode).
+ * returns the POM_UB_* flags of this tick, or 0xFFFFFFFF if the state is not representable */
+uint32_t pom_emul_step(void* state_1004, const int32_t* moves, int env_mode, int max_steps, uint32_t* status_io)
+{
+    uint32_t rec[POM_REC_DWORDS];
+    if (pom_pack_state((const int32_t*)state_1004, rec, 1)) return 0xFFFFFFFFu;
+    ArrayEnv env;
+    std::memset(&env, 0, sizeof env);
+    for (int r = 0; r < 61; r++) {
+        env.cells[2 * r] = (uint16_t)(rec[POM_REC_BOARD + r] & 0xFFFF);
+        env.cells[2 * r + 1] = (uint16_t)(rec[POM_REC_BOARD + r] >> 16);
+    }
+    for (int k = 0; k < 20; k++) {
+        env.bombs[k] = (int)rec[POM_REC_BOMBS + k];
+        env.flames[k] = (int)rec[POM_REC_FLAMES + k];
+    }
+    PomLane L;
+    pom_lane_load(L, rec[POM_REC_META], rec[POM_REC_META2], rec + POM_REC_AGENTS);
+    int time_step = (int)rec[POM_REC_TIMESTEP];
+    uint32_t status = status_io ? *status_io : 0;
+    L.ub = 0;
+    if (!(env_mode && (status & POM_ST_DONE))) {
+        PomStepper<ArrayEnv> st(env, L);
+        st.step(moves);
+        if (env_mode) {
+            time_step++;
+            status = pom_env_epilogue(L, time_step, max_steps, status);
+        }
+    }
+    for (int r = 0; r < 61; r++) rec[POM_REC_BOARD + r] = (uint32_t)env.cells[2 * r] | ((uint32_t)env.cells[2 * r + 1] << 16);
+    rec[POM_REC_TIMESTEP] = (uint32_t)time_step;
+    rec[POM_REC_META] = pom_lane_meta(L);
+    rec[POM_REC_META2] = pom_lane_meta2(L, status);
+    for (int i = 0; i < 4; i++) {
+        rec[POM_REC_AGENTS + 2 * i] = (uint32_t)L.a0[i];
+        rec[POM_REC_AGENTS + 2 * i + 1] = (uint32_t)L.a1[i];
+    }
+    for (int k = 0; k < 20; k++) {
+        rec[POM_REC_BOMBS + k] = (uint32_t)env.bombs[k];
+        rec[POM_REC_FLAMES + k] = (uint32_t)env.flames[k];
+    }
+    int32_t out[251];
+    std::memset(out, 0, sizeof out);
+    pom_unpack_state(rec, 1, out);
+    std::memcpy(state_1004, out, POM_STATE_BYTES);
+    if (status_io) *status_io = status;
+    return L.ub;
+}
+
+}
