@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched Pommerman tick on MI355X (BASELINE.json's metric).
+
+One "step" = one pass of the hot path over the whole batch: one launch of pom_step_kernel that
+advances every env of this rank by one tick with state round-tripping HBM (ticks_per_launch = 1).
+Workload (config.workload): 65,536 concurrent 11x11 FFA envs per GPU, start boards with the
+reference's cell distribution, Move[4] i.i.d. uniform over {IDLE,UP,DOWN,LEFT,RIGHT,BOMB}
+(RandomAgent distribution) from the counter-based stream of include/pom_rng.h, finished envs
+restart from their snapshot, 800-tick episode cap.  Inputs are resident in HBM before the timed
+region starts; nothing crosses PCIe inside it.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), envs sharded
+contiguously with no data-path collective; the only collective is the all-reduce of the
+step counters after the last tick (weak scaling: per-GPU batch fixed).
+
+The JSON line also carries
+  roofline     — algorithmic HBM bytes per launch (2024 B x envs) / mean launch time
+                 measured with HIP events on the launch stream, vs the 8 TB/s HBM3E peak;
+  cpu_baseline — the oracle (CPU restatement, bit-exact to the reference) timed on this host's
+                 cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_STEP = 2024  # 1004 B State read + 1004 B State write + 16 B Move[4]  
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def shard_plan(rank: int, world: int, envs_per_gpu: int) -> dict:
+    """Contiguous env ranges; env_offset keys the synthetic move stream so shards differ."""
+    return {"first_env": rank * envs_per_gpu, "n_envs": envs_per_gpu, "global_envs": world * envs_per_gpu}
+
+
+def reduce_counters(counters, dist_mod=None):
+    """Sum the per-rank int64 counters over ranks (RCCL all-reduce on GPU, gloo in CPU tests)."""
+    if dist_mod is not None and dist_mod.is_initialized() and dist_mod.get_world_size() > 1:
+        dist_mod.all_reduce(counters, op=dist_mod.ReduceOp.SUM)
+    return counters
+
+
+def reduce_max(value: float, device, dist_mod=None) -> float:
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist_mod is not None and dist_mod.is_initialized() and dist_mod.get_world_size() > 1:
+        dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cpu_baseline(start: np.ndarray, seed: int, dist_id: int, max_steps: int, budget_s: float = 10.0) -> dict:
+    """Time the oracle on the host cores on a bounded sample of the same workload."""
+    import ctypes as C
+    from tests.oracle_lib import ORACLE_DIR, Oracle
+
+    lib_path = os.path.join(ORACLE_DIR, "libpom_oracle_native.so")
+    flags = "-O3 -march=native"
+    try:  # tuned for THIS host; the generic build is the fallback
+        subprocess.run(["make", "-s", "-C", ORACLE_DIR, "libpom_oracle_native.so"], check=True, capture_output=True, timeout=120)
+        lib = C.CDLL(lib_path)
+    except Exception:
+        Oracle()
+        lib = C.CDLL(os.path.join(ORACLE_DIR, "libpom_oracle.so"))
+        flags = "-O3"
+    lib.pom_oracle_run_random.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.pom_oracle_run_random.restype = C.c_int64
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    per_thread = 2048
+    cores = max(1, min(cores, start.size // per_thread))
+    chunk_ticks = 50
+    totals = [0] * cores
+    deadline = time.perf_counter() + budget_s
+
+    def work(k: int) -> None:
+        init = np.ascontiguousarray(start[k * per_thread:(k + 1) * per_thread])
+        cur = init.copy()
+        tick = 0
+        while time.perf_counter() < deadline:
+            totals[k] += lib.pom_oracle_run_random(cur.ctypes.data, init.ctypes.data, per_thread, chunk_ticks, seed,
+                                                   k * per_thread, tick, dist_id, max_steps)
+            tick += chunk_ticks
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    wall = time.perf_counter() - t0
+    steps = int(sum(totals))
+    return {
+        "value": steps / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "sample": f"oracle/pom_oracle.c ({flags}), {cores} threads x {per_thread} envs of the same boards and move stream, "
+                  f"{steps} env-steps in {wall:.1f} s",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--kind", default="ffa", choices=["ffa", "stress"])
+    ap.add_argument("--dist", default="random", choices=["harmless", "random", "stress"])
+    ap.add_argument("--ticks-per-launch", type=int, default=1)
+    ap.add_argument("--max-steps", type=int, default=800)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as entry
+    entry.build_hip()
+    import pomcpp_amd as pa
+    from pomcpp_amd.batch import BatchEnvironment, MODE_ENV, CNT_STEPS
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the stepper has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    dist_id = {"harmless": 0, "random": 1, "stress": 2}[args.dist]
+    plan = shard_plan(rank, world, args.envs)
+
+    start = pa.make_boards(plan["n_envs"], seed=args.seed * 1000003 + rank, kind=args.kind)
+    # torch's default stream is handle 0, which the C-ABI reads as "create your own": run everything on an
+    # explicit torch stream so the HIP events below bracket exactly the stream the kernels are launched on
+    stream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    env = BatchEnvironment(plan["n_envs"], device=local_rank, mode=MODE_ENV, auto_reset=True, max_steps=args.max_steps,
+                           env_offset=plan["first_env"], stream=stream.cuda_stream)
+    env.make_game(start)
+    counters = torch.zeros(4, dtype=torch.int64, device=device)
+
+    def barrier() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    tpl = args.ticks_per_launch
+    for _ in range(args.warmup):
+        env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)
+    env.counters_into(counters.data_ptr())
+    reduce_counters(counters, dist)  # warm the RCCL communicator outside the timed region
+    env.reset_counters()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)
+    ev1.record(stream)
+    env.counters_into(counters.data_ptr())
+    reduce_counters(counters, dist)  # the one collective: step / episode totals over all ranks
+    barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = reduce_max(elapsed, device, dist)
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # mean launch-to-launch time of pom_step_kernel on its stream
+    kernel_ms = reduce_max(kernel_ms, device, dist)
+
+    total_steps = int(counters[CNT_STEPS].item())
+    expect = plan["global_envs"] * args.steps * tpl
+    if total_steps != expect:
+        raise SystemExit(f"step counter {total_steps} != envs x ticks {expect}")
+
+    if rank == 0:
+        algo_bytes = ALGO_BYTES_PER_STEP * plan["n_envs"] * tpl
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "env_steps_per_sec", "value": total_steps / elapsed, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.envs} concurrent 11x11 FFA envs per GPU, {args.kind} boards, uniform-{args.dist} Move[4] "
+                            f"(RandomAgent distribution), auto-reset, {args.max_steps}-tick cap",
+                "envs_per_gpu": args.envs, "global_envs": plan["global_envs"], "ticks_per_launch": tpl,
+                "parallelism": f"env-shard x{world}", "episodes_finished": int(counters[1].item()),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "pom_step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(start, args.seed, dist_id, args.max_steps)
+        print(json.dumps(line), flush=True)
+    env.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
