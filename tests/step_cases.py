@@ -1,0 +1,642 @@
+"""The reference's `[step function]` test cases restated as backend-neutral scripts.
+
+Each function below follows one TEST_CASE / SECTION of
+/root/reference/unit_test/bboard/board_logic.cpp (lines cited per case) against a small `api`:
+
+    s = api.make()                          std::make_unique<bboard::State>()
+    api.corners / put_agent / put_item / kill / plant_bomb / set_bomb_direction / spawn_flame
+    api.step(s, m) / api.several_steps(n, s, m)
+    api.require(cond) / api.require_agent(s, agent, x, y)      REQUIRE / REQUIRE_AGENT (:11-17)
+
+The same script runs (a) against the compiled reference when scripts/gen_golden.py records the
+golden trace, (b) against the oracle on CPU and (c) against the HIP path through the C-ABI — so the
+parity tests read like the reference's own.  `EXTRA_CASES` are directed vectors for the quirks of
+SURVEY.md §9 that the reference's suite does not reach.
+"""
+from __future__ import annotations
+
+from pomcpp_amd.state import Direction, Item, Move, bomb_x, bomb_y, is_flame, queue_get, BOMB_LIFETIME, FLAME_LIFETIME
+
+IDLE = Move.IDLE
+
+
+def idle():
+    return [IDLE, IDLE, IDLE, IDLE]
+
+
+def place_bombs_horizontally(api, s, agent, bombs):  # board_logic.cpp:34-46
+    m = idle()
+    for _ in range(bombs):
+        m[agent] = Move.BOMB
+        api.step(s, m)
+        m[agent] = Move.RIGHT
+        api.step(s, m)
+
+
+# ---- TEST_CASE("Basic Non-Obstacle Movement") :55-83 -------------------------------------------
+def basic_movement(api):
+    s = api.make()
+    api.corners(s, 0, 1, 2, 3)
+    m = idle()
+    m[0] = Move.RIGHT
+    api.step(s, m)
+    api.require_agent(s, 0, 1, 0)
+    m[0] = Move.DOWN
+    api.step(s, m)
+    api.require_agent(s, 0, 1, 1)
+    m[0] = Move.LEFT
+    api.step(s, m)
+    api.require_agent(s, 0, 0, 1)
+    m[0] = Move.UP
+    api.step(s, m)
+    api.require_agent(s, 0, 0, 0)
+    m[3] = Move.UP
+    api.step(s, m)
+    api.require_agent(s, 3, 0, 9)
+
+
+# ---- TEST_CASE("Basic Obstacle Collision") :85-102 ----------------------------------------------
+def obstacle_collision(api):
+    s = api.make()
+    api.corners(s, 0, 1, 2, 3)
+    m = idle()
+    api.put_item(s, 1, 0, Item.RIGID)
+    m[0] = Move.RIGHT
+    api.step(s, m)
+    api.require_agent(s, 0, 0, 0)
+    m[0] = Move.DOWN
+    api.step(s, m)
+    api.require_agent(s, 0, 0, 1)
+
+
+# ---- TEST_CASE("Movement Against Flames") :104-119 ----------------------------------------------
+def movement_against_flames(api):
+    s = api.make()
+    m = idle()
+    api.corners(s, 0, 1, 2, 3)
+    api.spawn_flame(s, 1, 1, 2)
+    m[0] = Move.RIGHT
+    api.step(s, m)
+    api.require(s["agents"][0, 0]["dead"])
+    api.require(s["board"][0, 0, 0] == Item.PASSAGE)
+
+
+# ---- TEST_CASE("Destination Collision") :121-171 ------------------------------------------------
+def _dest_collision_setup(api):
+    s = api.make()
+    api.put_agent(s, 0, 1, 0)
+    api.put_agent(s, 2, 1, 1)
+    api.kill(s, 2, 3)
+    return s, idle()
+
+
+def dest_collision_two_agents(api):
+    s, m = _dest_collision_setup(api)
+    m[0], m[1] = Move.RIGHT, Move.LEFT
+    api.step(s, m)
+    api.require_agent(s, 0, 0, 1)
+    api.require_agent(s, 1, 2, 1)
+
+
+def dest_collision_dead(api):
+    s, m = _dest_collision_setup(api)
+    m[0], m[1] = Move.RIGHT, Move.LEFT
+    api.kill(s, 1)
+    api.step(s, m)
+    api.require_agent(s, 0, 1, 1)
+
+
+def dest_collision_four_agents(api):
+    s, m = _dest_collision_setup(api)
+    api.put_agent(s, 1, 0, 2)
+    api.put_agent(s, 1, 2, 3)
+    m[0], m[1], m[2], m[3] = Move.RIGHT, Move.LEFT, Move.DOWN, Move.UP
+    api.step(s, m)
+    api.require_agent(s, 0, 0, 1)
+    api.require_agent(s, 1, 2, 1)
+    api.require_agent(s, 2, 1, 0)
+    api.require_agent(s, 3, 1, 2)
+
+
+# ---- TEST_CASE("Movement Dependency Handling") :173-239 -----------------------------------------
+def chain_against_obstacle(api):
+    s = api.make()
+    m = idle()
+    for i in range(4):
+        api.put_agent(s, i, 0, i)
+    api.put_item(s, 4, 0, Item.RIGID)
+    m[0] = m[1] = m[2] = m[3] = Move.RIGHT
+    api.step(s, m)
+    for i in range(4):
+        api.require_agent(s, i, i, 0)
+
+
+def two_on_one(api):  # :198-220 — triggers the reference's moves[-1] read (SURVEY Q-UB1)
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 0, 0, 0)
+    api.put_agent(s, 2, 0, 1)
+    api.put_agent(s, 1, 0, 2)
+    api.put_agent(s, 1, 1, 3)
+    m[0], m[1] = Move.RIGHT, Move.LEFT
+    m[2] = m[3] = Move.DOWN
+    api.step(s, m)
+    api.require_agent(s, 0, 0, 0)
+    api.require_agent(s, 1, 2, 0)
+    api.require_agent(s, 2, 1, 1)
+    api.require_agent(s, 3, 1, 2)
+
+
+def move_ouroboros(api):
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 0, 0, 0)
+    api.put_agent(s, 1, 0, 1)
+    api.put_agent(s, 1, 1, 2)
+    api.put_agent(s, 0, 1, 3)
+    m[0], m[1], m[2], m[3] = Move.RIGHT, Move.DOWN, Move.LEFT, Move.UP
+    api.step(s, m)
+    api.require_agent(s, 3, 0, 0)
+    api.require_agent(s, 0, 1, 0)
+    api.require_agent(s, 1, 1, 1)
+    api.require_agent(s, 2, 0, 1)
+
+
+# ---- TEST_CASE("Bomb Mechanics") :241-307 ---------------------------------------------------------
+def standard_bomb_laying(api):
+    s = api.make()
+    m = idle()
+    api.corners(s, 0, 1, 2, 3)
+    m[0] = Move.BOMB
+    api.step(s, m)
+    api.require(s["board"][0, 0, 0] == Item.AGENT0)
+    m[0] = Move.DOWN
+    api.step(s, m)
+    api.require(s["board"][0, 0, 0] == Item.BOMB)
+
+
+def bomb_block_simple(api):
+    s = api.make()
+    m = idle()
+    api.corners(s, 0, 1, 2, 3)
+    api.plant_bomb(s, 1, 0, 0)
+    m[0] = Move.RIGHT
+    api.step(s, m)
+    api.require_agent(s, 0, 0, 0)
+
+
+def bomb_block_complex(api):
+    s = api.make()
+    m = idle()
+    for i in range(4):
+        api.put_agent(s, i, 0, i)
+    m[0] = m[1] = m[2] = Move.RIGHT
+    m[3] = Move.BOMB
+    api.step(s, m)
+    api.require_agent(s, 0, 0, 0)
+    api.require_agent(s, 1, 1, 0)
+    api.require_agent(s, 2, 2, 0)
+    m[0] = m[1] = m[2] = IDLE
+    m[3] = Move.RIGHT
+    api.step(s, m)
+    api.require_agent(s, 3, 4, 0)
+
+
+def bomb_ouroboros_block(api):
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 0, 0, 0)
+    api.put_agent(s, 1, 0, 1)
+    api.put_agent(s, 1, 1, 2)
+    api.put_agent(s, 0, 1, 3)
+    m[0] = m[1] = m[2] = m[3] = Move.BOMB
+    api.step(s, m)
+    m[0], m[1], m[2], m[3] = Move.RIGHT, Move.DOWN, Move.LEFT, Move.UP
+    api.step(s, m)
+    api.require_agent(s, 0, 0, 0)
+    api.require_agent(s, 1, 1, 0)
+    api.require_agent(s, 2, 1, 1)
+    api.require_agent(s, 3, 0, 1)
+
+
+# ---- TEST_CASE("Bomb Explosion") :310-382 -----------------------------------------------------------
+def _explosion_setup(api):
+    s = api.make()
+    api.kill(s, 2, 3)
+    api.put_agent(s, 5, 5, 0)
+    return s, idle()
+
+
+def bomb_goes_off(api):
+    s, m = _explosion_setup(api)
+    m[0] = Move.BOMB
+    api.step(s, m)
+    m[0] = Move.UP
+    api.several_steps(BOMB_LIFETIME - 1, s, m)
+    api.require(s["board"][0, 5, 5] == Item.BOMB)
+    api.step(s, m)
+    api.require(is_flame(s["board"][0, 5, 5]))
+
+
+def destroy_objects_and_agents(api):
+    s, m = _explosion_setup(api)
+    api.put_item(s, 6, 5, Item.WOOD)
+    api.put_agent(s, 4, 5, 1)
+    m[0] = Move.BOMB
+    api.step(s, m)
+    m[0] = Move.UP
+    api.several_steps(BOMB_LIFETIME, s, m)
+    api.require(s["agents"][0, 1]["dead"])
+    api.require(is_flame(s["board"][0, 5, 4]))
+    api.require(is_flame(s["board"][0, 5, 6]))
+
+
+def keep_rigid(api):
+    s, m = _explosion_setup(api)
+    api.put_item(s, 6, 5, Item.RIGID)
+    m[0] = Move.BOMB
+    api.step(s, m)
+    m[0] = Move.UP
+    api.several_steps(BOMB_LIFETIME, s, m)
+    api.require(s["board"][0, 5, 6] == Item.RIGID)
+
+
+def kill_only_one_wood(api):
+    s, m = _explosion_setup(api)
+    api.put_item(s, 7, 5, Item.WOOD)
+    api.put_item(s, 8, 5, Item.WOOD)
+    s["agents"][0, 0]["bombStrength"] = 5
+    api.plant_bomb(s, 6, 5, 0, True)
+    api.several_steps(BOMB_LIFETIME, s, m)
+    api.require(is_flame(s["board"][0, 5, 7]))
+    api.require(not is_flame(s["board"][0, 5, 8]))
+
+
+def max_agent_bomb_limit(api):
+    s, m = _explosion_setup(api)
+    s["agents"][0, 0]["maxBombCount"] = 2
+    api.require(s["agents"][0, 0]["bombCount"] == 0)
+    place_bombs_horizontally(api, s, 0, 4)
+    api.require(s["board"][0, 5, 5] == Item.BOMB)
+    api.require(s["board"][0, 5, 6] == Item.BOMB)
+    api.require(s["board"][0, 5, 7] == Item.PASSAGE)
+    api.require(s["agents"][0, 0]["bombCount"] == 2)
+
+
+# ---- TEST_CASE("Flame Mechanics") :384-427 ------------------------------------------------------------
+def flame_lifetime(api):
+    s = api.make()
+    m = idle()
+    api.corners(s, 0, 1, 2, 3)
+    api.spawn_flame(s, 5, 5, 4)
+    api.step(s, m)
+    api.several_steps(FLAME_LIFETIME - 2, s, m)
+    api.require(is_flame(s["board"][0, 5, 5]))
+    api.step(s, m)
+    api.require(not is_flame(s["board"][0, 5, 5]))
+
+
+def flame_vanish_completely(api):
+    s = api.make()
+    m = idle()
+    api.corners(s, 0, 1, 2, 3)
+    api.spawn_flame(s, 5, 5, 4)
+    api.step(s, m)
+    for i in range(5):
+        api.require(is_flame(s["board"][0, 5, 5 + i]))
+        api.require(is_flame(s["board"][0, 5, 5 - i]))
+        api.require(is_flame(s["board"][0, 5 + i, 5]))
+        api.require(is_flame(s["board"][0, 5 - i, 5]))
+
+
+def flame_only_vanish_own(api):
+    s = api.make()
+    m = idle()
+    api.corners(s, 0, 1, 2, 3)
+    api.spawn_flame(s, 5, 5, 4)
+    api.step(s, m)
+    api.spawn_flame(s, 6, 6, 4)
+    api.several_steps(FLAME_LIFETIME - 1, s, m)
+    api.require(is_flame(s["board"][0, 5, 6]))
+    api.require(is_flame(s["board"][0, 6, 5]))
+    api.require(not is_flame(s["board"][0, 5, 5]))
+
+
+# ---- TEST_CASE("Chained Explosions") :429-472 -----------------------------------------------------------
+def chained_two_bombs(api):
+    s = api.make()
+    m = idle()
+    api.corners(s, 0, 1, 2, 3)
+    api.plant_bomb(s, 5, 5, 0, True)
+    api.step(s, m)
+    api.plant_bomb(s, 4, 5, 1, True)
+    api.several_steps(BOMB_LIFETIME - 1, s, m)
+    api.require(s["bombs_count"][0] == 0)
+    api.require(is_flame(s["board"][0, 5, 6]))
+
+
+def chained_two_bombs_covered(api):
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 5, 5, 0)
+    api.put_agent(s, 4, 5, 1)
+    api.kill(s, 2, 3)
+    m[0] = Move.BOMB
+    api.step(s, m)
+    m[1] = Move.BOMB
+    api.step(s, m)
+    m[0] = m[1] = Move.DOWN
+    api.several_steps(BOMB_LIFETIME - 2, s, m)
+    api.require(s["bombs_count"][0] == 2)
+    api.step(s, m)
+    api.require(s["bombs_count"][0] == 0)
+    api.require(s["flames_count"][0] == 2)
+
+
+# ---- TEST_CASE("Bomb Kick Mechanics") :474-634 ------------------------------------------------------------
+def _kick_setup(api):
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 0, 1, 0)
+    s["agents"][0, 0]["canKick"] = 1
+    api.plant_bomb(s, 1, 1, 0, True)
+    s["agents"][0, 0]["maxBombCount"] = 5  # MAX_BOMBS_PER_AGENT
+    m[0] = Move.RIGHT
+    return s, m
+
+
+def kick_one_agent_one_bomb(api):
+    s, m = _kick_setup(api)
+    api.kill(s, 1, 2, 3)
+    api.step(s, m)
+    api.require_agent(s, 0, 1, 1)
+    api.require(s["board"][0, 1, 2] == Item.BOMB)
+    for i in range(4):
+        api.require(s["board"][0, 1, 2 + i] == Item.BOMB)
+        api.step(s, m)
+        m[0] = IDLE
+
+
+def kick_against_flame(api):
+    s, m = _kick_setup(api)
+    api.kill(s, 1, 2, 3)
+    api.put_item(s, 5, 1, Item.FLAMES)
+    api.step(s, m)
+    m[0] = IDLE
+    api.several_steps(3, s, m)
+    api.require(is_flame(s["board"][0, 1, 5]))
+    api.require(s["bombs_count"][0] == 0)
+    api.require(s["flames_count"][0] == 1)
+    f = queue_get(s[0], "flames", 0)
+    api.require(f["x"] == 5 and f["y"] == 1)
+
+
+def kick_bomb_bomb_collision(api):
+    s, m = _kick_setup(api)
+    api.kill(s, 1, 2, 3)
+    api.plant_bomb(s, 7, 7, 0, True)
+    api.set_bomb_direction(s, 1, Direction.UP)
+    for _ in range(6):
+        api.step(s, m)
+        m[0] = IDLE
+    api.require(bomb_x(queue_get(s[0], "bombs", 0)) == 6)
+    api.require(bomb_x(queue_get(s[0], "bombs", 1)) == 7)
+    api.require(bomb_y(queue_get(s[0], "bombs", 1)) == 2)
+
+
+def kick_bomb_bomb_static(api):
+    s, m = _kick_setup(api)
+    api.kill(s, 1, 2, 3)
+    api.plant_bomb(s, 7, 6, 0, True)
+    api.put_item(s, 7, 0, Item.WOOD)
+    api.set_bomb_direction(s, 1, Direction.UP)
+    for _ in range(7):
+        api.step(s, m)
+        m[0] = IDLE
+    api.require(bomb_x(queue_get(s[0], "bombs", 0)) == 6)
+    api.require(bomb_x(queue_get(s[0], "bombs", 1)) == 7)
+    api.require(bomb_y(queue_get(s[0], "bombs", 1)) == 1)
+
+
+def kick_bounce_back_agent(api):
+    s, m = _kick_setup(api)
+    api.kill(s, 2, 3)
+    api.put_agent(s, 0, 2, 1)
+    m[1] = Move.UP
+    api.plant_bomb(s, 2, 2, 0, True)
+    api.set_bomb_direction(s, 1, Direction.UP)
+    api.step(s, m)
+    api.require_agent(s, 0, 0, 1)
+    api.require_agent(s, 1, 0, 2)
+    api.require(bomb_x(queue_get(s[0], "bombs", 0)) == 1)
+    api.require(bomb_x(queue_get(s[0], "bombs", 1)) == 2)
+
+
+def kick_bounce_back_complex_chain(api):
+    s, m = _kick_setup(api)
+    api.kill(s, 2, 3)
+    api.put_agent(s, 0, 2, 1)
+    m[1] = Move.UP
+    api.plant_bomb(s, 2, 2, 0, True)
+    api.plant_bomb(s, 0, 3, 0, True)
+    api.set_bomb_direction(s, 1, Direction.UP)
+    api.set_bomb_direction(s, 2, Direction.UP)
+    api.step(s, m)
+    api.require_agent(s, 0, 0, 1)
+    api.require_agent(s, 1, 0, 2)
+    api.require(s["board"][0, 3, 0] == Item.BOMB)
+    api.require(s["board"][0, 1, 1] == Item.BOMB)
+    api.require(s["board"][0, 2, 2] == Item.BOMB)
+
+
+def kick_bounce_back_super_complex_chain(api):  # :581-600, no assertions in the reference: trace only
+    s, m = _kick_setup(api)
+    api.kill(s, 3)
+    api.put_agent(s, 0, 2, 1)
+    api.put_agent(s, 1, 3, 2)
+    api.put_item(s, 2, 1, Item.RIGID)
+    m[1] = Move.UP
+    m[2] = Move.BOMB
+    api.plant_bomb(s, 0, 3, 0, True)
+    api.set_bomb_direction(s, 1, Direction.UP)
+    for _ in range(3):
+        api.step(s, m)
+        m[0] = m[1] = IDLE
+        m[2] = Move.LEFT
+
+
+def kick_bounce_back_wall(api):
+    s, m = _kick_setup(api)
+    api.kill(s, 1, 3)
+    api.put_agent(s, 1, 3, 2)
+    api.put_item(s, 2, 1, Item.RIGID)
+    m[2] = Move.LEFT
+    s["agents"][0, 2]["canKick"] = 1
+    api.plant_bomb(s, 0, 3, 0, True)
+    api.step(s, m)
+    api.require_agent(s, 2, 1, 3)
+    api.require(s["board"][0, 3, 0] == Item.BOMB)
+
+
+def kick_stepping_on_bombs(api):
+    s, m = _kick_setup(api)
+    api.put_agent(s, 6, 3, 0)
+    api.put_agent(s, 6, 4, 1)
+    api.put_agent(s, 6, 5, 2)
+    m[0] = m[1] = m[2] = IDLE
+    api.plant_bomb(s, 5, 6, 3, True)
+    api.plant_bomb(s, 6, 6, 2, True)
+    api.put_agent(s, 6, 6, 3)
+    m[3] = IDLE
+    api.step(s, m)
+    api.require_agent(s, 3, 6, 6)
+    m[3] = Move.LEFT
+    api.step(s, m)
+    api.require_agent(s, 3, 6, 6)
+
+
+CASES = {  # the 32 leaf runs of [step function]
+    "basic_movement": basic_movement,
+    "obstacle_collision": obstacle_collision,
+    "movement_against_flames": movement_against_flames,
+    "dest_collision_two_agents": dest_collision_two_agents,
+    "dest_collision_dead": dest_collision_dead,
+    "dest_collision_four_agents": dest_collision_four_agents,
+    "chain_against_obstacle": chain_against_obstacle,
+    "two_on_one": two_on_one,
+    "move_ouroboros": move_ouroboros,
+    "standard_bomb_laying": standard_bomb_laying,
+    "bomb_block_simple": bomb_block_simple,
+    "bomb_block_complex": bomb_block_complex,
+    "bomb_ouroboros_block": bomb_ouroboros_block,
+    "bomb_goes_off": bomb_goes_off,
+    "destroy_objects_and_agents": destroy_objects_and_agents,
+    "keep_rigid": keep_rigid,
+    "kill_only_one_wood": kill_only_one_wood,
+    "max_agent_bomb_limit": max_agent_bomb_limit,
+    "flame_lifetime": flame_lifetime,
+    "flame_vanish_completely": flame_vanish_completely,
+    "flame_only_vanish_own": flame_only_vanish_own,
+    "chained_two_bombs": chained_two_bombs,
+    "chained_two_bombs_covered": chained_two_bombs_covered,
+    "kick_one_agent_one_bomb": kick_one_agent_one_bomb,
+    "kick_against_flame": kick_against_flame,
+    "kick_bomb_bomb_collision": kick_bomb_bomb_collision,
+    "kick_bomb_bomb_static": kick_bomb_bomb_static,
+    "kick_bounce_back_agent": kick_bounce_back_agent,
+    "kick_bounce_back_complex_chain": kick_bounce_back_complex_chain,
+    "kick_bounce_back_super_complex_chain": kick_bounce_back_super_complex_chain,
+    "kick_bounce_back_wall": kick_bounce_back_wall,
+    "kick_stepping_on_bombs": kick_stepping_on_bombs,
+}
+
+
+# ---- directed vectors for SURVEY.md §9 quirks -------------------------------------------------------------
+def q1_stale_slot_direction_inherited(api):
+    """Q1: a bomb planted into a slot vacated by RemoveAt inherits that slot's stale direction nibble."""
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 0, 9, 0)
+    api.put_agent(s, 5, 5, 1)
+    api.kill(s, 2, 3)
+    s["agents"][0, 0]["maxBombCount"] = 3
+    api.put_item(s, 8, 2, Item.FLAMES)          # an orphan flame cell for bomb 1 to run into
+    api.plant_bomb(s, 2, 0, 0, True)            # slot 0: stays
+    api.plant_bomb(s, 5, 2, 0, True)            # slot 1: moving RIGHT towards the flame cell
+    api.set_bomb_direction(s, 1, Direction.RIGHT)
+    api.several_steps(3, s, m)                  # reaches (8,2), explodes, RemoveAt(1) leaves a stale copy in slot 1
+    api.require(s["bombs_count"][0] == 1)
+    m[0] = Move.BOMB
+    api.step(s, m)                              # planted into slot 1: inherits dir RIGHT and moves this very tick
+    api.require(s["bombs_count"][0] == 2)
+    api.require(bomb_x(queue_get(s[0], "bombs", 1)) == 1)
+
+
+def q2_stale_index_after_nested_chain(api):
+    """Q2: ExplodeBombAt(i) removes whatever sits at i after the nested chain shrank the queue."""
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 0, 0, 0)
+    api.put_agent(s, 10, 10, 1)
+    api.kill(s, 2, 3)
+    s["agents"][0, 0]["maxBombCount"] = 5
+    s["agents"][0, 0]["bombStrength"] = 3
+    s["agents"][0, 1]["maxBombCount"] = 5
+    s["agents"][0, 1]["bombStrength"] = 3
+    api.put_item(s, 8, 5, Item.FLAMES)
+    api.plant_bomb(s, 3, 5, 0, True)            # index 0, reached by the chain of the kicked bomb
+    api.plant_bomb(s, 5, 8, 1, True)            # index 1, bystander
+    api.plant_bomb(s, 5, 5, 0, True)            # index 2: chained by bomb 3's flame, itself chains index 0
+    api.plant_bomb(s, 6, 5, 1, True)            # index 3: kicked RIGHT into the flame cell
+    api.set_bomb_direction(s, 3, Direction.RIGHT)
+    api.several_steps(4, s, m)
+
+
+def q9_dead_agent_cancels_move(api):
+    """Q9: a dead agent's stale position and its Move entry still cancel a live agent's move as a 'switch'."""
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 1, 1, 0)
+    api.put_agent(s, 2, 1, 1)
+    api.kill(s, 1, 2, 3)
+    api.put_item(s, 2, 1, Item.PASSAGE)
+    m[0], m[1] = Move.RIGHT, Move.LEFT
+    api.step(s, m)
+    api.require_agent(s, 0, 1, 1)               # stayed
+    m[1] = IDLE
+    api.step(s, m)
+    api.require_agent(s, 0, 2, 1)               # now moves
+
+
+def q10_three_cycle_plus_one(api):
+    """Q10: no roots, but not a 4-cycle: dependency[] is overwritten and one agent is lost (Q-UB1)."""
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 1, 1, 0)
+    api.put_agent(s, 2, 1, 1)
+    api.put_agent(s, 2, 2, 2)
+    api.put_agent(s, 0, 1, 3)
+    m[0], m[1], m[2], m[3] = Move.RIGHT, Move.DOWN, Move.UP, Move.RIGHT
+    api.step(s, m)
+    api.step(s, m)
+
+
+def q7_out_of_order_timer_underflow(api):
+    """Q7: only the queue top is tested for time 0; a later bomb at 0 borrows from its direction nibble."""
+    s = api.make()
+    m = idle()
+    api.corners(s, 0, 1, 2, 3)
+    s["agents"][0, 0]["maxBombCount"] = 3
+    api.plant_bomb(s, 5, 5, 0, True, 6)
+    api.plant_bomb(s, 7, 7, 0, True, 2)
+    api.several_steps(8, s, m)
+
+
+def full_queues_stress(api):
+    """20 live bombs (queue full) detonating in one chain: full-depth explosion stack, flame queue fills."""
+    s = api.make()
+    m = idle()
+    api.corners(s, 0, 1, 2, 3)
+    for a in range(4):
+        s["agents"][0, a]["maxBombCount"] = 5
+        s["agents"][0, a]["bombStrength"] = 2
+    k = 0
+    for y in (2, 4, 6, 8):
+        for x in (1, 3, 5, 7, 9):
+            api.plant_bomb(s, x, y, k % 4, True, 3 if k == 0 else 9)
+            k += 1
+    api.require(s["bombs_count"][0] == 20)
+    m[0] = Move.BOMB                             # a 21st bomb is refused: maxBombCount reached
+    api.several_steps(6, s, m)
+
+
+EXTRA_CASES = {
+    "q1_stale_slot_direction_inherited": q1_stale_slot_direction_inherited,
+    "q2_stale_index_after_nested_chain": q2_stale_index_after_nested_chain,
+    "q7_out_of_order_timer_underflow": q7_out_of_order_timer_underflow,
+    "q9_dead_agent_cancels_move": q9_dead_agent_cancels_move,
+    "q10_three_cycle_plus_one": q10_three_cycle_plus_one,
+    "full_queues_stress": full_queues_stress,
+}
+
+ALL_CASES = {**CASES, **EXTRA_CASES}

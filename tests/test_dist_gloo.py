@@ -1,0 +1,56 @@
+"""The N>1 path of bench.py on CPU: world_size 2 over gloo — contiguous env shards, distinct move-stream
+offsets, the single counter all-reduce and the max-over-ranks timing."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = bench.shard_plan(rank, world, 32768)
+    counters = torch.tensor([plan["n_envs"] * 10, rank + 1, 0, 0], dtype=torch.int64)
+    bench.reduce_counters(counters, dist)
+    slowest = bench.reduce_max(1.0 + rank, torch.device("cpu"), dist)
+    q.put((rank, plan, counters.tolist(), slowest))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_shard_and_counter_allreduce():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (r0, p0, c0, t0), (r1, p1, c1, t1) = res
+    assert p0["first_env"] == 0 and p1["first_env"] == 32768 and p0["global_envs"] == 65536
+    assert p0["first_env"] + p0["n_envs"] == p1["first_env"]  # contiguous, disjoint
+    assert c0 == c1 == [2 * 32768 * 10, 3, 0, 0]
+    assert t0 == t1 == 2.0
+
+
+def test_single_process_helpers_are_identity():
+    sys.path.insert(0, ROOT)
+    import bench
+    c = torch.tensor([5, 1, 0, 0], dtype=torch.int64)
+    assert bench.reduce_counters(c, None).tolist() == [5, 1, 0, 0]
+    assert bench.reduce_max(3.5, torch.device("cpu"), None) == 3.5
+    assert bench.shard_plan(0, 1, 65536) == {"first_env": 0, "n_envs": 65536, "global_envs": 65536}

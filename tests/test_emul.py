@@ -1,0 +1,80 @@
+"""Kernel logic without a GPU: the device tick body (pomcpp_amd/csrc/pom_step_body.h) compiled for the host
+over a plain-array store (tests/emul) and fuzzed against the oracle, plus pack/unpack round trips.  This is a
+test build only — the product library contains no host stepper."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pomcpp_amd as pa
+from pomcpp_amd.state import STATE_DTYPE, Item
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "build")
+INC = ["-I" + os.path.join(ROOT, p) for p in ("include", "pomcpp_amd/csrc", "oracle")]
+
+
+@pytest.fixture(scope="module")
+def emul_bins():
+    os.makedirs(BUILD, exist_ok=True)
+    run = lambda *a: subprocess.run(list(a), check=True, cwd=ROOT)
+    run("g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-fPIC", *INC, "-c", "tests/emul/pom_emul.cpp", "-o", "build/pom_emul.o")
+    run("gcc", "-O2", "-std=c11", "-fPIC", *INC, "-c", "oracle/pom_oracle.c", "-o", "build/pom_oracle.o")
+    run("g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", *INC, "tests/emul/emul_fuzz.cpp", "build/pom_emul.o", "build/pom_oracle.o",
+        "-o", "build/emul_fuzz")
+    run("g++", "-shared", "-o", "build/libpom_emul.so", "build/pom_emul.o")
+    lib = C.CDLL(os.path.join(BUILD, "libpom_emul.so"))
+    lib.pom_emul_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.pom_emul_step.restype = C.c_uint32
+    return lib
+
+
+@pytest.mark.parametrize("scenario", [0, 1, 2, 3])
+def test_device_tick_body_matches_oracle_under_random_play(emul_bins, scenario):
+    out = subprocess.run([os.path.join(BUILD, "emul_fuzz"), str(scenario), "150000", "5"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert "0 mismatches" in out.stdout
+
+
+def test_pack_unpack_round_trip_and_rejections(emul_bins):
+    idle = np.zeros(4, dtype=np.int32)
+    boards = pa.make_boards(64, seed=9, kind="stress")
+    for i in range(len(boards)):
+        s = boards[i:i + 1].copy()
+        s["board"][0, 5, 5] = Item.BOMB  # still a legal value
+        before = s.copy()
+        st = C.c_uint32(1)  # done in ENV mode: the tick is skipped, only pack -> unpack happens
+        assert emul_bins.pom_emul_step(s.ctypes.data, idle.ctypes.data, 1, 0, C.byref(st)) == 0
+        assert s.tobytes() == before.tobytes()
+    bad = pa.new_states(1)
+    for poke in (lambda s: s["board"].__setitem__((0, 3, 3), 0x5000),          # between the item ranges
+                 lambda s: s["board"].__setitem__((0, 3, 3), -1),
+                 lambda s: s["board"].__setitem__((0, 3, 3), Item.AGENT0 + 4),  # a fifth agent
+                 lambda s: s["agents"]["x"].__setitem__((0, 1), 11),
+                 lambda s: s["bombs_count"].__setitem__(0, 21),
+                 lambda s: s["bombs_index"].__setitem__(0, 20),
+                 lambda s: s["agents"]["bombStrength"].__setitem__((0, 0), 256)):
+        s = bad.copy()
+        poke(s)
+        assert emul_bins.pom_emul_step(s.ctypes.data, idle.ctypes.data, 0, 0, None) == 0xFFFFFFFF
+
+
+def test_env_epilogue_timeout_and_winner(emul_bins):
+    s = pa.new_states(1)
+    pa.put_agents_in_corners(s[0])
+    pa.kill(s[0], 1, 2)
+    st = C.c_uint32(0)
+    mv = np.zeros(4, dtype=np.int32)
+    emul_bins.pom_emul_step(s.ctypes.data, mv.ctypes.data, 1, 3, C.byref(st))
+    assert st.value == 0 and s["timeStep"][0] == 1
+    pa.kill(s[0], 0)
+    emul_bins.pom_emul_step(s.ctypes.data, mv.ctypes.data, 1, 3, C.byref(st))
+    assert st.value & 1 and ((st.value >> 2) & 7) - 1 == 3  # agent 3 won
+    s2 = pa.new_states(1)
+    pa.put_agents_in_corners(s2[0])
+    st = C.c_uint32(0)
+    for _ in range(3):
+        emul_bins.pom_emul_step(s2.ctypes.data, mv.ctypes.data, 1, 3, C.byref(st))
+    assert st.value & 1 and st.value & 32 and s2["timeStep"][0] == 3  # done by the tick cap

@@ -1,0 +1,175 @@
+"""GPU: BASELINE.json's full sizes through size-independent properties, and the edge cases of the boundary."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import pomcpp_amd as pa
+from pomcpp_amd.batch import (BatchEnvironment, PomError, MODE_ENV, MODE_RAW, DIST_RANDOM, DIST_STRESS, CNT_STEPS, CNT_EPISODES,
+                              CNT_RESETS, CNT_UB_TICKS, UB_LOST_AGENT)
+from pomcpp_amd.state import Item, Move
+
+pytestmark = pytest.mark.gpu
+
+
+def _digest(states):
+    s = states.copy()
+    s["agents"]["pad"] = 0
+    return hashlib.blake2b(s.tobytes(), digest_size=16).hexdigest()
+
+
+@pytest.mark.parametrize("n,kind,dist", [(65536, "ffa", DIST_RANDOM), (65536, "stress", DIST_STRESS)])
+def test_full_size_is_deterministic_residency_invariant_and_matches_oracle_sample(hip_lib, oracle, n, kind, dist):
+    """65,536 envs (configs 3/5 size): the result must not depend on how many ticks stay resident in LDS per
+    launch, must be reproducible, must account for every env-step, and a 4,096-env slice must equal the oracle."""
+    ticks, seed = 96, 1234
+    start = pa.make_boards(n, seed=77, kind=kind)
+    digests, finals = [], []
+    for tpl in (1, 1, 16, 96):
+        with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800) as env:
+            env.make_game(start)
+            env.step_random(seed, dist, ticks=ticks, ticks_per_launch=tpl)
+            got = env.get_state()
+            cnt = env.counters()
+            st = env.status()
+        assert cnt[CNT_STEPS] == n * ticks
+        # an episode that ended is either still finished at the end or was restarted
+        assert cnt[CNT_EPISODES] == cnt[CNT_RESETS] + st["done"].sum()
+        digests.append(_digest(got))
+        finals.append(got)
+    assert len(set(digests)) == 1
+    lo = 20000
+    want = start[lo:lo + 4096].copy()
+    oracle.run_random(want, np.ascontiguousarray(start[lo:lo + 4096]), ticks, seed, lo, 0, dist, 800)
+    assert _digest(finals[0][lo:lo + 4096]) == _digest(want)
+
+
+def test_262144_envs_step_counts_and_shard_equivalence(hip_lib):
+    """Config 4's size on one GPU: stepping the whole batch equals stepping its 4 shards with env_offset."""
+    n, ticks, seed = 262144, 12, 5
+    start = pa.make_boards(n, seed=3)
+    with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800) as env:
+        env.make_game(start)
+        env.step_random(seed, DIST_RANDOM, ticks=ticks)
+        whole = env.get_state()
+        assert env.counters()[CNT_STEPS] == n * ticks
+    q = n // 4
+    for k in (0, 3):
+        with BatchEnvironment(q, mode=MODE_ENV, auto_reset=True, max_steps=800, env_offset=k * q) as env:
+            env.make_game(start[k * q:(k + 1) * q])
+            env.step_random(seed, DIST_RANDOM, ticks=ticks)
+            assert _digest(env.get_state()) == _digest(whole[k * q:(k + 1) * q])
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 129])
+def test_ragged_batch_sizes(hip_lib, oracle, n):
+    start = pa.make_boards(n, seed=n)
+    rng = np.random.default_rng(n)
+    ref = start.copy()
+    with BatchEnvironment(n, mode=MODE_RAW) as env:
+        env.make_game(start)
+        for _ in range(30):
+            mv = rng.integers(0, 6, size=(n, 4), dtype=np.int32)
+            env.step(mv)
+            oracle.step_batch(ref, mv)
+        assert _digest(env.get_state()) == _digest(ref)
+        assert env.counters()[CNT_STEPS] == 30 * n
+
+
+def test_partial_upload_download_ranges(hip_lib):
+    n = 200
+    a, b = pa.make_boards(n, seed=1), pa.make_boards(n, seed=2)
+    with BatchEnvironment(n, mode=MODE_RAW) as env:
+        env.make_game(a)
+        env.make_game(b[50:120], first=50)
+        got = env.get_state()
+        assert _digest(got[:50]) == _digest(a[:50]) and _digest(got[50:120]) == _digest(b[50:120])
+        assert _digest(got[120:]) == _digest(a[120:])
+        assert _digest(env.get_state(60, 7)) == _digest(b[60:67])
+        with pytest.raises(PomError) as e:
+            env.get_state(150, 51)
+        assert e.value.code == 1
+        with pytest.raises(PomError):
+            env.make_game(a, first=1)
+
+
+def test_empty_batch_and_bad_arguments(hip_lib):
+    with pytest.raises(PomError) as e:
+        BatchEnvironment(0)
+    assert e.value.code == 1
+    with pytest.raises(PomError):
+        BatchEnvironment(64, device=99)
+    with BatchEnvironment(8) as env:
+        with pytest.raises(ValueError):
+            env.step(np.zeros((8, 3), dtype=np.int32))
+        with pytest.raises(PomError):
+            env.step_random(1, 7, 1, 1)
+        assert env.get_state(0, 0).size == 0  # empty range is fine
+
+
+def test_unrepresentable_state_is_rejected_not_altered(hip_lib):
+    s = pa.make_boards(130, seed=8)
+    s["board"][77, 4, 4] = 12345678  # no reachable game state holds this
+    with BatchEnvironment(130, mode=MODE_ENV) as env:
+        with pytest.raises(PomError) as e:
+            env.make_game(s)
+        assert e.value.code == 3 and "env 77" in str(e.value)
+        st = env.status()
+        assert st["done"][77] == 1 and st["done"].sum() == 1  # parked as a finished blank board
+        got = env.get_state()
+        assert _digest(got[:77]) == _digest(s[:77]) and _digest(got[78:]) == _digest(s[78:])
+
+
+def test_out_of_range_move_values_and_dead_agent_moves(hip_lib, oracle):
+    """Move[4] entries of dead agents and values outside 0..5 are inputs: same result as the oracle."""
+    n = 256
+    start = pa.make_boards(n, seed=12)
+    for e in range(0, n, 3):
+        pa.kill(start[e], 1)
+    rng = np.random.default_rng(0)
+    ref = start.copy()
+    with BatchEnvironment(n, mode=MODE_RAW) as env:
+        env.make_game(start)
+        for _ in range(40):
+            mv = rng.integers(-2, 9, size=(n, 4), dtype=np.int32)
+            env.step(mv)
+            oracle.step_batch(ref, mv)
+        assert _digest(env.get_state()) == _digest(ref)
+
+
+def test_lost_agent_is_flagged_and_counted(hip_lib):
+    s = pa.new_states(64)
+    for e in range(64):
+        pa.put_agent(s[e], 0, 0, 0)
+        pa.put_agent(s[e], 2, 0, 1)
+        pa.put_agent(s[e], 1, 0, 2)
+        pa.put_agent(s[e], 1, 1, 3)
+    mv = np.tile(np.array([Move.RIGHT, Move.LEFT, Move.DOWN, Move.DOWN], dtype=np.int32), (64, 1))
+    with BatchEnvironment(64, mode=MODE_RAW) as env:
+        env.make_game(s)
+        env.step(mv)
+        st = env.status()
+        assert np.all(st["ubflags"] & UB_LOST_AGENT)
+        assert env.counters()[CNT_UB_TICKS] == 64
+        got = env.get_state()
+        assert np.all(got["agents"]["x"][:, 2] == 1) and np.all(got["agents"]["y"][:, 2] == 1)
+
+
+def test_single_state_drop_in_and_status_api(hip_lib, oracle):
+    from pomcpp_amd.batch import step_one
+    s = pa.make_boards(1, seed=4)
+    ref = s.copy()
+    rng = np.random.default_rng(4)
+    for _ in range(25):
+        mv = rng.integers(0, 6, size=4, dtype=np.int32)
+        step_one(s, mv)
+        oracle.step(ref, mv)
+    assert _digest(s) == _digest(ref)
+    with BatchEnvironment(3, mode=MODE_ENV, max_steps=5) as env:
+        env.make_game(pa.make_boards(3, seed=1))
+        for _ in range(7):
+            env.step(np.zeros((3, 4), dtype=np.int32))
+        st = env.status()
+        assert st["time_step"].tolist() == [5, 5, 5] and st["done"].tolist() == [1, 1, 1]  # frozen at the cap
+        assert st["winner"].tolist() == [-1, -1, -1] and env.is_done().all() and not env.is_draw().any()
+        env.snapshot()  # current state becomes the restart point, status cleared there
