@@ -1,0 +1,282 @@
+// pom_bboard.hpp — C++ host surface over the C-ABI (pom_batch.h) that keeps the reference's names for the
+// Step path, so code written against pomcpp's bboard.hpp — agents that read a `const State*`, game loops that
+// call `bboard::Step(State*, Move*)` — compiles against this header unchanged and runs the tick on the MI355X.
+//
+// What is mirrored (file:line in /root/reference/include/bboard.hpp): the constants :15-27, Move :35-43,
+// Direction :45-52, Item and its predicates :54-109, FixedQueue :115-188, Position :192-201, AgentInfo :228-245,
+// the bit-packed Bomb and its accessors :261-335, Flame :342-347, State :356-511 (identical 1004-byte layout,
+// checked below), Agent :517-533 and `Step` :668; from step_utility.hpp the two helpers agents call,
+// DesiredPosition :16 and IsOutOfBounds :155-166.  State methods that only place things are host inlines; the
+// ones that simulate (SpawnFlame, PopFlame, Explode*) live on the device path inside Step and are not offered
+// as host calls.  `BatchEnvironment` is the n-game counterpart of bboard::Environment :541-644.
+//
+// Not a port: there is no simulation code in this header.  Step() hands the State to libpom_batch.so.
+#ifndef POM_BBOARD_HPP_
+#define POM_BBOARD_HPP_
+
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "pom_batch.h"
+
+namespace bboard {
+
+constexpr int MOVE_COUNT = 4, AGENT_COUNT = 4, BOARD_SIZE = 11;
+constexpr int BOMB_LIFETIME = 10, BOMB_DEFAULT_STRENGTH = 1, FLAME_LIFETIME = 4;
+constexpr int MAX_BOMBS_PER_AGENT = 5, MAX_BOMBS = AGENT_COUNT * MAX_BOMBS_PER_AGENT;
+
+enum class Move : int { IDLE = 0, UP, DOWN, LEFT, RIGHT, BOMB };
+enum class Direction : int { IDLE = 0, UP, DOWN, LEFT, RIGHT };
+
+enum Item : int {
+    PASSAGE = POM_PASSAGE, RIGID = POM_RIGID, WOOD = POM_WOOD, BOMB = POM_BOMB, FLAMES = POM_FLAMES, FOG = POM_FOG,
+    EXTRABOMB = POM_EXTRABOMB, INCRRANGE = POM_INCRRANGE, KICK = POM_KICK, AGENTDUMMY = 9,
+    AGENT0 = POM_AGENT0, AGENT1, AGENT2, AGENT3
+};
+
+constexpr bool IS_WOOD(int v) { return (v >> 8) == 2; }
+constexpr bool IS_POWERUP(int v) { return v > 5 && v < 9; }
+constexpr bool IS_WALKABLE(int v) { return v == 0 || IS_POWERUP(v); }
+constexpr bool IS_FLAME(int v) { return (v >> 16) == 4; }
+constexpr bool IS_AGENT(int v) { return v >= (1 << 24); }
+constexpr bool IS_STATIC_MOV_BLOCK(int v) { return v == 1 || IS_WOOD(v) || IS_POWERUP(v); }
+constexpr int FLAME_ID(int v) { return (v & 0xFFFF) >> 3; }
+constexpr int FLAME_POWFLAG(int v) { return v & 3; }
+constexpr int WOOD_POWFLAG(int v) { return v & 3; }
+
+template <typename T, int TSize>
+struct FixedQueue {  // circular buffer; element k of the live range is queue[(index + k) % TSize]
+    T queue[TSize];
+    int index = 0;
+    int count = 0;
+
+    int RemainingCapacity() const { return TSize - count; }
+    T& NextPos() { return queue[(index + count) % TSize]; }
+    void AddElem(const T& e) { NextPos() = e; ++count; }
+    T& PopElem()
+    {
+        T& top = queue[index % TSize];
+        index = (index + 1) % TSize;
+        --count;
+        return top;
+    }
+    void RemoveAt(int at)
+    {
+        for (int k = at + 1; k < count; ++k) queue[(index + k - 1) % TSize] = queue[(index + k) % TSize];
+        --count;
+    }
+    T& operator[](int k) { return queue[(index + k) % TSize]; }
+    const T& operator[](int k) const { return queue[(index + k) % TSize]; }
+};
+
+struct Position {
+    int x, y;
+};
+inline bool operator==(const Position& a, const Position& b) { return a.x == b.x && a.y == b.y; }
+
+struct AgentInfo {
+    int x, y;
+    int bombCount = 0, maxBombCount = 1, bombStrength = BOMB_DEFAULT_STRENGTH;
+    bool canKick = false, dead = false;
+    Position GetPos() const { return {x, y}; }
+};
+
+// one int per bomb: x[0,4) y[4,8) id[8,12) strength[12,16) time[16,20) direction[20,24) moved[24,28)
+typedef int Bomb;
+constexpr int BMB_POS(Bomb b) { return b & 0xFF; }
+constexpr int BMB_POS_X(Bomb b) { return b & 0xF; }
+constexpr int BMB_POS_Y(Bomb b) { return (b >> 4) & 0xF; }
+constexpr int BMB_ID(Bomb b) { return (b >> 8) & 0xF; }
+constexpr int BMB_STRENGTH(Bomb b) { return (b >> 12) & 0xF; }
+constexpr int BMB_TIME(Bomb b) { return (b >> 16) & 0xF; }
+constexpr int BMB_DIR(Bomb b) { return (b >> 20) & 0xF; }
+constexpr int BMB_MOVED(Bomb b) { return (b >> 24) & 0xF; }
+namespace detail {
+inline void put_nibbles(Bomb& b, unsigned mask, unsigned v) { b = int((unsigned(b) & ~mask) + v); }
+}
+inline void ReduceBombTimer(Bomb& b) { b = int(unsigned(b) - (1u << 16)); }
+inline void SetBombPosition(Bomb& b, int x, int y) { detail::put_nibbles(b, 0xFFu, unsigned(x) + (unsigned(y) << 4)); }
+inline void SetBombID(Bomb& b, int id) { detail::put_nibbles(b, 0xF00u, unsigned(id) << 8); }
+inline void SetBombStrength(Bomb& b, int s) { detail::put_nibbles(b, 0xF000u, unsigned(s) << 12); }
+inline void SetBombTime(Bomb& b, int t) { detail::put_nibbles(b, 0xF0000u, unsigned(t) << 16); }
+inline void SetBombDirection(Bomb& b, Direction d) { detail::put_nibbles(b, 0xF00000u, unsigned(d) << 20); }
+inline void SetBombMovedFlag(Bomb& b, bool m) { detail::put_nibbles(b, 0xF000000u, unsigned(m) << 24); }
+
+struct Flame {
+    Position position;
+    int timeLeft = FLAME_LIFETIME;
+    int strength;
+};
+
+struct State {
+    int board[BOARD_SIZE][BOARD_SIZE];  // [y][x]
+    int timeStep = 0;
+    int aliveAgents = AGENT_COUNT;
+    AgentInfo agents[AGENT_COUNT];
+    FixedQueue<Bomb, MAX_BOMBS> bombs;
+    FixedQueue<Flame, MAX_BOMBS> flames;
+
+    int& operator[](const Position& p) { return board[p.y][p.x]; }
+    void PutItem(int x, int y, Item item) { board[y][x] = item; }
+    void PutAgent(int x, int y, int id)
+    {
+        board[y][x] = AGENT0 + id;
+        agents[id].x = x;
+        agents[id].y = y;
+    }
+    void PutAgentsInCorners(int a0, int a1, int a2, int a3)
+    {
+        const int e = BOARD_SIZE - 1;
+        board[0][0] = AGENT0 + a0;
+        board[0][e] = AGENT0 + a1;
+        board[e][e] = AGENT0 + a2;
+        board[e][0] = AGENT0 + a3;
+        agents[a1].x = agents[a2].x = e;
+        agents[a2].y = agents[a3].y = e;
+    }
+    void Kill(int id)
+    {
+        if (!agents[id].dead) {
+            agents[id].dead = true;
+            --aliveAgents;
+        }
+    }
+    template <typename... Rest>
+    void Kill(int id, Rest... rest)
+    {
+        Kill(id);
+        Kill(rest...);
+    }
+    void PlantBombModifiedLife(int x, int y, int id, int lifeTime = BOMB_LIFETIME, bool setItem = false)
+    {
+        if (agents[id].bombCount >= agents[id].maxBombCount) return;
+        Bomb& b = bombs.NextPos();  // the slot's other bits are deliberately left as they are
+        SetBombID(b, id);
+        SetBombPosition(b, x, y);
+        SetBombStrength(b, agents[id].bombStrength);
+        SetBombTime(b, lifeTime);
+        if (setItem) board[y][x] = BOMB;
+        ++agents[id].bombCount;
+        ++bombs.count;
+    }
+    void PlantBomb(int x, int y, int id, bool setItem = false) { PlantBombModifiedLife(x, y, id, BOMB_LIFETIME, setItem); }
+    int GetBombIndex(int x, int y) const
+    {
+        for (int k = 0; k < bombs.count; ++k)
+            if (BMB_POS(bombs[k]) == x + (y << 4)) return k;
+        return -1;
+    }
+    bool HasBomb(int x, int y) const { return GetBombIndex(x, y) >= 0; }
+    Bomb* GetBomb(int x, int y)
+    {
+        const int k = GetBombIndex(x, y);
+        return k < 0 ? nullptr : &bombs[k];
+    }
+    int GetAgent(int x, int y) const
+    {
+        for (int i = 0; i < AGENT_COUNT; ++i)
+            if (!agents[i].dead && agents[i].x == x && agents[i].y == y) return i;
+        return -1;
+    }
+    static Item FlagItem(int flag) { return flag >= 1 && flag <= 3 ? Item(EXTRABOMB + flag - 1) : PASSAGE; }
+};
+
+static_assert(sizeof(State) == POM_STATE_BYTES, "bboard::State must stay the reference's 1004 bytes");
+static_assert(offsetof(State, timeStep) == 484 && offsetof(State, aliveAgents) == 488, "State layout");
+static_assert(offsetof(State, agents) == 492 && sizeof(AgentInfo) == 24 && offsetof(AgentInfo, canKick) == 20, "State layout");
+static_assert(offsetof(State, bombs) == 588 && offsetof(State, flames) == 676 && sizeof(Flame) == 16, "State layout");
+
+struct Agent {  // a behaviour: State in, Move out
+    virtual ~Agent() {}
+    int id = -1;
+    virtual Move act(const State* state) = 0;
+};
+
+struct PomException : std::runtime_error {
+    int code;
+    PomException(int c, const char* what) : std::runtime_error(what), code(c) {}
+};
+inline void pom_check(int rc)
+{
+    if (rc != POM_OK) throw PomException(rc, pom_last_error());
+}
+
+// One simulation tick of one State, executed on the GPU (bboard.hpp:668).  `moves` holds AGENT_COUNT entries.
+inline void Step(State* state, Move* moves)
+{
+    static_assert(sizeof(Move) == sizeof(int32_t), "Move is an int enum");
+    pom_check(pom_step(state, reinterpret_cast<const int32_t*>(moves)));
+}
+
+namespace util {
+inline Position DesiredPosition(int x, int y, Move m)
+{
+    return {x + (m == Move::RIGHT) - (m == Move::LEFT), y + (m == Move::DOWN) - (m == Move::UP)};
+}
+inline Position DesiredPosition(const Bomb b) { return DesiredPosition(BMB_POS_X(b), BMB_POS_Y(b), Move(BMB_DIR(b))); }
+inline bool IsOutOfBounds(int x, int y) { return x < 0 || y < 0 || x >= BOARD_SIZE || y >= BOARD_SIZE; }
+inline bool IsOutOfBounds(const Position& p) { return IsOutOfBounds(p.x, p.y); }
+}  // namespace util
+
+// n concurrent games on one device: MakeGame / Step / IsDone / IsDraw / GetWinner / GetState of Environment,
+// with moves for all n games handed over at once.  Agents are asked for a move only while alive
+// (environment.cpp:139-146); a dead agent's entry is IDLE.
+class BatchEnvironment {
+public:
+    explicit BatchEnvironment(int64_t n, int device = 0, bool autoReset = false, int maxSteps = 0) : n_(n), states_(size_t(n))
+    {
+        PomBatchOptions o{};
+        o.struct_size = sizeof o;
+        o.device = device;
+        o.mode = POM_MODE_ENV;
+        o.auto_reset = autoReset;
+        o.max_steps = maxSteps;
+        pom_check(pom_batch_create(&h_, n, &o));
+    }
+    ~BatchEnvironment() { pom_batch_destroy(h_); }
+    BatchEnvironment(const BatchEnvironment&) = delete;
+    BatchEnvironment& operator=(const BatchEnvironment&) = delete;
+
+    int64_t Size() const { return n_; }
+    void MakeGame(const State* start) { pom_check(pom_batch_upload(h_, start, 0, n_)); }
+    void Step(const Move* moves /* [n][AGENT_COUNT] */) { pom_check(pom_batch_step(h_, reinterpret_cast<const int32_t*>(moves))); }
+    // ask `agents` (shared by all games) for moves on the current states, then step: Environment::Step
+    void Step(const std::array<Agent*, AGENT_COUNT>& agents)
+    {
+        const State* st = GetStates();
+        std::vector<Move> mv(size_t(n_) * AGENT_COUNT, Move::IDLE);
+        for (int64_t e = 0; e < n_; ++e)
+            for (int i = 0; i < AGENT_COUNT; ++i)
+                if (!st[e].agents[i].dead) {
+                    agents[i]->id = i;
+                    mv[size_t(e) * AGENT_COUNT + i] = agents[i]->act(&st[e]);
+                }
+        Step(mv.data());
+    }
+    const State* GetStates()
+    {
+        pom_check(pom_batch_download(h_, states_.data(), 0, n_));
+        return states_.data();
+    }
+    void Status(std::vector<int32_t>& done, std::vector<int32_t>& winner, std::vector<int32_t>& draw)
+    {
+        done.resize(size_t(n_));
+        winner.resize(size_t(n_));
+        draw.resize(size_t(n_));
+        pom_check(pom_batch_status(h_, 0, n_, done.data(), winner.data(), draw.data(), nullptr, nullptr, nullptr));
+    }
+    PomBatch* Handle() { return h_; }
+
+private:
+    PomBatch* h_ = nullptr;
+    int64_t n_;
+    std::vector<State> states_;
+};
+
+}  // namespace bboard
+
+#endif  // POM_BBOARD_HPP_

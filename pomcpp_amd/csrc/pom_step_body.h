@@ -64,8 +64,24 @@ POM_HD int pb_time(int b) { return (b >> 16) & 0xF; }
 POM_HD int pb_dir(int b) { return (b >> 20) & 0xF; }
 POM_HD int pb_set(int b, uint32_t mask, uint32_t v) { return (int)(((uint32_t)b & ~mask) + v); }
 
-/* ---- 4-way register selects for the agents */
-POM_HD int sel4(int i, const int v[4]) { return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3]; }
+/* ---- 4-way register selects for the agents.
+ * hipcc folds select(cond, load v[0], load v[1]) into a dynamically indexed load, which pins the whole
+ * array in scratch (4 scratch_store + 1 scratch_load per use, hundreds of cycles each on gfx950).  Passing
+ * each value through an empty asm makes it an opaque VGPR value, so the chain stays 3 v_cndmask. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define POM_IN_VGPR(x) asm("" : "+v"(x))
+#else
+#define POM_IN_VGPR(x) ((void)0)
+#endif
+POM_HD int sel4(int i, const int v[4])
+{
+    int v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+    POM_IN_VGPR(v0);
+    POM_IN_VGPR(v1);
+    POM_IN_VGPR(v2);
+    POM_IN_VGPR(v3);
+    return i == 0 ? v0 : i == 1 ? v1 : i == 2 ? v2 : v3;
+}
 POM_HD void put4(int i, int v[4], int x)
 {
     v[0] = i == 0 ? x : v[0];
