@@ -54,6 +54,8 @@ typedef struct PomBatchOptions {
     int32_t auto_reset;   /* ENV mode: a finished env is reloaded from its snapshot and stepped in the same tick */
     int32_t max_steps;    /* ENV mode: env is done once timeStep reaches this (0 = no limit); StartGame's bound, environment.cpp:71 */
     int64_t env_offset;   /* global index of env 0, keys the synthetic move stream when a job is sharded over GPUs */
+    int32_t envs_per_wave; /* 0 = choose by batch size; else 16, 32 or 64 envs per wavefront (results are identical) */
+    int32_t reserved_;
 } PomBatchOptions;
 
 typedef struct PomBatch PomBatch;

@@ -16,7 +16,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define POM_HD __host__ __device__ inline
+#define POM_HD __host__ __device__ __attribute__((always_inline)) inline
 #elif defined(__cplusplus)
 #define POM_HD inline
 #else

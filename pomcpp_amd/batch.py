@@ -39,7 +39,7 @@ class _Options(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p),
         ("mode", C.c_int32), ("auto_reset", C.c_int32), ("max_steps", C.c_int32),
-        ("env_offset", C.c_int64),
+        ("env_offset", C.c_int64), ("envs_per_wave", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -104,11 +104,11 @@ def step_one(state: np.ndarray, moves) -> None:
 
 class BatchEnvironment:
     def __init__(self, n_envs: int, device: int = 0, mode: int = MODE_ENV, auto_reset: bool = False,
-                 max_steps: int = 0, env_offset: int = 0, stream: Optional[int] = None):
+                 max_steps: int = 0, env_offset: int = 0, stream: Optional[int] = None, envs_per_wave: int = 0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.n = int(n_envs)
-        o = _Options(C.sizeof(_Options), device, stream, mode, int(auto_reset), max_steps, env_offset)
+        o = _Options(C.sizeof(_Options), device, stream, mode, int(auto_reset), max_steps, env_offset, envs_per_wave, 0)
         _check(self._lib, self._lib.pom_batch_create(C.byref(self._h), self.n, C.byref(o)))
 
     def close(self) -> None:

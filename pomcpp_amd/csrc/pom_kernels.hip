@@ -13,6 +13,7 @@
 
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -34,18 +35,26 @@ enum {
 };
 
 
+/*
+ * EPW = envs per wavefront (64, 32 or 16).  The tick is executed by ONE lane per env; with EPW < 64 the other
+ * lanes of the wavefront only help moving the record (each DMA / store instruction then covers 64/EPW rows),
+ * which trades idle lanes for more resident wavefronts per SIMD: the tick is bound by issue latency, not by
+ * lane throughput, and a batch of a few thousand envs would otherwise leave most of the 1024 SIMDs empty.
+ * The LDS tile is [row][EPW]; bank = (row*EPW + env) mod 32.
+ */
+template <int EPW>
 struct LdsEnv {
-    uint32_t* t; /* &tile[lane] */
-    __device__ int cell(int c) const { return reinterpret_cast<const uint16_t*>(t)[(c >> 1) * 128 + (c & 1)]; }
-    __device__ void set_cell(int c, int v) { reinterpret_cast<uint16_t*>(t)[(c >> 1) * 128 + (c & 1)] = (uint16_t)v; }
-    __device__ int bomb(int s) const { return (int)t[(ROW_BOMBS + s) * 64]; }
-    __device__ void set_bomb(int s, int v) { t[(ROW_BOMBS + s) * 64] = (uint32_t)v; }
-    __device__ int flame(int s) const { return (int)t[(ROW_FLAMES + s) * 64]; }
-    __device__ void set_flame(int s, int v) { t[(ROW_FLAMES + s) * 64] = (uint32_t)v; }
-    __device__ int bdest(int i) const { return reinterpret_cast<const uint8_t*>(t + ROW_BDEST * 64)[(i >> 2) * 256 + (i & 3)]; }
-    __device__ void set_bdest(int i, int v) { reinterpret_cast<uint8_t*>(t + ROW_BDEST * 64)[(i >> 2) * 256 + (i & 3)] = (uint8_t)v; }
-    __device__ int frame(int d) const { return (int)t[(ROW_STACK + d) * 64]; }
-    __device__ void set_frame(int d, int v) { t[(ROW_STACK + d) * 64] = (uint32_t)v; }
+    uint32_t* t; /* &tile[env_in_wave] */
+    __device__ int cell(int c) const { return reinterpret_cast<const uint16_t*>(t)[(c >> 1) * (2 * EPW) + (c & 1)]; }
+    __device__ void set_cell(int c, int v) { reinterpret_cast<uint16_t*>(t)[(c >> 1) * (2 * EPW) + (c & 1)] = (uint16_t)v; }
+    __device__ int bomb(int s) const { return (int)t[(ROW_BOMBS + s) * EPW]; }
+    __device__ void set_bomb(int s, int v) { t[(ROW_BOMBS + s) * EPW] = (uint32_t)v; }
+    __device__ int flame(int s) const { return (int)t[(ROW_FLAMES + s) * EPW]; }
+    __device__ void set_flame(int s, int v) { t[(ROW_FLAMES + s) * EPW] = (uint32_t)v; }
+    __device__ int bdest(int i) const { return reinterpret_cast<const uint8_t*>(t + ROW_BDEST * EPW)[(i >> 2) * (4 * EPW) + (i & 3)]; }
+    __device__ void set_bdest(int i, int v) { reinterpret_cast<uint8_t*>(t + ROW_BDEST * EPW)[(i >> 2) * (4 * EPW) + (i & 3)] = (uint8_t)v; }
+    __device__ int frame(int d) const { return (int)t[(ROW_STACK + d) * EPW]; }
+    __device__ void set_frame(int d, int v) { t[(ROW_STACK + d) * EPW] = (uint32_t)v; }
 };
 
 struct StepParams {
@@ -57,66 +66,126 @@ struct StepParams {
     uint64_t seed;
     uint32_t tick0;
     int32_t dist, ticks, mode, auto_reset, max_steps;
+#if defined(POM_DIAG)
+    long long* diag; /* POM_PH_N accumulators per wavefront, diagnostic build only */
+#endif
 };
 
-/* rows of the HBM record that go to LDS: board, bombs, flames */
-__device__ __forceinline__ void load_tile(const uint32_t* __restrict__ col, int64_t np, uint32_t* t)
+/*
+ * HBM -> LDS without touching VGPRs: `global_load_lds_dword` takes a per-lane global address and writes LDS
+ * at (wave-uniform base) + 4*lane.  With the [row][EPW] tile one instruction therefore lands 64/EPW
+ * consecutive rows (lane l -> row r0 + l/EPW, env l%EPW); all rows are in flight at once, no ds_write.
+ * `col` may differ per lane: state column or snapshot column of the lane's env.
+ */
+__device__ __forceinline__ void dma_rows(const uint32_t* g, uint32_t* lds_base)
 {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
+}
+template <int EPW, int REC0, int LDS0, int ROWS>
+__device__ __forceinline__ void load_segment(const uint32_t* col, int64_t np, uint32_t* tile, int sub)
+{
+    constexpr int G = 64 / EPW;
+    /* a rolled loop with a running pointer: fully unrolled, hipcc precomputes all 101 per-lane 64-bit
+     * addresses first (200+ VGPRs), which caps the occupancy the smaller EPW variants exist for */
+    const uint32_t* g = col + (int64_t)(REC0 + sub) * np;
+    const int64_t stride = (int64_t)G * np;
+#pragma unroll 4
+    for (int r0 = 0; r0 < ROWS; r0 += G) {
+        if (G == 1 || r0 + sub < ROWS) dma_rows(g, tile + (LDS0 + r0) * EPW);
+        g += stride;
+    }
+}
+template <int EPW>
+__device__ __forceinline__ void load_tile(const uint32_t* col, int64_t np, uint32_t* tile, int sub)
+{
+    load_segment<EPW, POM_REC_BOARD, ROW_BOARD, 61>(col, np, tile, sub);
+    load_segment<EPW, POM_REC_BOMBS, ROW_BOMBS, 20>(col, np, tile, sub);
+    load_segment<EPW, POM_REC_FLAMES, ROW_FLAMES, 20>(col, np, tile, sub);
+}
+template <int EPW, int REC0, int LDS0, int ROWS>
+__device__ __forceinline__ void store_segment(uint32_t* col, int64_t np, const uint32_t* tile, int sub, int el)
+{
+    constexpr int G = 64 / EPW;
+    uint32_t* g = col + (int64_t)(REC0 + sub) * np;
+    const int64_t stride = (int64_t)G * np;
+    const uint32_t* l = tile + (LDS0 + sub) * EPW + el;
 #pragma unroll 8
-    for (int r = 0; r < 61; r++) t[(ROW_BOARD + r) * 64] = col[(POM_REC_BOARD + r) * np];
-#pragma unroll 10
-    for (int r = 0; r < 20; r++) t[(ROW_BOMBS + r) * 64] = col[(POM_REC_BOMBS + r) * np];
-#pragma unroll 10
-    for (int r = 0; r < 20; r++) t[(ROW_FLAMES + r) * 64] = col[(POM_REC_FLAMES + r) * np];
+    for (int r0 = 0; r0 < ROWS; r0 += G) {
+        if (G == 1 || r0 + sub < ROWS) *g = l[r0 * EPW];
+        g += stride;
+    }
 }
 
-__global__ __launch_bounds__(64) void pom_step_kernel(StepParams p)
+template <int EPW>
+__global__ __launch_bounds__(64, (EPW == 16 ? 4 : 2)) void pom_step_kernel(StepParams p)
 {
-    __shared__ uint32_t tile[LDS_ROWS * 64];
+    __shared__ uint32_t tile[LDS_ROWS * EPW];
     const int lane = threadIdx.x;
-    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    const int el = lane % EPW, sub = lane / EPW; /* env within the wavefront; which of the 64/EPW row groups this lane moves */
+    const int64_t e = (int64_t)blockIdx.x * EPW + el;
     const int64_t np = p.n_pad;
-    const bool valid = e < p.n;
+    const bool owner = sub == 0;             /* the lane that runs env e's tick */
+    const bool valid = owner && e < p.n;
     const bool env_mode = p.mode == POM_MODE_ENV;
-    uint32_t* t = tile + lane;
-    uint32_t* col = p.state + e;           /* buffers hold n_pad columns: in range for every lane */
+    uint32_t* t = tile + el;
+    uint32_t* col = p.state + e;             /* buffers hold n_pad columns: in range for every lane */
     const uint32_t* scol = p.snap + e;
 
+#if defined(POM_DIAG)
+    const long long t_begin = (long long)clock64();
+#endif
     uint32_t status = (col[POM_REC_META2 * np] >> 8) & 0xFF;
     long long c_steps = 0, c_episodes = 0, c_resets = 0, c_ub = 0;
 
     /* a finished env restarts from its snapshot: pick the source column per lane, one pass */
-    bool reload = valid && env_mode && p.auto_reset && (status & POM_ST_DONE);
+    bool reload = e < p.n && env_mode && p.auto_reset && (status & POM_ST_DONE);
     const uint32_t* src = reload ? scol : col;
-    load_tile(src, np, t);
-    int time_step = (int)src[POM_REC_TIMESTEP * np];
-    uint32_t ag[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) ag[k] = src[(POM_REC_AGENTS + k) * np];
+    load_tile<EPW>(src, np, tile, sub);
+    int time_step = 0;
+    uint32_t ag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     PomLane L;
     {
-        const uint32_t m2 = src[POM_REC_META2 * np];
-        pom_lane_load(L, src[POM_REC_META * np], m2, ag);
+        uint32_t m = 0, m2 = 0;
+        if (owner) {
+            time_step = (int)src[POM_REC_TIMESTEP * np];
+#pragma unroll
+            for (int k = 0; k < 8; k++) ag[k] = src[(POM_REC_AGENTS + k) * np];
+            m = src[POM_REC_META * np];
+            m2 = src[POM_REC_META2 * np];
+        }
+        pom_lane_load(L, m, m2, ag);
         status = (m2 >> 8) & 0xFF;
     }
-    c_resets += __popcll(__ballot(reload));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the DMA rows have landed (one wavefront per workgroup: no barrier) */
+    c_resets += __popcll(__ballot(reload && owner));
 
-    LdsEnv acc{t};
-    PomStepper<LdsEnv> stepper(acc, L);
+    LdsEnv<EPW> acc{t};
+    PomStepper<LdsEnv<EPW>> stepper(acc, L);
+#if defined(POM_DIAG)
+    for (int k = 0; k < POM_PH_N; k++) L.t_acc[k] = 0;
+    L.t_last = t_begin;
+    POM_STAMP(L, POM_PH_LOAD);
+#endif
 
     for (int tk = 0; tk < p.ticks; tk++) {
         if (tk > 0) {
-            reload = valid && env_mode && p.auto_reset && (status & POM_ST_DONE);
+            /* every lane of the env's row group needs its owner's verdict */
+            const int done_now = __shfl((int)(status & POM_ST_DONE), el);
+            reload = e < p.n && env_mode && p.auto_reset && done_now;
             if (reload) {
-                load_tile(scol, np, t);
-                time_step = (int)scol[POM_REC_TIMESTEP * np];
+                load_tile<EPW>(scol, np, tile, sub); /* EXEC-masked: only the restarting envs' columns are overwritten */
+                if (owner) {
+                    time_step = (int)scol[POM_REC_TIMESTEP * np];
 #pragma unroll
-                for (int k = 0; k < 8; k++) ag[k] = scol[(POM_REC_AGENTS + k) * np];
-                const uint32_t m2 = scol[POM_REC_META2 * np];
-                pom_lane_load(L, scol[POM_REC_META * np], m2, ag);
-                status = (m2 >> 8) & 0xFF;
+                    for (int k = 0; k < 8; k++) ag[k] = scol[(POM_REC_AGENTS + k) * np];
+                    const uint32_t m2 = scol[POM_REC_META2 * np];
+                    pom_lane_load(L, scol[POM_REC_META * np], m2, ag);
+                    status = (m2 >> 8) & 0xFF;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            c_resets += __popcll(__ballot(reload));
+            c_resets += __popcll(__ballot(reload && owner));
         }
         const bool active = valid && !(env_mode && (status & POM_ST_DONE));
         bool newly_done = false, new_ub = false;
@@ -142,24 +211,30 @@ __global__ __launch_bounds__(64) void pom_step_kernel(StepParams p)
         c_steps += __popcll(__ballot(active));
         c_episodes += __popcll(__ballot(newly_done));
         c_ub += __popcll(__ballot(new_ub));
+        POM_STAMP(L, POM_PH_EPILOGUE);
     }
 
-    /* write back */
-#pragma unroll 8
-    for (int r = 0; r < 61; r++) col[(POM_REC_BOARD + r) * np] = t[(ROW_BOARD + r) * 64];
-    col[POM_REC_TIMESTEP * np] = (uint32_t)time_step;
-    col[POM_REC_META * np] = pom_lane_meta(L);
-    col[POM_REC_META2 * np] = pom_lane_meta2(L, status);
+    /* write back: LDS rows by all lanes, the register-resident rows by the owner */
+    store_segment<EPW, POM_REC_BOARD, ROW_BOARD, 61>(col, np, tile, sub, el);
+    store_segment<EPW, POM_REC_BOMBS, ROW_BOMBS, 20>(col, np, tile, sub, el);
+    store_segment<EPW, POM_REC_FLAMES, ROW_FLAMES, 20>(col, np, tile, sub, el);
+    if (owner) {
+        col[POM_REC_TIMESTEP * np] = (uint32_t)time_step;
+        col[POM_REC_META * np] = pom_lane_meta(L);
+        col[POM_REC_META2 * np] = pom_lane_meta2(L, status);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        col[(POM_REC_AGENTS + 2 * i) * np] = (uint32_t)L.a0[i];
-        col[(POM_REC_AGENTS + 2 * i + 1) * np] = (uint32_t)L.a1[i];
+        for (int i = 0; i < 4; i++) {
+            col[(POM_REC_AGENTS + 2 * i) * np] = (uint32_t)L.a0[i];
+            col[(POM_REC_AGENTS + 2 * i + 1) * np] = (uint32_t)L.a1[i];
+        }
     }
-#pragma unroll 10
-    for (int r = 0; r < 20; r++) col[(POM_REC_BOMBS + r) * np] = t[(ROW_BOMBS + r) * 64];
-#pragma unroll 10
-    for (int r = 0; r < 20; r++) col[(POM_REC_FLAMES + r) * np] = t[(ROW_FLAMES + r) * 64];
 
+#if defined(POM_DIAG)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    POM_STAMP(L, POM_PH_STORE);
+    if (lane == 0 && p.diag) /* one slot per wavefront: no contended atomics that would distort the timing */
+        for (int k = 0; k < POM_PH_N; k++) p.diag[(int64_t)blockIdx.x * POM_PH_N + k] += L.t_acc[k];
+#endif
     if (lane == 0) { /* each wavefront owns its slot: no atomics on the tick path */
         int64_t* wc = p.wave_counters + (int64_t)blockIdx.x * POM_CNT_N;
         wc[POM_CNT_STEPS] += c_steps;
@@ -266,7 +341,8 @@ struct PomBatch {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int64_t n = 0, n_pad = 0, n_waves = 0, env_offset = 0;
+    int64_t n = 0, n_pad = 0, n_waves = 0, env_offset = 0; /* n_waves: counter slots, sized for the smallest EPW */
+    int epw = 64;
     int mode = POM_MODE_ENV, auto_reset = 0, max_steps = 0;
     uint32_t* state = nullptr;
     uint32_t* snap = nullptr;
@@ -277,6 +353,9 @@ struct PomBatch {
     int64_t* totals_dev = nullptr;
     int* first_bad = nullptr;
     uint64_t tick = 0;
+#if defined(POM_DIAG)
+    long long* diag = nullptr;
+#endif
 };
 
 extern "C" {
@@ -340,7 +419,21 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
     h->device = o.device;
     h->n = n_envs;
     h->n_pad = (n_envs + 63) / 64 * 64;
-    h->n_waves = h->n_pad / 64;
+    h->n_waves = h->n_pad / 16;
+    /* envs per wavefront: the tick is issue-bound, so what matters is filling the 1024 SIMDs and, for big
+     * batches, not letting the 32 KB tile of 64-env wavefronts cap residency at 5 per CU.  Measured on MI355X
+     * (scripts/epw_sweep.py, profiles/r01_epw_sweep.txt): 16 wins below ~8k envs, 32 from there up. */
+    h->epw = h->n_pad <= 8192 ? 16 : 32;
+    if (o.envs_per_wave == 16 || o.envs_per_wave == 32 || o.envs_per_wave == 64) h->epw = o.envs_per_wave;
+    else if (o.envs_per_wave != 0) {
+        snprintf(g_err, sizeof g_err, "pom_batch_create: envs_per_wave must be 0, 16, 32 or 64");
+        delete h;
+        return POM_E_ARG;
+    }
+    if (const char* ev = getenv("POM_EPW")) { /* tuning override for sweeps */
+        const int v = atoi(ev);
+        if (v == 16 || v == 32 || v == 64) h->epw = v;
+    }
     h->mode = o.mode;
     h->auto_reset = o.auto_reset;
     h->max_steps = o.max_steps;
@@ -475,7 +568,17 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
     p.mode = h->mode;
     p.auto_reset = h->auto_reset;
     p.max_steps = h->max_steps;
-    pom_step_kernel<<<dim3((unsigned)h->n_waves), dim3(64), 0, h->stream>>>(p);
+#if defined(POM_DIAG)
+    if (!h->diag) {
+        HIPCHK(hipMalloc((void**)&h->diag, (size_t)h->n_waves * POM_PH_N * 8));
+        HIPCHK(hipMemsetAsync(h->diag, 0, (size_t)h->n_waves * POM_PH_N * 8, h->stream));
+    }
+    p.diag = h->diag;
+#endif
+    const dim3 grid((unsigned)(h->n_pad / h->epw));
+    if (h->epw == 64) pom_step_kernel<64><<<grid, dim3(64), 0, h->stream>>>(p);
+    else if (h->epw == 32) pom_step_kernel<32><<<grid, dim3(64), 0, h->stream>>>(p);
+    else pom_step_kernel<16><<<grid, dim3(64), 0, h->stream>>>(p);
     HIPCHK(hipGetLastError());
     return POM_OK;
 }
@@ -579,6 +682,28 @@ int pom_batch_device_view(PomBatch* h, void** base, int64_t* n_pad, int32_t* rec
     if (rec_dwords) *rec_dwords = POM_REC_DWORDS;
     return POM_OK;
 }
+
+#if defined(POM_DIAG)
+/* diagnostic build only: the step kernel with zero ticks = HBM -> LDS -> HBM round trip of every record */
+int pom_diag_copy_only(PomBatch* h)
+{
+    return launch_step(h, nullptr, 0, 0, 0);
+}
+/* diagnostic build only: read and clear the per-phase cycle sums (summed over wavefronts) */
+int pom_diag_read(PomBatch* h, long long out[POM_PH_N])
+{
+    if (!h || !h->diag) return POM_E_ARG;
+    long long* tmp = new long long[(size_t)h->n_waves * POM_PH_N];
+    HIPCHK(hipMemcpyAsync(tmp, h->diag, (size_t)h->n_waves * POM_PH_N * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemsetAsync(h->diag, 0, (size_t)h->n_waves * POM_PH_N * 8, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < POM_PH_N; k++) out[k] = 0;
+    for (int64_t w = 0; w < h->n_waves; w++)
+        for (int k = 0; k < POM_PH_N; k++) out[k] += tmp[w * POM_PH_N + k];
+    delete[] tmp;
+    return POM_OK;
+}
+#endif
 
 int pom_step(void* state_1004, const int32_t moves[4])
 {

@@ -38,11 +38,28 @@
 #define POM_Q 20
 #define POM_STACK_DEPTH 21 /* one frame per queued bomb + the initiating flame */
 
+/* POM_DIAG builds (scripts/phase_stamps.py, never shipped) accumulate s_memtime deltas per phase */
+#if defined(POM_DIAG) && defined(__HIP_DEVICE_COMPILE__)
+#define POM_STAMP(L, k)                                   \
+    do {                                                  \
+        const long long now_ = (long long)clock64();      \
+        (L).t_acc[k] += now_ - (L).t_last;                \
+        (L).t_last = now_;                                \
+    } while (0)
+#else
+#define POM_STAMP(L, k) ((void)0)
+#endif
+enum { POM_PH_LOAD = 0, POM_PH_FLAMES, POM_PH_AGENT_PREP, POM_PH_AGENT_LOOP, POM_PH_BOMB_A, POM_PH_BOMB_B, POM_PH_TICK_BOMBS,
+       POM_PH_EPILOGUE, POM_PH_STORE, POM_PH_N };
+
 struct PomLane { /* the register-resident part of one env */
     int a0[4];   /* x:8 | y:8 | bombCount:8 | canKick@24 | dead@25 — only ever indexed statically */
     int a1[4];   /* maxBombCount:16 | bombStrength:16 */
     int alive, bIdx, bCnt, fIdx, fCnt;
     uint32_t ub;
+#if defined(POM_DIAG)
+    long long t_last, t_acc[POM_PH_N];
+#endif
 };
 
 /* ---- cell-code predicates (Item helpers, bboard.hpp:73-109, on 16-bit codes) */
@@ -382,6 +399,7 @@ struct PomStepper {
     POM_HD void step(const int mv_in[4])
     {
         tick_flames(); /* step.cpp:15 */
+        POM_STAMP(L, POM_PH_FLAMES);
 
         /* moves: anything outside 0..5 acts as "no displacement, not IDLE, not BOMB" -> code 6 */
         int mv[4];
@@ -442,6 +460,7 @@ struct PomStepper {
 #pragma unroll
         for (int i = 0; i < 4; i++) dstp |= (uint32_t)(((dx[i] + 1) & 0xF) | (((dy[i] + 1) & 0xF) << 4)) << (8 * i);
 
+        POM_STAMP(L, POM_PH_AGENT_PREP);
         /* agent loop, step.cpp:35-185 */
         {
             int root_idx = 0;
@@ -545,6 +564,7 @@ struct PomStepper {
             }
         }
 
+        POM_STAMP(L, POM_PH_AGENT_LOOP);
         if (L.bCnt > 0) {
             /* ResetBombFlags + FillBombDestPos, step_utility.cpp:331-337,146-152 */
             for (int k = 0; k < L.bCnt; k++) {
@@ -576,6 +596,7 @@ struct PomStepper {
                     }
                 }
             }
+            POM_STAMP(L, POM_PH_BOMB_A);
             /* bomb loop B, step.cpp:230-278 */
             for (int k = 0; k < L.bCnt; k++) {
                 int b = bomb_at(k);
@@ -592,7 +613,7 @@ struct PomStepper {
                     free_way = !pc_is_static_block(te);
                 }
                 if (free_way) {
-                    if (bomb_collision(mvp, k)) continue;
+                    if (d != 0 && bomb_collision(mvp, k)) continue; /* an idle bomb was tested above; nothing changed since */
                     b = bomb_at(k);
                     set_bomb_at(k, pb_set(b, 0xFFu, (uint32_t)tx + ((uint32_t)ty << 4)));
                     if (bomb_index(bx | (by << 4)) < 0 && a.cell(by * POM_N + bx) == POM_C_BOMB)
@@ -614,6 +635,7 @@ struct PomStepper {
                     set_bomb_at(k, pb_set(b, 0xF00000u, 0));
                 }
             }
+            POM_STAMP(L, POM_PH_BOMB_B);
             /* TickBombs, step_utility.cpp:224-245 */
             for (int k = 0; k < L.bCnt; k++)
                 set_bomb_at(k, (int)((uint32_t)bomb_at(k) - (1u << 16)));
@@ -624,6 +646,7 @@ struct PomStepper {
                 run_explosions(begin_flame(0, pb_x(c), pb_y(c), pb_strength(c), POM_REM_TOP));
             }
         }
+        POM_STAMP(L, POM_PH_TICK_BOMBS);
     }
 };
 

@@ -173,3 +173,30 @@ def test_single_state_drop_in_and_status_api(hip_lib, oracle):
         assert st["time_step"].tolist() == [5, 5, 5] and st["done"].tolist() == [1, 1, 1]  # frozen at the cap
         assert st["winner"].tolist() == [-1, -1, -1] and env.is_done().all() and not env.is_draw().any()
         env.snapshot()  # current state becomes the restart point, status cleared there
+
+
+@pytest.mark.parametrize("epw", [16, 32, 64])
+@pytest.mark.parametrize("kind,dist", [("ffa", DIST_RANDOM), ("stress", DIST_STRESS)])
+def test_every_envs_per_wave_variant_matches_oracle(hip_lib, oracle, epw, kind, dist):
+    """The three kernel instantiations (16 / 32 / 64 envs per wavefront) are the same function of the input."""
+    n, ticks, seed = 3000 + epw, 80, 4242
+    start = pa.make_boards(n, seed=31, kind=kind)
+    want = start.copy()
+    oracle.run_random(want, start, ticks, seed, 0, 0, dist, 800)
+    for tpl in (1, 5):
+        with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800, envs_per_wave=epw) as env:
+            env.make_game(start)
+            env.step_random(seed, dist, ticks=ticks, ticks_per_launch=tpl)
+            assert _digest(env.get_state()) == _digest(want)
+            assert env.counters()[CNT_STEPS] == n * ticks
+    rng = np.random.default_rng(epw)
+    ref = start.copy()
+    with BatchEnvironment(n, mode=MODE_RAW, envs_per_wave=epw) as env:
+        env.make_game(start)
+        for _ in range(25):
+            mv = rng.integers(0, 6, size=(n, 4), dtype=np.int32)
+            env.step(mv)
+            oracle.step_batch(ref, mv)
+        assert _digest(env.get_state()) == _digest(ref)
+    with pytest.raises(PomError):
+        BatchEnvironment(64, envs_per_wave=48)
