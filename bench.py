@@ -190,6 +190,10 @@ def main() -> None:
     if rank == 0:
         algo_bytes = ALGO_BYTES_PER_STEP * plan["n_envs"] * tpl
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None  # PMC-derived HBM bytes per launch come from the committed rocprofv3 passes, for this workload only
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tj) and args.envs == 65536 and tpl == 1 and args.kind == "ffa" and args.dist == "random":
+            traffic = json.load(open(tj))["hbm_bytes_per_launch"]
         line = {
             "metric": "env_steps_per_sec", "value": total_steps / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,7 +207,7 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "kernel": "pom_step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
