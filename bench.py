@@ -121,6 +121,8 @@ def main() -> None:
     ap.add_argument("--max-steps", type=int, default=800)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=0, help="sub-batches per step (0 = library default)")
+    ap.add_argument("--envs-per-wave", type=int, default=0)
     args = ap.parse_args()
 
     import torch
@@ -151,7 +153,8 @@ def main() -> None:
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     env = BatchEnvironment(plan["n_envs"], device=local_rank, mode=MODE_ENV, auto_reset=True, max_steps=args.max_steps,
-                           env_offset=plan["first_env"], stream=stream.cuda_stream)
+                           env_offset=plan["first_env"], stream=stream.cuda_stream, streams=args.streams,
+                           envs_per_wave=args.envs_per_wave)
     env.make_game(start)
     counters = torch.zeros(4, dtype=torch.int64, device=device)
 
@@ -173,14 +176,23 @@ def main() -> None:
     ev0.record(stream)
     for _ in range(args.steps):
         env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)
+    env.flush()  # steps run as sub-batches on internal streams: order them before the event on this stream
     ev1.record(stream)
     env.counters_into(counters.data_ptr())
     reduce_counters(counters, dist)  # the one collective: step / episode totals over all ranks
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = reduce_max(elapsed, device, dist)
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # mean launch-to-launch time of pom_step_kernel on its stream
-    kernel_ms = reduce_max(kernel_ms, device, dist)
+    step_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream: mean time of one step (all its launches)
+    step_ms = reduce_max(step_ms, device, dist)
+    # a step is issued as `parts` launches of pom_step_kernel over contiguous sub-batches on parallel streams; time the
+    # individual launches too (HIP events on their own streams), outside the timed region
+    epw, parts = env.launch_shape()
+    env.profile(True)
+    for _ in range(max(1, 256 // parts)):
+        env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)
+    launch_ms, n_launch = env.profile_read()
+    env.profile(False)
 
     total_steps = int(counters[CNT_STEPS].item())
     expect = plan["global_envs"] * args.steps * tpl
@@ -189,7 +201,7 @@ def main() -> None:
 
     if rank == 0:
         algo_bytes = ALGO_BYTES_PER_STEP * plan["n_envs"] * tpl
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        achieved = algo_bytes / (step_ms * 1e-3) / 1e9
         traffic = None  # PMC-derived HBM bytes per launch come from the committed rocprofv3 passes, for this workload only
         tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tj) and args.envs == 65536 and tpl == 1 and args.kind == "ffa" and args.dist == "random":
@@ -203,12 +215,17 @@ def main() -> None:
                 "workload": f"{args.envs} concurrent 11x11 FFA envs per GPU, {args.kind} boards, uniform-{args.dist} Move[4] "
                             f"(RandomAgent distribution), auto-reset, {args.max_steps}-tick cap",
                 "envs_per_gpu": args.envs, "global_envs": plan["global_envs"], "ticks_per_launch": tpl,
+                "envs_per_wave": epw, "launches_per_step": parts,
                 "parallelism": f"env-shard x{world}", "episodes_finished": int(counters[1].item()),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": "pom_step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel": f"pom_step_kernel<{epw}>", "step_ms": step_ms, "algorithmic_bytes_per_step": algo_bytes,
+                # one step = `launches_per_step` concurrent launches; per launch: bytes / mean duration (matches rocprofv3's AverageNs)
+                "launches_per_step": parts,
+                "launch": {"algorithmic_bytes": algo_bytes // parts, "ms": launch_ms, "timed_launches": n_launch,
+                           "achieved": (algo_bytes / parts) / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else None},
             },
         }
         if world == 1 and not args.no_cpu_baseline:

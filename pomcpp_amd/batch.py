@@ -39,7 +39,7 @@ class _Options(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p),
         ("mode", C.c_int32), ("auto_reset", C.c_int32), ("max_steps", C.c_int32),
-        ("env_offset", C.c_int64), ("envs_per_wave", C.c_int32), ("reserved_", C.c_int32),
+        ("env_offset", C.c_int64), ("envs_per_wave", C.c_int32), ("streams", C.c_int32),
     ]
 
 
@@ -80,6 +80,10 @@ def load_library() -> C.CDLL:
     lib.pom_batch_counters_device.argtypes = [P, VP]
     lib.pom_batch_reset_counters.argtypes = [P]
     lib.pom_batch_sync.argtypes = [P]
+    lib.pom_batch_flush.argtypes = [P]
+    lib.pom_batch_profile.argtypes = [P, C.c_int]
+    lib.pom_batch_profile_read.argtypes = [P, C.POINTER(C.c_double), C.POINTER(I64)]
+    lib.pom_batch_launch_shape.argtypes = [P, C.POINTER(I32), C.POINTER(I32)]
     lib.pom_batch_device_view.argtypes = [P, C.POINTER(VP), C.POINTER(I64), C.POINTER(I32)]
     lib.pom_step.argtypes = [VP, VP]
     _lib = lib
@@ -104,11 +108,12 @@ def step_one(state: np.ndarray, moves) -> None:
 
 class BatchEnvironment:
     def __init__(self, n_envs: int, device: int = 0, mode: int = MODE_ENV, auto_reset: bool = False,
-                 max_steps: int = 0, env_offset: int = 0, stream: Optional[int] = None, envs_per_wave: int = 0):
+                 max_steps: int = 0, env_offset: int = 0, stream: Optional[int] = None, envs_per_wave: int = 0,
+                 streams: int = 0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.n = int(n_envs)
-        o = _Options(C.sizeof(_Options), device, stream, mode, int(auto_reset), max_steps, env_offset, envs_per_wave, 0)
+        o = _Options(C.sizeof(_Options), device, stream, mode, int(auto_reset), max_steps, env_offset, envs_per_wave, streams)
         _check(self._lib, self._lib.pom_batch_create(C.byref(self._h), self.n, C.byref(o)))
 
     def close(self) -> None:
@@ -197,6 +202,23 @@ class BatchEnvironment:
 
     def sync(self) -> None:
         _check(self._lib, self._lib.pom_batch_sync(self._h))
+
+    def flush(self) -> None:
+        """Make the handle's stream wait for all steps issued so far (host does not block)."""
+        _check(self._lib, self._lib.pom_batch_flush(self._h))
+
+    def profile(self, enable: bool) -> None:
+        _check(self._lib, self._lib.pom_batch_profile(self._h, int(enable)))
+
+    def profile_read(self):
+        ms, n = C.c_double(), C.c_int64()
+        _check(self._lib, self._lib.pom_batch_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def launch_shape(self):
+        epw, parts = C.c_int32(), C.c_int32()
+        _check(self._lib, self._lib.pom_batch_launch_shape(self._h, C.byref(epw), C.byref(parts)))
+        return epw.value, parts.value
 
     def device_view(self):
         base, n_pad, rec = C.c_void_p(), C.c_int64(), C.c_int32()

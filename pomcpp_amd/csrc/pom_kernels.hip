@@ -66,6 +66,7 @@ struct StepParams {
     uint64_t seed;
     uint32_t tick0;
     int32_t dist, ticks, mode, auto_reset, max_steps;
+    int64_t block0; /* this launch covers tiles block0 .. block0 + gridDim.x - 1 (sub-batch of a split step) */
 #if defined(POM_DIAG)
     long long* diag; /* POM_PH_N accumulators per wavefront, diagnostic build only */
 #endif
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(64, (EPW == 16 ? 4 : 2)) void pom_step_kernel(StepP
     __shared__ uint32_t tile[LDS_ROWS * EPW];
     const int lane = threadIdx.x;
     const int el = lane % EPW, sub = lane / EPW; /* env within the wavefront; which of the 64/EPW row groups this lane moves */
-    const int64_t e = (int64_t)blockIdx.x * EPW + el;
+    const int64_t tile_id = p.block0 + blockIdx.x;
+    const int64_t e = tile_id * EPW + el;
     const int64_t np = p.n_pad;
     const bool owner = sub == 0;             /* the lane that runs env e's tick */
     const bool valid = owner && e < p.n;
@@ -233,10 +235,10 @@ __global__ __launch_bounds__(64, (EPW == 16 ? 4 : 2)) void pom_step_kernel(StepP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     POM_STAMP(L, POM_PH_STORE);
     if (lane == 0 && p.diag) /* one slot per wavefront: no contended atomics that would distort the timing */
-        for (int k = 0; k < POM_PH_N; k++) p.diag[(int64_t)blockIdx.x * POM_PH_N + k] += L.t_acc[k];
+        for (int k = 0; k < POM_PH_N; k++) p.diag[tile_id * POM_PH_N + k] += L.t_acc[k];
 #endif
     if (lane == 0) { /* each wavefront owns its slot: no atomics on the tick path */
-        int64_t* wc = p.wave_counters + (int64_t)blockIdx.x * POM_CNT_N;
+        int64_t* wc = p.wave_counters + tile_id * POM_CNT_N;
         wc[POM_CNT_STEPS] += c_steps;
         wc[POM_CNT_EPISODES] += c_episodes;
         wc[POM_CNT_RESETS] += c_resets;
@@ -353,10 +355,26 @@ struct PomBatch {
     int64_t* totals_dev = nullptr;
     int* first_bad = nullptr;
     uint64_t tick = 0;
+    /* A step is issued as `parts` kernels over contiguous tile ranges on internal streams: the launches are
+     * independent (envs never interact), so one part's HBM load / store phases overlap the others' compute
+     * instead of all wavefronts of the chip loading and storing in lock-step.  The caller's stream is forked
+     * into the sub-streams lazily and joined again before anything else touches the batch. */
+    enum { MAX_PARTS = 8, PROF_RING = 256 };
+    int parts = 1;
+    hipStream_t sub[MAX_PARTS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS] = {};
+    bool forked = false;
+    /* optional per-launch timing (pom_batch_profile) */
+    bool profiling = false;
+    hipEvent_t prof_ev[2 * PROF_RING] = {};
+    int prof_n = 0;
 #if defined(POM_DIAG)
     long long* diag = nullptr;
 #endif
 };
+
+static int fork_parts(PomBatch* h);
+static int join_parts(PomBatch* h);
 
 extern "C" {
 
@@ -373,7 +391,16 @@ int pom_batch_destroy(PomBatch* h)
 {
     if (!h) return POM_E_ARG;
     (void)hipSetDevice(h->device);
+    for (int k = 0; k < PomBatch::MAX_PARTS; k++)
+        if (h->sub[k]) (void)hipStreamSynchronize(h->sub[k]);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int k = 0; k < PomBatch::MAX_PARTS; k++) {
+        if (h->sub[k]) (void)hipStreamDestroy(h->sub[k]);
+        if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int k = 0; k < 2 * PomBatch::PROF_RING; k++)
+        if (h->prof_ev[k]) (void)hipEventDestroy(h->prof_ev[k]);
     (void)hipFree(h->state);
     (void)hipFree(h->snap);
     (void)hipFree(h->moves_dev);
@@ -434,6 +461,23 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
         const int v = atoi(ev);
         if (v == 16 || v == 32 || v == 64) h->epw = v;
     }
+    /* sub-batches per step.  Measured on MI355X (scripts/streams_test.py, profiles/r01_streams.txt): 2 parts give
+     * 40.8 -> 36.4 us at 64k envs and 120 -> 93 us at 262k, 4 parts only 35.1 — but ROCm multiplexes all streams of
+     * the process onto 4 hardware queues, kernels that share a queue serialize, and each part has a ~30 us latency
+     * floor, so more sub-streams than free queues (e.g. next to torch's own streams) DOUBLES the step time.
+     * Two parts stay inside that budget. */
+    h->parts = h->n_pad >= 8192 ? 2 : 1;
+    if (o.streams >= 1 && o.streams <= PomBatch::MAX_PARTS) h->parts = o.streams;
+    else if (o.streams != 0) {
+        snprintf(g_err, sizeof g_err, "pom_batch_create: streams must be 0..%d", (int)PomBatch::MAX_PARTS);
+        delete h;
+        return POM_E_ARG;
+    }
+    if (const char* ev = getenv("POM_STREAMS")) {
+        const int v = atoi(ev);
+        if (v >= 1 && v <= PomBatch::MAX_PARTS) h->parts = v;
+    }
+    if ((int64_t)h->parts > h->n_pad / h->epw) h->parts = (int)(h->n_pad / h->epw);
     h->mode = o.mode;
     h->auto_reset = o.auto_reset;
     h->max_steps = o.max_steps;
@@ -458,6 +502,18 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
             return POM_E_HIP;
         }
         h->own_stream = true;
+    }
+    if (h->parts > 1) {
+        hipError_t e_ = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+        for (int k = 0; k < h->parts && e_ == hipSuccess; k++) {
+            e_ = hipStreamCreateWithFlags(&h->sub[k], hipStreamNonBlocking);
+            if (e_ == hipSuccess) e_ = hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming);
+        }
+        if (e_ != hipSuccess) {
+            set_err("sub-stream setup", e_);
+            pom_batch_destroy(h);
+            return POM_E_HIP;
+        }
     }
     const size_t rec_bytes = (size_t)POM_REC_DWORDS * 4 * (size_t)h->n_pad;
     ALLOC(h->state, rec_bytes);
@@ -499,6 +555,7 @@ int pom_batch_upload(PomBatch* h, const void* states, int64_t first, int64_t cou
     int rc = check_range(h, first, count);
     if (rc || !states) return rc ? rc : POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
     const int big = INT_MAX;
     HIPCHK(hipMemcpyAsync(h->first_bad, &big, sizeof big, hipMemcpyHostToDevice, h->stream));
     int64_t bad_env = -1;
@@ -530,6 +587,7 @@ int pom_batch_download(PomBatch* h, void* states, int64_t first, int64_t count)
     int rc = check_range(h, first, count);
     if (rc || !states) return rc ? rc : POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
     for (int64_t off = 0; off < count; off += h->staging_envs) {
         const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
         HIPCHK(hipMemsetAsync(h->staging, 0, (size_t)c * POM_STATE_BYTES, h->stream));
@@ -546,8 +604,30 @@ int pom_batch_snapshot(PomBatch* h)
 {
     if (!h) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
     pom_snapshot_kernel<<<dim3((unsigned)((h->n_pad + 255) / 256)), dim3(256), 0, h->stream>>>(h->state, h->snap, h->n_pad);
     HIPCHK(hipGetLastError());
+    return POM_OK;
+}
+
+/* caller's stream -> sub-streams: everything already queued on the caller's stream happens before the parts */
+static int fork_parts(PomBatch* h)
+{
+    if (h->parts == 1 || h->forked) return POM_OK;
+    HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+    for (int k = 0; k < h->parts; k++) HIPCHK(hipStreamWaitEvent(h->sub[k], h->ev_fork, 0));
+    h->forked = true;
+    return POM_OK;
+}
+/* sub-streams -> caller's stream: whatever is queued on the caller's stream next sees all parts finished */
+static int join_parts(PomBatch* h)
+{
+    if (h->parts == 1 || !h->forked) return POM_OK;
+    for (int k = 0; k < h->parts; k++) {
+        HIPCHK(hipEventRecord(h->ev_join[k], h->sub[k]));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join[k], 0));
+    }
+    h->forked = false;
     return POM_OK;
 }
 
@@ -575,11 +655,26 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
     }
     p.diag = h->diag;
 #endif
-    const dim3 grid((unsigned)(h->n_pad / h->epw));
-    if (h->epw == 64) pom_step_kernel<64><<<grid, dim3(64), 0, h->stream>>>(p);
-    else if (h->epw == 32) pom_step_kernel<32><<<grid, dim3(64), 0, h->stream>>>(p);
-    else pom_step_kernel<16><<<grid, dim3(64), 0, h->stream>>>(p);
-    HIPCHK(hipGetLastError());
+    const int64_t tiles = h->n_pad / h->epw;
+    int rc = fork_parts(h);
+    if (rc) return rc;
+    for (int k = 0; k < h->parts; k++) {
+        const int64_t b0 = tiles * k / h->parts, b1 = tiles * (k + 1) / h->parts;
+        if (b1 <= b0) continue;
+        hipStream_t st = h->parts == 1 ? h->stream : h->sub[k];
+        p.block0 = b0;
+        const dim3 grid((unsigned)(b1 - b0));
+        const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
+        if (prof) HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_n], st));
+        if (h->epw == 64) pom_step_kernel<64><<<grid, dim3(64), 0, st>>>(p);
+        else if (h->epw == 32) pom_step_kernel<32><<<grid, dim3(64), 0, st>>>(p);
+        else pom_step_kernel<16><<<grid, dim3(64), 0, st>>>(p);
+        HIPCHK(hipGetLastError());
+        if (prof) {
+            HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_n + 1], st));
+            h->prof_n++;
+        }
+    }
     return POM_OK;
 }
 
@@ -587,13 +682,19 @@ int pom_batch_step_device(PomBatch* h, const int32_t* moves_dev)
 {
     if (!h || !moves_dev) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    return launch_step(h, moves_dev, 0, 0, 1);
+    /* the moves were produced on the caller's stream and may be overwritten there right after this call */
+    int rc = join_parts(h);
+    if (!rc) rc = launch_step(h, moves_dev, 0, 0, 1);
+    if (!rc) rc = join_parts(h);
+    return rc;
 }
 
 int pom_batch_step(PomBatch* h, const int32_t* moves_host)
 {
     if (!h || !moves_host) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    int rc = join_parts(h); /* the previous step's parts still read moves_dev */
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(h->moves_dev, moves_host, (size_t)h->n * 16, hipMemcpyHostToDevice, h->stream));
     return launch_step(h, h->moves_dev, 0, 0, 1);
 }
@@ -625,6 +726,7 @@ int pom_batch_status(PomBatch* h, int64_t first, int64_t count, int32_t* done, i
     int rc = check_range(h, first, count);
     if (rc) return rc;
     HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
     void* outs[6] = {done, winner, draw, alive, time_step, ubflags};
     /* the AoS staging buffer doubles as scratch: 6 ints per env << 251 */
     for (int64_t off = 0; off < count; off += h->staging_envs) {
@@ -643,6 +745,7 @@ int pom_batch_counters_device(PomBatch* h, void* dev_int64x4)
 {
     if (!h || !dev_int64x4) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
     pom_reduce_counters_kernel<<<dim3(1), dim3(256), 0, h->stream>>>(h->wave_counters, h->n_waves, (int64_t*)dev_int64x4);
     HIPCHK(hipGetLastError());
     return POM_OK;
@@ -662,6 +765,7 @@ int pom_batch_reset_counters(PomBatch* h)
 {
     if (!h) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
     HIPCHK(hipMemsetAsync(h->wave_counters, 0, (size_t)h->n_waves * POM_CNT_N * 8, h->stream));
     return POM_OK;
 }
@@ -670,6 +774,7 @@ int pom_batch_sync(PomBatch* h)
 {
     if (!h) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
     HIPCHK(hipStreamSynchronize(h->stream));
     return POM_OK;
 }
@@ -704,6 +809,50 @@ int pom_diag_read(PomBatch* h, long long out[POM_PH_N])
     return POM_OK;
 }
 #endif
+
+int pom_batch_flush(PomBatch* h)
+{
+    if (!h) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    return join_parts(h);
+}
+
+int pom_batch_profile(PomBatch* h, int enable)
+{
+    if (!h) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    if (enable && !h->prof_ev[0])
+        for (int k = 0; k < 2 * PomBatch::PROF_RING; k++) HIPCHK(hipEventCreate(&h->prof_ev[k]));
+    h->profiling = enable != 0;
+    h->prof_n = 0;
+    return POM_OK;
+}
+
+int pom_batch_profile_read(PomBatch* h, double* mean_ms, int64_t* launches)
+{
+    if (!h) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double sum = 0;
+    for (int k = 0; k < h->prof_n; k++) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, h->prof_ev[2 * k], h->prof_ev[2 * k + 1]));
+        sum += ms;
+    }
+    if (mean_ms) *mean_ms = h->prof_n ? sum / h->prof_n : 0.0;
+    if (launches) *launches = h->prof_n;
+    h->prof_n = 0;
+    return POM_OK;
+}
+
+int pom_batch_launch_shape(PomBatch* h, int32_t* envs_per_wave, int32_t* launches_per_step)
+{
+    if (!h) return POM_E_ARG;
+    if (envs_per_wave) *envs_per_wave = h->epw;
+    if (launches_per_step) *launches_per_step = h->parts;
+    return POM_OK;
+}
 
 int pom_step(void* state_1004, const int32_t moves[4])
 {

@@ -184,84 +184,93 @@ struct PomStepper {
     }
 
     /* ------------------------------------------------------------------ *
-     * Explosions.  A frame is one SpawnFlame activation (bboard.cpp:198-263):
-     *   x:4 | y:4 | s:4 (ray length, clamped to 11) | dir:3 | i:4 | resume:1 | rem:6
-     * rem = queue offset handed to ExplodeBombAt (bboard.cpp:111-118) whose
-     * bookkeeping runs when the frame finishes, POM_REM_TOP for the queue top
-     * (ExplodeTopBomb + PopBomb, bboard.cpp:93-97,191-196).
+     * Explosions (bboard.cpp:24-57, 111-118, 191-263) without recursion.
+     * One SpawnFlame activation = one frame: origin x,y, ray length s (clamped to 11: cells further out
+     * are off the board), ray dir 0..3 (+x,-x,+y,-y), step i, and `rem`: the queue offset whose
+     * ExplodeBombAt bookkeeping runs when the frame finishes (REM_TOP: ExplodeTopBomb + PopBomb,
+     * bboard.cpp:93-97,191-196).  The ACTIVE frame lives in registers; only the suspended parents of a
+     * chain sit in the store's frame rows, packed x:4|y:4|s:4|dir:3|i:4|rem:6.  One loop iteration = one
+     * ray cell: one cell read, at most one cell write.
      * ------------------------------------------------------------------ */
-    enum { POM_REM_TOP = 62, POM_REM_NONE = 63 };
+    enum { REM_TOP = 62, REM_NONE = 63 };
 
-    POM_HD static int fr_make(int x, int y, int s, int dir, int i, int resume, int rem)
+    POM_HD int owner_strength(int b) /* agents[BMB_ID(b)].bombStrength: the owner's CURRENT strength, SURVEY Q3 */
     {
-        return x | (y << 4) | (s << 8) | (dir << 12) | (i << 15) | (resume << 19) | (rem << 20);
+        const int owner = pb_id(b);
+        if (owner < POM_AGENT_COUNT) return (sel4(owner, L.a1) >> 16) & 0xFFFF;
+        L.ub |= POM_UB_BAD_INDEX;
+        return 0;
     }
 
-    /* SpawnFlame prologue (bboard.cpp:200-218) + push */
-    POM_HD int begin_flame(int sp, int x, int y, int strength, int rem)
+    /* SpawnFlame prologue, bboard.cpp:200-218 */
+    POM_HD void flame_prologue(int x, int y, int strength)
     {
-        if (sp >= POM_STACK_DEPTH) { /* cannot happen with <= 20 queued bombs; never overrun the frame rows */
-            L.ub |= POM_UB_BAD_INDEX;
-            return sp;
-        }
-        a.set_flame((L.fIdx + L.fCnt) % POM_Q, x | (y << 8) | (POM_FLAME_LIFETIME << 16) | ((strength & 0xFF) << 24));
+        int slot = L.fIdx + L.fCnt; /* NextPos(): (index + count) % 20, count may exceed 20 (see tick_flames) */
+        slot = slot >= 2 * POM_Q ? slot % POM_Q : wrap20(slot);
+        a.set_flame(slot, x | (y << 8) | (POM_FLAME_LIFETIME << 16) | ((strength & 0xFF) << 24));
         L.fCnt++;
         const int c = y * POM_N + x;
         const int e = a.cell(c);
         if (pc_is_agent(e)) kill(e & 0x3FFF);
         a.set_cell(c, POM_C_FLAME | (c << 3));
-        const int s = strength < 0 ? 0 : strength > POM_N ? POM_N : strength;
-        a.set_frame(sp, fr_make(x, y, s, 0, 1, 0, rem));
-        return sp + 1;
     }
 
-    POM_HD void run_explosions(int sp)
+    POM_HD void explode(int x, int y, int strength, int rem)
     {
-        while (sp > 0) {
-            const int fr = a.frame(sp - 1);
-            const int x = fr & 0xF, y = (fr >> 4) & 0xF, s = (fr >> 8) & 0xF;
-            int dir = (fr >> 12) & 7, i = (fr >> 15) & 0xF;
-            const int resume = (fr >> 19) & 1, rem = (fr >> 20) & 63;
-            if (dir >= 4) { /* all four rays done: the caller's bookkeeping */
-                if (rem == POM_REM_TOP) {
+        flame_prologue(x, y, strength);
+        int s = strength < 0 ? 0 : strength > POM_N ? POM_N : strength;
+        int dir = 0, i = 1, sp = 0, resume = 0;
+        for (;;) {
+            if (!resume) { /* skip exhausted rays: length s or the board edge, whichever is nearer */
+                for (; dir < 4; dir++, i = 1) {
+                    const int room = dir == 0 ? POM_N - 1 - x : dir == 1 ? x : dir == 2 ? POM_N - 1 - y : y;
+                    if (i <= (room < s ? room : s)) break;
+                }
+            }
+            if (dir >= 4) { /* all four rays done: the caller's bookkeeping, then back into the parent */
+                if (rem == REM_TOP) {
                     owner_bombcount_dec(bomb_at(0));
                     L.bIdx = wrap20(L.bIdx + 1);
                     L.bCnt--;
-                } else if (rem != POM_REM_NONE) {
-                    /* slot re-read after the nested chain: stale index, SURVEY Q2 */
+                } else if (rem != REM_NONE) {
+                    /* the slot is re-read after the nested chain: stale index, SURVEY Q2 */
                     owner_bombcount_dec(bomb_at(rem));
                     remove_at(rem);
                 }
+                if (sp == 0) return;
                 sp--;
-                continue;
+                const int fr = a.frame(sp);
+                x = fr & 0xF; y = (fr >> 4) & 0xF; s = (fr >> 8) & 0xF;
+                dir = (fr >> 12) & 7; i = (fr >> 15) & 0xF; rem = (fr >> 19) & 63;
+                resume = 1; /* continue inside SpawnFlameItem, after its ExplodeBombAt */
             }
-            /* ray order +x, -x, +y, -y (bboard.cpp:220-262) */
             const int cx = x + (dir == 0 ? i : dir == 1 ? -i : 0);
             const int cy = y + (dir == 2 ? i : dir == 3 ? -i : 0);
-            if (i > s || oob(cx, cy)) {
-                a.set_frame(sp - 1, fr_make(x, y, s, dir + 1, 1, 0, rem));
-                continue;
-            }
             const int c = cy * POM_N + cx;
+            const int e = a.cell(c); /* on resume: re-read, the nested chain may have changed the cell */
             if (!resume) { /* SpawnFlameItem head, bboard.cpp:26-40 */
-                const int e = a.cell(c);
                 if (pc_is_agent(e)) kill(e & 0x3FFF);
                 if (e == POM_C_BOMB || pc_is_agent(e)) {
                     const int j = bomb_index(cx | (cy << 4));
                     if (j >= 0) {
-                        a.set_frame(sp - 1, fr_make(x, y, s, dir, i, 1, rem));
-                        /* ExplodeBombAt: the owner's CURRENT strength */
-                        const int owner = pb_id(bomb_at(j));
-                        int strength = 0;
-                        if (owner < POM_AGENT_COUNT) strength = (sel4(owner, L.a1) >> 16) & 0xFFFF;
-                        else L.ub |= POM_UB_BAD_INDEX;
-                        sp = begin_flame(sp, cx, cy, strength, j);
-                        continue;
+                        if (sp >= POM_STACK_DEPTH) { /* cannot happen with <= 20 queued bombs */
+                            L.ub |= POM_UB_BAD_INDEX;
+                        } else {
+                            a.set_frame(sp, x | (y << 4) | (s << 8) | (dir << 12) | (i << 15) | (rem << 19));
+                            sp++;
+                            const int st2 = owner_strength(bomb_at(j));
+                            x = cx; y = cy; rem = j;
+                            flame_prologue(x, y, st2);
+                            s = st2 < 0 ? 0 : st2 > POM_N ? POM_N : st2;
+                            dir = 0;
+                            i = 1;
+                            continue;
+                        }
                     }
                 }
             }
-            /* SpawnFlameItem tail, bboard.cpp:42-56 (cell re-read after the nested chain) */
-            const int e = a.cell(c);
+            resume = 0;
+            /* SpawnFlameItem tail, bboard.cpp:42-56 */
             int go_on = 0;
             if (e != POM_C_RIGID) {
                 const int was_wood = pc_is_wood(e);
@@ -270,7 +279,6 @@ struct PomStepper {
             }
             if (go_on) i++;
             else { dir++; i = 1; }
-            a.set_frame(sp - 1, fr_make(x, y, s, dir, i, 0, rem));
         }
     }
 
@@ -460,6 +468,14 @@ struct PomStepper {
 #pragma unroll
         for (int i = 0; i < 4; i++) dstp |= (uint32_t)(((dx[i] + 1) & 0xF) | (((dy[i] + 1) & 0xF) << 4)) << (8 * i);
 
+        /* HasBomb(x, y) is only ever asked about the moving agent's own cell (step.cpp:89,127,152,172) and bombs
+         * do not move during the agent loop: one pass over the queue answers it for all four agents */
+        int on_bomb = 0;
+        for (int k = 0; k < L.bCnt; k++) {
+            const int bp = pb_pos(bomb_at(k));
+#pragma unroll
+            for (int j = 0; j < 4; j++) on_bomb |= (bp == (px[j] | (py[j] << 4))) << j;
+        }
         POM_STAMP(L, POM_PH_AGENT_PREP);
         /* agent loop, step.cpp:35-185 */
         {
@@ -499,6 +515,8 @@ struct PomStepper {
                             a.set_bomb(slot, b);
                             put4(i, L.a0, ag_bombcount_add(av, 1));
                             L.bCnt++;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) on_bomb |= ((L.a0[j] & 0xFFFF) == (av & 0xFFFF)) << j;
                         }
                     }
                     i = next;
@@ -519,7 +537,7 @@ struct PomStepper {
                     deadmask |= 1 << i;
                     const int oc = y * POM_N + x;
                     if (a.cell(oc) == (POM_C_AGENT | i))
-                        a.set_cell(oc, bomb_index(x | (y << 4)) >= 0 ? POM_C_BOMB : POM_C_PASSAGE);
+                        a.set_cell(oc, ((on_bomb >> i) & 1) ? POM_C_BOMB : POM_C_PASSAGE);
                     i = next;
                     continue;
                 }
@@ -546,11 +564,11 @@ struct PomStepper {
                 const int oc = y * POM_N + x;
                 if (item == POM_C_PASSAGE || (ouroboros && pc_is_agent(item))) { /* step.cpp:120-140 */
                     if (a.cell(oc) == (POM_C_AGENT | i))
-                        a.set_cell(oc, bomb_index(x | (y << 4)) >= 0 ? POM_C_BOMB : POM_C_PASSAGE);
+                        a.set_cell(oc, ((on_bomb >> i) & 1) ? POM_C_BOMB : POM_C_PASSAGE);
                     a.set_cell(dc, POM_C_AGENT | i);
                     put4(i, L.a0, ag_setpos(sel4(i, L.a0), ddx, ddy));
                 } else if (item == POM_C_BOMB) { /* step.cpp:147-184: kicker and non-kicker both step on */
-                    a.set_cell(oc, bomb_index(x | (y << 4)) >= 0 ? POM_C_BOMB : POM_C_PASSAGE);
+                    a.set_cell(oc, ((on_bomb >> i) & 1) ? POM_C_BOMB : POM_C_PASSAGE);
                     a.set_cell(dc, POM_C_AGENT | i);
                     const int cur = sel4(i, L.a0);
                     put4(i, L.a0, ag_setpos(cur, ddx, ddy));
@@ -566,11 +584,25 @@ struct PomStepper {
 
         POM_STAMP(L, POM_PH_AGENT_LOOP);
         if (L.bCnt > 0) {
-            /* ResetBombFlags + FillBombDestPos, step_utility.cpp:331-337,146-152 */
+            /* ResetBombFlags + FillBombDestPos, step_utility.cpp:331-337,146-152.  The same pass notes whether any
+             * bomb of this env is moving and whether two bombs share a cell (121-bit occupancy in 4 registers):
+             * if neither, loop B below cannot see a collision and collapses to one cell test per bomb. */
+            int moving = 0, shared = 0;
+            uint32_t occ[4] = {0, 0, 0, 0};
             for (int k = 0; k < L.bCnt; k++) {
                 const int b = pb_set(bomb_at(k), 0xF000000u, 0);
                 set_bomb_at(k, b);
                 a.set_bdest(k, bomb_target_key(b));
+                moving |= pb_dir(b) != 0;
+                const int idx = pb_y(b) * POM_N + pb_x(b);
+                const int w = idx >> 5;
+                const uint32_t m = 1u << (idx & 31);
+                const uint32_t cur = w == 0 ? occ[0] : w == 1 ? occ[1] : w == 2 ? occ[2] : occ[3];
+                shared |= (cur & m) != 0;
+                occ[0] |= w == 0 ? m : 0u;
+                occ[1] |= w == 1 ? m : 0u;
+                occ[2] |= w == 2 ? m : 0u;
+                occ[3] |= w >= 3 ? m : 0u;
             }
             /* bomb loop A, step.cpp:195-227 */
             for (int k = 0; k < L.bCnt; k++) {
@@ -598,6 +630,17 @@ struct PomStepper {
             }
             POM_STAMP(L, POM_PH_BOMB_A);
             /* bomb loop B, step.cpp:230-278 */
+            if (!moving && !shared) {
+                /* every bomb rests on a cell of its own: HasBombCollision is false for all of them, each "moves"
+                 * onto its own cell (step.cpp:243-272): a walkable cell there becomes BOMB, a flame detonates it */
+                for (int k = 0; k < L.bCnt; k++) {
+                    const int b = bomb_at(k);
+                    const int c = pb_y(b) * POM_N + pb_x(b);
+                    const int e = a.cell(c);
+                    if (pc_is_walkable(e)) a.set_cell(c, POM_C_BOMB);
+                    else if (pc_is_flame(e)) explode(pb_x(b), pb_y(b), owner_strength(b), k);
+                }
+            } else
             for (int k = 0; k < L.bCnt; k++) {
                 int b = bomb_at(k);
                 if (pb_dir(b) == 0) {
@@ -625,11 +668,7 @@ struct PomStepper {
                         /* ExplodeBombAt(GetBombIndex(target)), bboard.cpp:111-118 */
                         const int j = bomb_index(tx | (ty << 4));
                         const int jb = bomb_at(j);
-                        const int owner = pb_id(jb);
-                        int strength = 0;
-                        if (owner < POM_AGENT_COUNT) strength = (sel4(owner, L.a1) >> 16) & 0xFFFF;
-                        else L.ub |= POM_UB_BAD_INDEX;
-                        run_explosions(begin_flame(0, pb_x(jb), pb_y(jb), strength, j));
+                        explode(pb_x(jb), pb_y(jb), owner_strength(jb), j);
                     }
                 } else {
                     set_bomb_at(k, pb_set(b, 0xF00000u, 0));
@@ -643,7 +682,7 @@ struct PomStepper {
             for (int k = 0; k < n && L.bCnt > 0; k++) {
                 const int c = bomb_at(0);
                 if (pb_time(c) != 0) break;
-                run_explosions(begin_flame(0, pb_x(c), pb_y(c), pb_strength(c), POM_REM_TOP));
+                explode(pb_x(c), pb_y(c), pb_strength(c), REM_TOP);
             }
         }
         POM_STAMP(L, POM_PH_TICK_BOMBS);

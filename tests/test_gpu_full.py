@@ -200,3 +200,40 @@ def test_every_envs_per_wave_variant_matches_oracle(hip_lib, oracle, epw, kind, 
         assert _digest(env.get_state()) == _digest(ref)
     with pytest.raises(PomError):
         BatchEnvironment(64, envs_per_wave=48)
+
+
+@pytest.mark.parametrize("streams", [1, 2, 3, 8])
+def test_split_steps_over_streams_give_identical_results(hip_lib, oracle, streams):
+    """A step may be issued as several launches on internal streams; states, status and counters must not depend on it,
+    with the synthetic stream, with host moves, and when uploads / downloads are interleaved with steps."""
+    n, ticks, seed = 5000, 60, 808
+    start = pa.make_boards(n, seed=5)
+    want = start.copy()
+    oracle.run_random(want, start, ticks, seed, 0, 0, DIST_RANDOM, 800)
+    with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800, streams=streams) as env:
+        assert env.launch_shape()[1] == streams
+        env.make_game(start)
+        env.step_random(seed, DIST_RANDOM, ticks=ticks // 2)
+        mid = env.get_state()          # joins the sub-streams
+        env.make_game(mid)             # re-upload: snapshot becomes `mid`, but nothing restarts in the next 30 ticks unless done
+        env.make_game(start)           # back to the original snapshot ...
+        env.set_tick(0)
+        env.step_random(seed, DIST_RANDOM, ticks=ticks)   # ... and replay the whole run
+        assert _digest(env.get_state()) == _digest(want)
+        assert env.counters()[CNT_STEPS] == n * (ticks + ticks // 2)
+    rng = np.random.default_rng(streams)
+    ref = start.copy()
+    with BatchEnvironment(n, mode=MODE_RAW, streams=streams) as env:
+        env.make_game(start)
+        for t in range(20):
+            mv = rng.integers(0, 6, size=(n, 4), dtype=np.int32)
+            env.step(mv)
+            mv[:] = 0                  # the host buffer may be reused immediately
+            oracle.step_batch(ref, rng_moves := None) if False else None
+        # recompute the same moves for the oracle
+        rng = np.random.default_rng(streams)
+        for t in range(20):
+            oracle.step_batch(ref, rng.integers(0, 6, size=(n, 4), dtype=np.int32))
+        assert _digest(env.get_state()) == _digest(ref)
+    with pytest.raises(PomError):
+        BatchEnvironment(64, streams=9)
