@@ -123,6 +123,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=0, help="sub-batches per step (0 = library default)")
     ap.add_argument("--envs-per-wave", type=int, default=0)
+    ap.add_argument("--lanes-per-env", type=int, default=0)
     args = ap.parse_args()
 
     import torch
@@ -154,7 +155,7 @@ def main() -> None:
     assert stream.cuda_stream != 0
     env = BatchEnvironment(plan["n_envs"], device=local_rank, mode=MODE_ENV, auto_reset=True, max_steps=args.max_steps,
                            env_offset=plan["first_env"], stream=stream.cuda_stream, streams=args.streams,
-                           envs_per_wave=args.envs_per_wave)
+                           envs_per_wave=args.envs_per_wave, lanes_per_env=args.lanes_per_env)
     env.make_game(start)
     counters = torch.zeros(4, dtype=torch.int64, device=device)
 
@@ -187,7 +188,7 @@ def main() -> None:
     step_ms = reduce_max(step_ms, device, dist)
     # a step is issued as `parts` launches of pom_step_kernel over contiguous sub-batches on parallel streams; time the
     # individual launches too (HIP events on their own streams), outside the timed region
-    epw, parts = env.launch_shape()
+    epw, lpe, parts = env.launch_shape()
     env.profile(True)
     for _ in range(max(1, 256 // parts)):
         env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)
@@ -215,13 +216,13 @@ def main() -> None:
                 "workload": f"{args.envs} concurrent 11x11 FFA envs per GPU, {args.kind} boards, uniform-{args.dist} Move[4] "
                             f"(RandomAgent distribution), auto-reset, {args.max_steps}-tick cap",
                 "envs_per_gpu": args.envs, "global_envs": plan["global_envs"], "ticks_per_launch": tpl,
-                "envs_per_wave": epw, "launches_per_step": parts,
+                "envs_per_wave": epw, "lanes_per_env": lpe, "launches_per_step": parts,
                 "parallelism": f"env-shard x{world}", "episodes_finished": int(counters[1].item()),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": f"pom_step_kernel<{epw}>", "step_ms": step_ms, "algorithmic_bytes_per_step": algo_bytes,
+                "kernel": f"pom_step_kernel<{epw}, {lpe}>", "step_ms": step_ms, "algorithmic_bytes_per_step": algo_bytes,
                 # one step = `launches_per_step` concurrent launches; per launch: bytes / mean duration (matches rocprofv3's AverageNs)
                 "launches_per_step": parts,
                 "launch": {"algorithmic_bytes": algo_bytes // parts, "ms": launch_ms, "timed_launches": n_launch,

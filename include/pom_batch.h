@@ -54,9 +54,12 @@ typedef struct PomBatchOptions {
     int32_t auto_reset;   /* ENV mode: a finished env is reloaded from its snapshot and stepped in the same tick */
     int32_t max_steps;    /* ENV mode: env is done once timeStep reaches this (0 = no limit); StartGame's bound, environment.cpp:71 */
     int64_t env_offset;   /* global index of env 0, keys the synthetic move stream when a job is sharded over GPUs */
-    int32_t envs_per_wave; /* 0 = choose by batch size; else 16, 32 or 64 envs per wavefront (results are identical) */
+    int32_t envs_per_wave; /* 0 = default (16); else 16, 32 or 64 envs per wavefront (results are identical) */
     int32_t streams;       /* 0 = choose by batch size; else 1..8 sub-batches per step, each on an internal stream, so that
                               one part's load/store overlaps the others' compute (results are identical) */
+    int32_t lanes_per_env; /* 0 = default (4: a quad of adjacent lanes runs each env's tick and splits its order-free parts,
+                              needs envs_per_wave 16); 1 = one lane per env */
+    int32_t reserved_;
 } PomBatchOptions;
 
 typedef struct PomBatch PomBatch;
@@ -103,8 +106,8 @@ int pom_batch_flush(PomBatch* h);
 /* per-launch timing with HIP events on the launch streams: enable, step (at most 256 launches are kept), read the mean */
 int pom_batch_profile(PomBatch* h, int enable);
 int pom_batch_profile_read(PomBatch* h, double* mean_ms, int64_t* launches);
-/* how a step is issued: envs per wavefront and kernel launches (sub-batches) per step */
-int pom_batch_launch_shape(PomBatch* h, int32_t* envs_per_wave, int32_t* launches_per_step);
+/* how a step is issued: envs per wavefront, lanes per env and kernel launches (sub-batches) per step */
+int pom_batch_launch_shape(PomBatch* h, int32_t* envs_per_wave, int32_t* lanes_per_env, int32_t* launches_per_step);
 
 /* zero-copy view for device-side consumers (policies, observation kernels): SoA records,
  * dword d of env e at base[d * n_pad + e]; layout in pomcpp_amd/csrc/pom_packed.h */

@@ -40,11 +40,12 @@ class _Options(C.Structure):
         ("struct_size", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p),
         ("mode", C.c_int32), ("auto_reset", C.c_int32), ("max_steps", C.c_int32),
         ("env_offset", C.c_int64), ("envs_per_wave", C.c_int32), ("streams", C.c_int32),
+        ("lanes_per_env", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libpom_batch.so")
+    return os.environ.get("POM_LIB") or os.path.join(_HERE, "libpom_batch.so")  # POM_LIB: experimental builds only
 
 
 _lib = None
@@ -83,7 +84,7 @@ def load_library() -> C.CDLL:
     lib.pom_batch_flush.argtypes = [P]
     lib.pom_batch_profile.argtypes = [P, C.c_int]
     lib.pom_batch_profile_read.argtypes = [P, C.POINTER(C.c_double), C.POINTER(I64)]
-    lib.pom_batch_launch_shape.argtypes = [P, C.POINTER(I32), C.POINTER(I32)]
+    lib.pom_batch_launch_shape.argtypes = [P, C.POINTER(I32), C.POINTER(I32), C.POINTER(I32)]
     lib.pom_batch_device_view.argtypes = [P, C.POINTER(VP), C.POINTER(I64), C.POINTER(I32)]
     lib.pom_step.argtypes = [VP, VP]
     _lib = lib
@@ -109,11 +110,12 @@ def step_one(state: np.ndarray, moves) -> None:
 class BatchEnvironment:
     def __init__(self, n_envs: int, device: int = 0, mode: int = MODE_ENV, auto_reset: bool = False,
                  max_steps: int = 0, env_offset: int = 0, stream: Optional[int] = None, envs_per_wave: int = 0,
-                 streams: int = 0):
+                 streams: int = 0, lanes_per_env: int = 0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.n = int(n_envs)
-        o = _Options(C.sizeof(_Options), device, stream, mode, int(auto_reset), max_steps, env_offset, envs_per_wave, streams)
+        o = _Options(C.sizeof(_Options), device, stream, mode, int(auto_reset), max_steps, env_offset, envs_per_wave, streams,
+                     lanes_per_env, 0)
         _check(self._lib, self._lib.pom_batch_create(C.byref(self._h), self.n, C.byref(o)))
 
     def close(self) -> None:
@@ -216,9 +218,10 @@ class BatchEnvironment:
         return ms.value, n.value
 
     def launch_shape(self):
-        epw, parts = C.c_int32(), C.c_int32()
-        _check(self._lib, self._lib.pom_batch_launch_shape(self._h, C.byref(epw), C.byref(parts)))
-        return epw.value, parts.value
+        """(envs per wavefront, lanes per env, launches per step)"""
+        epw, lpe, parts = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(self._lib, self._lib.pom_batch_launch_shape(self._h, C.byref(epw), C.byref(lpe), C.byref(parts)))
+        return epw.value, lpe.value, parts.value
 
     def device_view(self):
         base, n_pad, rec = C.c_void_p(), C.c_int64(), C.c_int32()

@@ -36,25 +36,64 @@ enum {
 
 
 /*
- * EPW = envs per wavefront (64, 32 or 16).  The tick is executed by ONE lane per env; with EPW < 64 the other
- * lanes of the wavefront only help moving the record (each DMA / store instruction then covers 64/EPW rows),
- * which trades idle lanes for more resident wavefronts per SIMD: the tick is bound by issue latency, not by
- * lane throughput, and a batch of a few thousand envs would otherwise leave most of the 1024 SIMDs empty.
- * The LDS tile is [row][EPW]; bank = (row*EPW + env) mod 32.
+ * EPW = envs per wavefront (64, 32 or 16), G = lanes that work on one env during the tick (pom_step_body.h):
+ *   G = 1  one lane per env runs the tick; with EPW < 64 the other lanes only help moving the record (each DMA /
+ *          store instruction then covers 64/EPW rows), trading idle lanes for more resident wavefronts per SIMD;
+ *   G = 4  (EPW = 16) the four ADJACENT lanes 4e..4e+3 run env e's tick in lock-step and split the order-free
+ *          parts; their cross-lane traffic is DPP quad permutes (one VALU op, no LDS).
+ * The LDS tile is [row][EPW]; bank = (row*EPW + env) mod 32; the G lanes of an env read the same address (broadcast).
  */
-template <int EPW>
+template <int EPW, int GG>
 struct LdsEnv {
+    static constexpr int G = GG;
     uint32_t* t; /* &tile[env_in_wave] */
+    int sub_;    /* lane's index within its env's group; 0 = owner */
+    __device__ int sub() const { return G == 1 ? 0 : sub_; }
+    __device__ bool owner() const { return G == 1 || sub_ == 0; }
+    /* quad reductions: lane ^ 1, then lane ^ 2 */
+    __device__ static int dpp_x1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false); }
+    __device__ static int dpp_x2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false); }
+    __device__ int gor(int v) const
+    {
+        if (G == 1) return v;
+        v |= dpp_x1(v);
+        return v | dpp_x2(v);
+    }
+    __device__ int gadd(int v) const
+    {
+        if (G == 1) return v;
+        v += dpp_x1(v);
+        return v + dpp_x2(v);
+    }
+    template <int J>
+    __device__ int gbcast(int v) const /* the value held by member J of the quad */
+    {
+        if (G == 1) return v;
+        return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xF, 0xF, false);
+    }
+    __device__ int gmin(int v) const
+    {
+        if (G == 1) return v;
+        const int a = dpp_x1(v);
+        v = a < v ? a : v;
+        const int b = dpp_x2(v);
+        return b < v ? b : v;
+    }
     __device__ int cell(int c) const { return reinterpret_cast<const uint16_t*>(t)[(c >> 1) * (2 * EPW) + (c & 1)]; }
-    __device__ void set_cell(int c, int v) { reinterpret_cast<uint16_t*>(t)[(c >> 1) * (2 * EPW) + (c & 1)] = (uint16_t)v; }
+    __device__ void put_cell(int c, int v) { reinterpret_cast<uint16_t*>(t)[(c >> 1) * (2 * EPW) + (c & 1)] = (uint16_t)v; }
     __device__ int bomb(int s) const { return (int)t[(ROW_BOMBS + s) * EPW]; }
-    __device__ void set_bomb(int s, int v) { t[(ROW_BOMBS + s) * EPW] = (uint32_t)v; }
+    __device__ void put_bomb(int s, int v) { t[(ROW_BOMBS + s) * EPW] = (uint32_t)v; }
     __device__ int flame(int s) const { return (int)t[(ROW_FLAMES + s) * EPW]; }
-    __device__ void set_flame(int s, int v) { t[(ROW_FLAMES + s) * EPW] = (uint32_t)v; }
+    __device__ void put_flame(int s, int v) { t[(ROW_FLAMES + s) * EPW] = (uint32_t)v; }
     __device__ int bdest(int i) const { return reinterpret_cast<const uint8_t*>(t + ROW_BDEST * EPW)[(i >> 2) * (4 * EPW) + (i & 3)]; }
-    __device__ void set_bdest(int i, int v) { reinterpret_cast<uint8_t*>(t + ROW_BDEST * EPW)[(i >> 2) * (4 * EPW) + (i & 3)] = (uint8_t)v; }
+    __device__ void put_bdest(int i, int v) { reinterpret_cast<uint8_t*>(t + ROW_BDEST * EPW)[(i >> 2) * (4 * EPW) + (i & 3)] = (uint8_t)v; }
     __device__ int frame(int d) const { return (int)t[(ROW_STACK + d) * EPW]; }
-    __device__ void set_frame(int d, int v) { t[(ROW_STACK + d) * EPW] = (uint32_t)v; }
+    /* replicated code: all G lanes get here with the same value, the owner writes */
+    __device__ void set_cell(int c, int v) { if (owner()) put_cell(c, v); }
+    __device__ void set_bomb(int s, int v) { if (owner()) put_bomb(s, v); }
+    __device__ void set_flame(int s, int v) { if (owner()) put_flame(s, v); }
+    __device__ void set_bdest(int i, int v) { if (owner()) put_bdest(i, v); }
+    __device__ void set_frame(int d, int v) { if (owner()) t[(ROW_STACK + d) * EPW] = (uint32_t)v; }
 };
 
 struct StepParams {
@@ -118,20 +157,34 @@ __device__ __forceinline__ void store_segment(uint32_t* col, int64_t np, const u
     }
 }
 
-template <int EPW>
-__global__ __launch_bounds__(64, (EPW == 16 ? 4 : 2)) void pom_step_kernel(StepParams p)
+/* the quad kernel needs 157 VGPRs: 3 wavefronts per SIMD without spilling (capping it at 128 for 4 costs 60 B/lane of
+ * scratch and measured 12 % slower, profiles/r01_quad.txt) */
+#ifndef POM_QUAD_WAVES
+#define POM_QUAD_WAVES 3
+#endif
+template <int EPW, int G>
+__global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : 2)) void pom_step_kernel(StepParams p)
 {
+    static_assert(G == 1 || (G == 4 && EPW == 16), "a quad per env needs 16 envs per wavefront");
     __shared__ uint32_t tile[LDS_ROWS * EPW];
     const int lane = threadIdx.x;
-    const int el = lane % EPW, sub = lane / EPW; /* env within the wavefront; which of the 64/EPW row groups this lane moves */
     const int64_t tile_id = p.block0 + blockIdx.x;
-    const int64_t e = tile_id * EPW + el;
     const int64_t np = p.n_pad;
-    const bool owner = sub == 0;             /* the lane that runs env e's tick */
-    const bool valid = owner && e < p.n;
     const bool env_mode = p.mode == POM_MODE_ENV;
-    uint32_t* t = tile + el;
-    uint32_t* col = p.state + e;             /* buffers hold n_pad columns: in range for every lane */
+    /* data movement: lane -> (env el, row group sub) so that one DMA / store instruction covers 64/EPW rows */
+    const int el = lane % EPW, sub = lane / EPW;
+    const int64_t e_d = tile_id * EPW + el;
+    uint32_t* col_d = p.state + e_d;         /* buffers hold n_pad columns: in range for every lane */
+    const uint32_t* scol_d = p.snap + e_d;
+    /* the tick: G = 1: the lanes with sub == 0 own env el; G = 4: lane -> (env lane/4, member lane%4), all lanes run */
+    const int ec = G == 1 ? el : lane >> 2;
+    const int member = G == 1 ? 0 : lane & 3;
+    const int64_t e = tile_id * EPW + ec;
+    const bool owner = G == 1 ? sub == 0 : member == 0; /* the lane that speaks for env e (register rows, counters) */
+    const bool runs = G == 1 ? sub == 0 : true;         /* the lanes that execute env e's tick */
+    const bool valid = runs && e < p.n;
+    uint32_t* t = tile + ec;
+    uint32_t* col = p.state + e;
     const uint32_t* scol = p.snap + e;
 
 #if defined(POM_DIAG)
@@ -143,13 +196,17 @@ __global__ __launch_bounds__(64, (EPW == 16 ? 4 : 2)) void pom_step_kernel(StepP
     /* a finished env restarts from its snapshot: pick the source column per lane, one pass */
     bool reload = e < p.n && env_mode && p.auto_reset && (status & POM_ST_DONE);
     const uint32_t* src = reload ? scol : col;
-    load_tile<EPW>(src, np, tile, sub);
+    {
+        const bool reload_d = G == 1 ? reload
+                                     : (e_d < p.n && env_mode && p.auto_reset && ((col_d[POM_REC_META2 * np] >> 8) & POM_ST_DONE));
+        load_tile<EPW>(reload_d ? scol_d : col_d, np, tile, sub);
+    }
     int time_step = 0;
     uint32_t ag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     PomLane L;
     {
         uint32_t m = 0, m2 = 0;
-        if (owner) {
+        if (runs) {
             time_step = (int)src[POM_REC_TIMESTEP * np];
 #pragma unroll
             for (int k = 0; k < 8; k++) ag[k] = src[(POM_REC_AGENTS + k) * np];
@@ -162,8 +219,8 @@ __global__ __launch_bounds__(64, (EPW == 16 ? 4 : 2)) void pom_step_kernel(StepP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the DMA rows have landed (one wavefront per workgroup: no barrier) */
     c_resets += __popcll(__ballot(reload && owner));
 
-    LdsEnv<EPW> acc{t};
-    PomStepper<LdsEnv<EPW>> stepper(acc, L);
+    LdsEnv<EPW, G> acc{t, member};
+    PomStepper<LdsEnv<EPW, G>> stepper(acc, L);
 #if defined(POM_DIAG)
     for (int k = 0; k < POM_PH_N; k++) L.t_acc[k] = 0;
     L.t_last = t_begin;
@@ -172,12 +229,13 @@ __global__ __launch_bounds__(64, (EPW == 16 ? 4 : 2)) void pom_step_kernel(StepP
 
     for (int tk = 0; tk < p.ticks; tk++) {
         if (tk > 0) {
-            /* every lane of the env's row group needs its owner's verdict */
-            const int done_now = __shfl((int)(status & POM_ST_DONE), el);
-            reload = e < p.n && env_mode && p.auto_reset && done_now;
-            if (reload) {
-                load_tile<EPW>(scol, np, tile, sub); /* EXEC-masked: only the restarting envs' columns are overwritten */
-                if (owner) {
+            /* the lanes that move env el's rows need the verdict of the lane that owns env el */
+            const int done_d = __shfl((int)(status & POM_ST_DONE), G == 1 ? el : 4 * el);
+            const bool reload_d = e_d < p.n && env_mode && p.auto_reset && done_d;
+            reload = e < p.n && env_mode && p.auto_reset && (status & POM_ST_DONE) && runs;
+            if (reload_d) load_tile<EPW>(scol_d, np, tile, sub); /* EXEC-masked: only the restarting envs' columns are overwritten */
+            if (__any(reload_d)) {
+                if (reload) {
                     time_step = (int)scol[POM_REC_TIMESTEP * np];
 #pragma unroll
                     for (int k = 0; k < 8; k++) ag[k] = scol[(POM_REC_AGENTS + k) * np];
@@ -210,16 +268,16 @@ __global__ __launch_bounds__(64, (EPW == 16 ? 4 : 2)) void pom_step_kernel(StepP
                 newly_done = (status & POM_ST_DONE) != 0;
             }
         }
-        c_steps += __popcll(__ballot(active));
-        c_episodes += __popcll(__ballot(newly_done));
-        c_ub += __popcll(__ballot(new_ub));
+        c_steps += __popcll(__ballot(active && owner));
+        c_episodes += __popcll(__ballot(newly_done && owner));
+        c_ub += __popcll(__ballot(new_ub && owner));
         POM_STAMP(L, POM_PH_EPILOGUE);
     }
 
     /* write back: LDS rows by all lanes, the register-resident rows by the owner */
-    store_segment<EPW, POM_REC_BOARD, ROW_BOARD, 61>(col, np, tile, sub, el);
-    store_segment<EPW, POM_REC_BOMBS, ROW_BOMBS, 20>(col, np, tile, sub, el);
-    store_segment<EPW, POM_REC_FLAMES, ROW_FLAMES, 20>(col, np, tile, sub, el);
+    store_segment<EPW, POM_REC_BOARD, ROW_BOARD, 61>(col_d, np, tile, sub, el);
+    store_segment<EPW, POM_REC_BOMBS, ROW_BOMBS, 20>(col_d, np, tile, sub, el);
+    store_segment<EPW, POM_REC_FLAMES, ROW_FLAMES, 20>(col_d, np, tile, sub, el);
     if (owner) {
         col[POM_REC_TIMESTEP * np] = (uint32_t)time_step;
         col[POM_REC_META * np] = pom_lane_meta(L);
@@ -345,6 +403,7 @@ struct PomBatch {
     bool own_stream = false;
     int64_t n = 0, n_pad = 0, n_waves = 0, env_offset = 0; /* n_waves: counter slots, sized for the smallest EPW */
     int epw = 64;
+    bool quad = false; /* EPW 16 with four lanes per env (pom_step_kernel<16, 4>) */
     int mode = POM_MODE_ENV, auto_reset = 0, max_steps = 0;
     uint32_t* state = nullptr;
     uint32_t* snap = nullptr;
@@ -447,20 +506,41 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
     h->n = n_envs;
     h->n_pad = (n_envs + 63) / 64 * 64;
     h->n_waves = h->n_pad / 16;
-    /* envs per wavefront: the tick is issue-bound, so what matters is filling the 1024 SIMDs and, for big
-     * batches, not letting the 32 KB tile of 64-env wavefronts cap residency at 5 per CU.  Measured on MI355X
-     * (scripts/epw_sweep.py, profiles/r01_epw_sweep.txt): 16 wins below ~8k envs, 32 from there up. */
-    h->epw = h->n_pad <= 8192 ? 16 : 32;
-    if (o.envs_per_wave == 16 || o.envs_per_wave == 32 || o.envs_per_wave == 64) h->epw = o.envs_per_wave;
-    else if (o.envs_per_wave != 0) {
+    /* Kernel shape.  Default: the quad kernel (16 envs per wavefront, 4 adjacent lanes per env) — fastest at every batch
+     * size measured (profiles/r01_quad.txt).  The one-lane-per-env variants (64 / 32 / 16 envs per wavefront) stay
+     * selectable; all produce identical results. */
+    h->epw = 16;
+    h->quad = true;
+    if (o.lanes_per_env != 0 && o.lanes_per_env != 1 && o.lanes_per_env != 4) {
+        snprintf(g_err, sizeof g_err, "pom_batch_create: lanes_per_env must be 0, 1 or 4");
+        delete h;
+        return POM_E_ARG;
+    }
+    if (o.envs_per_wave != 0 && o.envs_per_wave != 16 && o.envs_per_wave != 32 && o.envs_per_wave != 64) {
         snprintf(g_err, sizeof g_err, "pom_batch_create: envs_per_wave must be 0, 16, 32 or 64");
         delete h;
         return POM_E_ARG;
     }
-    if (const char* ev = getenv("POM_EPW")) { /* tuning override for sweeps */
-        const int v = atoi(ev);
-        if (v == 16 || v == 32 || v == 64) h->epw = v;
+    if (o.envs_per_wave != 0) {
+        h->epw = o.envs_per_wave;
+        h->quad = h->epw == 16 && o.lanes_per_env != 1;
+    } else if (o.lanes_per_env == 1) {
+        h->quad = false;
+        h->epw = h->n_pad <= 8192 ? 16 : 32;
     }
+    if (o.lanes_per_env == 4 && !h->quad) {
+        snprintf(g_err, sizeof g_err, "pom_batch_create: lanes_per_env 4 needs envs_per_wave 16 (or 0)");
+        delete h;
+        return POM_E_ARG;
+    }
+    if (const char* ev = getenv("POM_EPW")) { /* tuning overrides for sweeps */
+        const int v = atoi(ev);
+        if (v == 16 || v == 32 || v == 64) {
+            h->epw = v;
+            h->quad = false;
+        }
+    }
+    if (const char* ev = getenv("POM_QUAD")) h->quad = atoi(ev) != 0 && h->epw == 16;
     /* sub-batches per step.  Measured on MI355X (scripts/streams_test.py, profiles/r01_streams.txt): 2 parts give
      * 40.8 -> 36.4 us at 64k envs and 120 -> 93 us at 262k, 4 parts only 35.1 — but ROCm multiplexes all streams of
      * the process onto 4 hardware queues, kernels that share a queue serialize, and each part has a ~30 us latency
@@ -666,9 +746,10 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
         const dim3 grid((unsigned)(b1 - b0));
         const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
         if (prof) HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_n], st));
-        if (h->epw == 64) pom_step_kernel<64><<<grid, dim3(64), 0, st>>>(p);
-        else if (h->epw == 32) pom_step_kernel<32><<<grid, dim3(64), 0, st>>>(p);
-        else pom_step_kernel<16><<<grid, dim3(64), 0, st>>>(p);
+        if (h->epw == 64) pom_step_kernel<64, 1><<<grid, dim3(64), 0, st>>>(p);
+        else if (h->epw == 32) pom_step_kernel<32, 1><<<grid, dim3(64), 0, st>>>(p);
+        else if (h->quad) pom_step_kernel<16, 4><<<grid, dim3(64), 0, st>>>(p);
+        else pom_step_kernel<16, 1><<<grid, dim3(64), 0, st>>>(p);
         HIPCHK(hipGetLastError());
         if (prof) {
             HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_n + 1], st));
@@ -846,10 +927,11 @@ int pom_batch_profile_read(PomBatch* h, double* mean_ms, int64_t* launches)
     return POM_OK;
 }
 
-int pom_batch_launch_shape(PomBatch* h, int32_t* envs_per_wave, int32_t* launches_per_step)
+int pom_batch_launch_shape(PomBatch* h, int32_t* envs_per_wave, int32_t* lanes_per_env, int32_t* launches_per_step)
 {
     if (!h) return POM_E_ARG;
     if (envs_per_wave) *envs_per_wave = h->epw;
+    if (lanes_per_env) *lanes_per_env = h->quad ? 4 : 1;
     if (launches_per_step) *launches_per_step = h->parts;
     return POM_OK;
 }

@@ -115,7 +115,7 @@ POM_HD int pom_pack_state(const int32_t* st, uint32_t* rec, int64_t stride)
         rec[(POM_REC_BOMBS + k) * stride] = (uint32_t)bombs[k];
     for (int k = 0; k < POM_MAX_BOMBS; k++) {
         const int32_t* f = flames + 4 * k;
-        bad |= (f[0] < 0) | (f[0] > 255) | (f[1] < 0) | (f[1] > 255);
+        bad |= (f[0] < 0) | (f[0] >= POM_BOARD_SIZE) | (f[1] < 0) | (f[1] >= POM_BOARD_SIZE); /* also the stale slots */
         bad |= (f[2] < -128) | (f[2] > 127) | (f[3] < 0) | (f[3] > 255);
         rec[(POM_REC_FLAMES + k) * stride] =
             (uint32_t)f[0] | ((uint32_t)f[1] << 8) | (((uint32_t)f[2] & 0xFF) << 16) | ((uint32_t)f[3] << 24);

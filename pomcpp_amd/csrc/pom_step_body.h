@@ -22,7 +22,18 @@
  *   - board cells are the 16-bit codes of pom_packed.h, bombs the reference's raw
  *     bit-packed ints, flames one dword each.
  *
+ * G lanes per env.  The store says how many lanes of the wavefront work on one env (A::G): 1 in the
+ * 64/32/16-envs-per-wavefront kernels and on the host, 4 ADJACENT lanes (a quad) in pom_step_kernel_quad.
+ * All G lanes execute the tick in lock-step on identical register state ("replicated"): every decision is
+ * taken G times, writes to the store go through the owner lane only (set_*).  Where the reference's order
+ * does not matter the work is split instead — lane `sub` takes queue slots / flame arms / explosion rays
+ * sub, sub+G, ... and writes with put_* — and the partial results are combined with the group reductions
+ * gor / gmin / gadd (DPP quad permutes on the device, identities for G = 1).  Every split section is
+ * read-only until a group vote has excluded the order-dependent cases, which then run replicated.
+ *
  * Store interface A (all indices per lane):
+ *   static constexpr int G;  int sub();  int gor(int) / gmin(int) / gadd(int)
+ *   set_x(...)  write by the owner lane only (replicated code)   put_x(...)  write by the calling lane (split code)
  *   int  cell(int c) / void set_cell(int c, int code)      c = y*11+x, 16-bit codes
  *   int  bomb(int slot) / void set_bomb(int slot, int v)    physical queue slot 0..19
  *   int  flame(int slot) / void set_flame(int slot, int v)  packed x|y<<8|time<<16|strength<<24
@@ -133,15 +144,17 @@ struct PomStepper {
      * HasBomb / GetBomb / GetBombIndex, bboard.cpp:265-311 */
     POM_HD int bomb_index(int pos) const
     {
-        int r = -1;
-        for (int i = 0; i < L.bCnt; i++) {
+        int r = 99; /* split: lane `sub` looks at offsets sub, sub+G, ...; the lowest hit of the group wins */
+        for (int i = a.sub(); i < L.bCnt; i += A::G) {
             if (pb_pos(bomb_at(i)) == pos) {
                 r = i;
                 break;
             }
         }
-        return r;
+        r = a.gmin(r);
+        return r == 99 ? -1 : r;
     }
+    POM_HD void put_bomb_at(int i, int v) { a.put_bomb(wrap20(L.bIdx + i), v); }
 
     POM_HD int get_agent(int x, int y) const /* bboard.cpp:289-299 */
     {
@@ -178,8 +191,12 @@ struct PomStepper {
 
     POM_HD void remove_at(int at) /* FixedQueue::RemoveAt, bboard.hpp:151-160 */
     {
-        for (int i = at + 1; i < L.bCnt; i++)
-            set_bomb_at(i - 1, bomb_at(i));
+        /* split: slot i-1 <- slot i for i = at+1+sub, +G, ...  Within one pass all reads are issued before all
+         * writes (one ds_read, then one ds_write per wavefront), and slot i-1 was read one lane / one pass earlier */
+        for (int i = at + 1 + a.sub(); i < L.bCnt; i += A::G) {
+            const int v = bomb_at(i);
+            put_bomb_at(i - 1, v);
+        }
         L.bCnt--;
     }
 
@@ -215,10 +232,69 @@ struct PomStepper {
         a.set_cell(c, POM_C_FLAME | (c << 3));
     }
 
+    /* bookkeeping after a frame's four rays: ExplodeTopBomb's PopBomb / ExplodeBombAt's RemoveAt */
+    POM_HD void explode_epilogue(int rem)
+    {
+        if (rem == REM_TOP) {
+            owner_bombcount_dec(bomb_at(0));
+            L.bIdx = wrap20(L.bIdx + 1);
+            L.bCnt--;
+        } else if (rem != REM_NONE) {
+            /* the slot is re-read after the nested chain: stale index, SURVEY Q2 */
+            owner_bombcount_dec(bomb_at(rem));
+            remove_at(rem);
+        }
+    }
+
+    POM_HD static int ray_cell(int c0, int dir, int i) { return c0 + (dir == 0 ? i : dir == 1 ? -i : dir == 2 ? POM_N * i : -POM_N * i); }
+    POM_HD static int ray_room(int x, int y, int s, int dir)
+    {
+        const int room = dir == 0 ? POM_N - 1 - x : dir == 1 ? x : dir == 2 ? POM_N - 1 - y : y;
+        return room < s ? room : s;
+    }
+
     POM_HD void explode(int x, int y, int strength, int rem)
     {
-        flame_prologue(x, y, strength);
         int s = strength < 0 ? 0 : strength > POM_N ? POM_N : strength;
+        /* Split fast path.  Read-only scan of the four rays (lane `sub` takes rays sub, sub+G, ...): how far does
+         * each reach, and does any of them touch a BOMB or an agent cell?  If none does, no chain and no kill can
+         * happen along the rays, every cell belongs to exactly one ray, and the order +x,-x,+y,-y is immaterial:
+         * the rays are then written in parallel.  Otherwise nothing has been written yet and the literal
+         * sequential engine below runs (replicated). */
+        {
+            const int c0 = y * POM_N + x;
+            int touchy = 0;
+            uint32_t lens = 0; /* reach of ray r in nibble r */
+            for (int r = a.sub(); r < 4; r += A::G) {
+                const int lim = ray_room(x, y, s, r);
+                int len = 0;
+                for (int i = 1; i <= lim; i++) {
+                    const int e = a.cell(ray_cell(c0, r, i));
+                    if (e == POM_C_BOMB || pc_is_agent(e)) {
+                        touchy = 1;
+                        break;
+                    }
+                    if (e == POM_C_RIGID) break;
+                    len = i;
+                    if (pc_is_wood(e)) break;
+                }
+                lens |= (uint32_t)len << (4 * r);
+            }
+            if (!a.gor(touchy)) {
+                flame_prologue(x, y, strength);
+                for (int r = a.sub(); r < 4; r += A::G) {
+                    const int len = (lens >> (4 * r)) & 0xF;
+                    for (int i = 1; i <= len; i++) {
+                        const int c = ray_cell(c0, r, i);
+                        const int e = a.cell(c);
+                        a.put_cell(c, POM_C_FLAME | ((c0 << 3) + (pc_is_wood(e) ? (e & 3) : 0)));
+                    }
+                }
+                explode_epilogue(rem);
+                return;
+            }
+        }
+        flame_prologue(x, y, strength);
         int dir = 0, i = 1, sp = 0, resume = 0;
         for (;;) {
             if (!resume) { /* skip exhausted rays: length s or the board edge, whichever is nearer */
@@ -228,15 +304,7 @@ struct PomStepper {
                 }
             }
             if (dir >= 4) { /* all four rays done: the caller's bookkeeping, then back into the parent */
-                if (rem == REM_TOP) {
-                    owner_bombcount_dec(bomb_at(0));
-                    L.bIdx = wrap20(L.bIdx + 1);
-                    L.bCnt--;
-                } else if (rem != REM_NONE) {
-                    /* the slot is re-read after the nested chain: stale index, SURVEY Q2 */
-                    owner_bombcount_dec(bomb_at(rem));
-                    remove_at(rem);
-                }
+                explode_epilogue(rem);
                 if (sp == 0) return;
                 sp--;
                 const int fr = a.frame(sp);
@@ -286,27 +354,38 @@ struct PomStepper {
     POM_HD void tick_flames() /* step_utility.cpp:208-222 + PopFlame bboard.cpp:148-180 */
     {
         if (L.fCnt <= 0) return;
-        for (int i = 0; i < L.fCnt; i++) {
-            const int p = (L.fIdx + i) % POM_Q;
-            const int f = a.flame(p);
-            a.set_flame(p, (f & ~0xFF0000) | ((f - 0x10000) & 0xFF0000));
+        {   /* timeLeft-- of every queued flame; split over the lanes (offsets i and i+20 fall to the same lane) */
+            int p = L.fIdx + a.sub();
+            p = wrap20(p);
+            for (int i = a.sub(); i < L.fCnt; i += A::G) {
+                const int f = a.flame(p);
+                a.put_flame(p, (f & ~0xFF0000) | ((f - 0x10000) & 0xFF0000));
+                p = wrap20(p + A::G);
+            }
         }
         const int n = L.fCnt;
         for (int k = 0; k < n; k++) {
             const int f = a.flame(L.fIdx);
-            if (((f >> 16) & 0xFF) != 0) continue;
+            if (((f >> 16) & 0xFF) != 0) break; /* nothing pops, so flames[0] stays what it is for the remaining rounds */
+            /* PopFlame: every flame cell on the +-strength cross that carries this origin's id gives way to the item
+             * under it.  The cells are independent: the four arms are split over the lanes, the centre is the owner's */
             const int x = f & 0xFF, y = (f >> 8) & 0xFF;
             int s = (f >> 24) & 0xFF;
             s = s > POM_N ? POM_N : s; /* cells further out are out of bounds anyway */
             const int sig = x + POM_N * y;
-            for (int d = -s; d <= s; d++) {
-                if (!oob(x + d, y)) {
-                    const int c = y * POM_N + x + d, e = a.cell(c);
-                    if (pc_is_flame(e) && ((e & 0x3FFF) >> 3) == sig) a.set_cell(c, pc_flag_item(e & 3));
+            if (!oob(x, y)) {
+                const int c0 = y * POM_N + x;
+                {
+                    const int e = a.cell(c0);
+                    if (pc_is_flame(e) && ((e & 0x3FFF) >> 3) == sig) a.set_cell(c0, pc_flag_item(e & 3));
                 }
-                if (!oob(x, y + d)) {
-                    const int c = (y + d) * POM_N + x, e = a.cell(c);
-                    if (pc_is_flame(e) && ((e & 0x3FFF) >> 3) == sig) a.set_cell(c, pc_flag_item(e & 3));
+                for (int r = a.sub(); r < 4; r += A::G) {
+                    const int lim = ray_room(x, y, s, r);
+                    for (int i = 1; i <= lim; i++) {
+                        const int c = ray_cell(c0, r, i);
+                        const int e = a.cell(c);
+                        if (pc_is_flame(e) && ((e & 0x3FFF) >> 3) == sig) a.put_cell(c, pc_flag_item(e & 3));
+                    }
                 }
             }
             L.fIdx = wrap20(L.fIdx + 1);
@@ -471,14 +550,107 @@ struct PomStepper {
         /* HasBomb(x, y) is only ever asked about the moving agent's own cell (step.cpp:89,127,152,172) and bombs
          * do not move during the agent loop: one pass over the queue answers it for all four agents */
         int on_bomb = 0;
-        for (int k = 0; k < L.bCnt; k++) {
+        for (int k = a.sub(); k < L.bCnt; k += A::G) { /* split over the lanes, OR-combined */
             const int bp = pb_pos(bomb_at(k));
 #pragma unroll
             for (int j = 0; j < 4; j++) on_bomb |= (bp == (px[j] | (py[j] << 4))) << j;
         }
+        on_bomb = a.gor(on_bomb);
         POM_STAMP(L, POM_PH_AGENT_PREP);
         /* agent loop, step.cpp:35-185 */
-        {
+        int agents_done = 0;
+        if (A::G == 4) {
+            /* Quad fast path: lane m handles agent m, all four in ONE pass.  Sound when the order of the loop cannot
+             * matter: no dependency edge (every agent is a root, visited 0,1,2,3) and no two live agents on one cell.
+             * Then an agent reads and writes only its own cell, its destination (shared destinations block both,
+             * step_utility.cpp:264-277, whichever comes first; a shared flame kills both), its own registers and its
+             * own queue slot.  Queue order of planters = agent order = exclusive prefix count below. */
+            int alone = nroots == 4;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = i + 1; j < 4; j++)
+                    alone &= ((deadmask >> i) & 1) | ((deadmask >> j) & 1) | (px[i] != px[j]) | (py[i] != py[j]);
+            if (alone) {
+                agents_done = 1;
+                const int m = a.sub();
+                int av = sel4(m, L.a0), a1v = sel4(m, L.a1);
+                const int mvm = (mvp >> (4 * m)) & 0xF;
+                const int live = !ag_dead(av);
+                /* plants: PlantBombModifiedLife(x, y, m, 11), bboard.cpp:125-146 */
+                const int wants = live && mvm == POM_MOVE_BOMB && pom_sext8((uint32_t)av >> 16) < pom_sext16((uint32_t)a1v);
+                const int w_all = a.gor(wants << m);
+                const int slot_off = __builtin_popcount(w_all & ((1 << m) - 1));
+                const int fits = wants && L.bCnt + slot_off < POM_Q;
+                int ubm = (wants && !fits) ? POM_UB_QUEUE_OVERFLOW : 0;
+                if (fits) {
+                    const int slot = wrap20(L.bIdx + L.bCnt + slot_off);
+                    int b = a.bomb(slot); /* stale bits of the slot survive: SURVEY Q1 */
+                    b = pb_set(b, 0xF00u, (uint32_t)m << 8);
+                    b = pb_set(b, 0xFFu, (uint32_t)ag_x(av) + ((uint32_t)ag_y(av) << 4));
+                    b = pb_set(b, 0xF000u, (uint32_t)((a1v >> 16) & 0xFFFF) << 12);
+                    b = pb_set(b, 0xF0000u, (uint32_t)(POM_BOMB_LIFETIME + 1) << 16);
+                    a.put_bomb(slot, b);
+                    av = ag_bombcount_add(av, 1);
+                }
+                int died = 0;
+                if (live && mvm != POM_MOVE_IDLE && mvm != POM_MOVE_BOMB) {
+                    const int x = ag_x(av), y = ag_y(av);
+                    const int dkey = (dstp >> (8 * m)) & 0xFF;
+                    const int ddx = (dkey & 0xF) - 1, ddy = (dkey >> 4) - 1;
+                    if (!oob(ddx, ddy)) {
+                        const int dc = ddy * POM_N + ddx, oc = y * POM_N + x;
+                        int item = a.cell(dc);
+                        const int vacated = ((on_bomb >> m) & 1) ? POM_C_BOMB : POM_C_PASSAGE;
+                        int collide = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            collide |= (j != m) & !((deadmask >> j) & 1) & (((dstp >> (8 * j)) & 0xFF) == (uint32_t)dkey);
+                        if (pc_is_flame(item)) { /* step.cpp:84-99 */
+                            died = 1;
+                            av |= 1 << 25;
+                            if (a.cell(oc) == (POM_C_AGENT | m)) a.put_cell(oc, vacated);
+                        } else if (!collide) {
+                            if (pc_is_powerup(item)) { /* ConsumePowerup, step_utility.cpp:247-262 */
+                                if (item == POM_EXTRABOMB) a1v = (a1v & ~0xFFFF) | ((a1v + 1) & 0xFFFF);
+                                else if (item == POM_INCRRANGE) a1v += 1 << 16;
+                                else av |= 1 << 24;
+                                item = POM_C_PASSAGE;
+                            }
+                            if (item == POM_C_PASSAGE) { /* step.cpp:120-140 */
+                                if (a.cell(oc) == (POM_C_AGENT | m)) a.put_cell(oc, vacated);
+                                a.put_cell(dc, POM_C_AGENT | m);
+                                av = ag_setpos(av, ddx, ddy);
+                            } else if (item == POM_C_BOMB) { /* step.cpp:147-184 */
+                                a.put_cell(oc, vacated);
+                                a.put_cell(dc, POM_C_AGENT | m);
+                                av = ag_setpos(av, ddx, ddy);
+                                if (ag_kick(av)) {
+                                    int bi = -1; /* GetBomb: the lanes are on different cells here, each scans for itself */
+                                    for (int k = 0; k < L.bCnt; k++) {
+                                        if (pb_pos(bomb_at(k)) == (ddx | (ddy << 4))) {
+                                            bi = k;
+                                            break;
+                                        }
+                                    }
+                                    if (bi < 0) ubm |= POM_UB_NULL_BOMB; /* step.cpp:167 dereferences nullptr */
+                                    else put_bomb_at(bi, pb_set(bomb_at(bi), 0xF00000u, (uint32_t)mvm << 20));
+                                }
+                            }
+                        }
+                    }
+                }
+                /* back to identical registers in all four lanes */
+                L.a0[0] = a.template gbcast<0>(av); L.a0[1] = a.template gbcast<1>(av);
+                L.a0[2] = a.template gbcast<2>(av); L.a0[3] = a.template gbcast<3>(av);
+                L.a1[0] = a.template gbcast<0>(a1v); L.a1[1] = a.template gbcast<1>(a1v);
+                L.a1[2] = a.template gbcast<2>(a1v); L.a1[3] = a.template gbcast<3>(a1v);
+                L.alive -= a.gadd(died);
+                L.bCnt += a.gadd(fits);
+                L.ub |= (uint32_t)a.gor(ubm);
+            }
+        }
+        if (!agents_done) {
             int root_idx = 0;
             int i = ouroboros ? 0 : (int)(roots & 0xF);
             for (int n = 0; n < 4; n++) {
@@ -589,10 +761,10 @@ struct PomStepper {
              * if neither, loop B below cannot see a collision and collapses to one cell test per bomb. */
             int moving = 0, shared = 0;
             uint32_t occ[4] = {0, 0, 0, 0};
-            for (int k = 0; k < L.bCnt; k++) {
+            for (int k = a.sub(); k < L.bCnt; k += A::G) { /* split: each lane its own slots, combined below */
                 const int b = pb_set(bomb_at(k), 0xF000000u, 0);
-                set_bomb_at(k, b);
-                a.set_bdest(k, bomb_target_key(b));
+                put_bomb_at(k, b);
+                a.put_bdest(k, bomb_target_key(b));
                 moving |= pb_dir(b) != 0;
                 const int idx = pb_y(b) * POM_N + pb_x(b);
                 const int w = idx >> 5;
@@ -603,6 +775,16 @@ struct PomStepper {
                 occ[1] |= w == 1 ? m : 0u;
                 occ[2] |= w == 2 ? m : 0u;
                 occ[3] |= w >= 3 ? m : 0u;
+            }
+            if (A::G > 1) { /* two lanes' bombs share a cell iff the lanes' cell sets overlap: |union| < sum of |set| */
+                int mine = 0, all = 0;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    mine += __builtin_popcount(occ[w]);
+                    all += __builtin_popcount((uint32_t)a.gor((int)occ[w]));
+                }
+                shared = a.gor(shared) | (a.gadd(mine) != all);
+                moving = a.gor(moving);
             }
             /* bomb loop A, step.cpp:195-227 */
             for (int k = 0; k < L.bCnt; k++) {
@@ -632,13 +814,28 @@ struct PomStepper {
             /* bomb loop B, step.cpp:230-278 */
             if (!moving && !shared) {
                 /* every bomb rests on a cell of its own: HasBombCollision is false for all of them, each "moves"
-                 * onto its own cell (step.cpp:243-272): a walkable cell there becomes BOMB, a flame detonates it */
-                for (int k = 0; k < L.bCnt; k++) {
+                 * onto its own cell (step.cpp:243-272): a walkable cell there becomes BOMB, a flame detonates it.
+                 * Split: first only look (does any bomb sit in a flame?); without a detonation the writes are
+                 * independent and done in parallel, with one the queue is walked in order */
+                int in_flame = 0;
+                for (int k = a.sub(); k < L.bCnt; k += A::G) {
                     const int b = bomb_at(k);
-                    const int c = pb_y(b) * POM_N + pb_x(b);
-                    const int e = a.cell(c);
-                    if (pc_is_walkable(e)) a.set_cell(c, POM_C_BOMB);
-                    else if (pc_is_flame(e)) explode(pb_x(b), pb_y(b), owner_strength(b), k);
+                    in_flame |= pc_is_flame(a.cell(pb_y(b) * POM_N + pb_x(b)));
+                }
+                if (!a.gor(in_flame)) {
+                    for (int k = a.sub(); k < L.bCnt; k += A::G) {
+                        const int b = bomb_at(k);
+                        const int c = pb_y(b) * POM_N + pb_x(b);
+                        if (pc_is_walkable(a.cell(c))) a.put_cell(c, POM_C_BOMB);
+                    }
+                } else {
+                    for (int k = 0; k < L.bCnt; k++) {
+                        const int b = bomb_at(k);
+                        const int c = pb_y(b) * POM_N + pb_x(b);
+                        const int e = a.cell(c);
+                        if (pc_is_walkable(e)) a.set_cell(c, POM_C_BOMB);
+                        else if (pc_is_flame(e)) explode(pb_x(b), pb_y(b), owner_strength(b), k);
+                    }
                 }
             } else
             for (int k = 0; k < L.bCnt; k++) {
@@ -676,8 +873,8 @@ struct PomStepper {
             }
             POM_STAMP(L, POM_PH_BOMB_B);
             /* TickBombs, step_utility.cpp:224-245 */
-            for (int k = 0; k < L.bCnt; k++)
-                set_bomb_at(k, (int)((uint32_t)bomb_at(k) - (1u << 16)));
+            for (int k = a.sub(); k < L.bCnt; k += A::G) /* split */
+                put_bomb_at(k, (int)((uint32_t)bomb_at(k) - (1u << 16)));
             const int n = L.bCnt;
             for (int k = 0; k < n && L.bCnt > 0; k++) {
                 const int c = bomb_at(0);

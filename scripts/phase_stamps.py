@@ -24,7 +24,7 @@ subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared"
 import pomcpp_amd.batch as B
 B.library_path = lambda: lib
 import pomcpp_amd as pa
-env = B.BatchEnvironment(a.envs, mode=B.MODE_ENV, auto_reset=True, max_steps=800)
+env = B.BatchEnvironment(a.envs, mode=B.MODE_ENV, auto_reset=True, max_steps=800, streams=1)
 env.make_game(pa.make_boards(a.envs, seed=1, kind=a.kind))
 env.step_random(1, a.dist, ticks=50)
 out = (C.c_longlong * 9)()
@@ -35,7 +35,7 @@ env.step_random(1, a.dist, ticks=a.ticks)
 L.pom_diag_read(env._h, out)
 names = ["load", "tick_flames", "agent_prep", "agent_loop", "bomb_loop_A", "bomb_loop_B", "tick_bombs+explosions", "epilogue", "store"]
 v = np.array(list(out), dtype=np.float64)
-waves = (a.envs + 63) // 64
+epw = env.launch_shape()[0]; waves = (a.envs + epw - 1) // epw
 per = v / (waves * a.ticks)
 print(f"envs {a.envs} kind {a.kind} dist {a.dist}: s_memtime ticks per wavefront-tick (100 MHz clock ticks if constant clock), total {per.sum():.0f}")
 for n, x in zip(names, per):

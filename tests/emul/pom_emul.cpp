@@ -13,6 +13,16 @@ struct ArrayEnv {
     uint16_t cells[122];
     int bombs[20], flames[20], stack[POM_STACK_DEPTH];
     uint8_t bd[20];
+    static constexpr int G = 1; /* one lane per env: the split sections degenerate to plain loops */
+    int sub() const { return 0; }
+    int gor(int v) const { return v; }
+    int gmin(int v) const { return v; }
+    int gadd(int v) const { return v; }
+    template <int J> int gbcast(int v) const { return v; }
+    void put_cell(int c, int v) { cells[c] = (uint16_t)v; }
+    void put_bomb(int s, int v) { bombs[s] = v; }
+    void put_flame(int s, int v) { flames[s] = v; }
+    void put_bdest(int i, int v) { bd[i] = (uint8_t)v; }
     int cell(int c) const { return cells[c]; }
     void set_cell(int c, int v) { cells[c] = (uint16_t)v; }
     int bomb(int s) const { return bombs[s]; }

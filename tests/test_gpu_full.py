@@ -175,23 +175,25 @@ def test_single_state_drop_in_and_status_api(hip_lib, oracle):
         env.snapshot()  # current state becomes the restart point, status cleared there
 
 
-@pytest.mark.parametrize("epw", [16, 32, 64])
+@pytest.mark.parametrize("epw,lpe", [(16, 4), (16, 1), (32, 1), (64, 1)])
 @pytest.mark.parametrize("kind,dist", [("ffa", DIST_RANDOM), ("stress", DIST_STRESS)])
-def test_every_envs_per_wave_variant_matches_oracle(hip_lib, oracle, epw, kind, dist):
-    """The three kernel instantiations (16 / 32 / 64 envs per wavefront) are the same function of the input."""
-    n, ticks, seed = 3000 + epw, 80, 4242
+def test_every_kernel_variant_matches_oracle(hip_lib, oracle, epw, lpe, kind, dist):
+    """The four kernel instantiations (quad per env; one lane per env at 16 / 32 / 64 envs per wavefront) are the same
+    function of the input."""
+    n, ticks, seed = 3000 + epw + lpe, 80, 4242
     start = pa.make_boards(n, seed=31, kind=kind)
     want = start.copy()
     oracle.run_random(want, start, ticks, seed, 0, 0, dist, 800)
     for tpl in (1, 5):
-        with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800, envs_per_wave=epw) as env:
+        with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800, envs_per_wave=epw, lanes_per_env=lpe) as env:
+            assert env.launch_shape()[:2] == (epw, lpe)
             env.make_game(start)
             env.step_random(seed, dist, ticks=ticks, ticks_per_launch=tpl)
             assert _digest(env.get_state()) == _digest(want)
             assert env.counters()[CNT_STEPS] == n * ticks
     rng = np.random.default_rng(epw)
     ref = start.copy()
-    with BatchEnvironment(n, mode=MODE_RAW, envs_per_wave=epw) as env:
+    with BatchEnvironment(n, mode=MODE_RAW, envs_per_wave=epw, lanes_per_env=lpe) as env:
         env.make_game(start)
         for _ in range(25):
             mv = rng.integers(0, 6, size=(n, 4), dtype=np.int32)
@@ -200,6 +202,8 @@ def test_every_envs_per_wave_variant_matches_oracle(hip_lib, oracle, epw, kind, 
         assert _digest(env.get_state()) == _digest(ref)
     with pytest.raises(PomError):
         BatchEnvironment(64, envs_per_wave=48)
+    with pytest.raises(PomError):
+        BatchEnvironment(64, envs_per_wave=32, lanes_per_env=4)
 
 
 @pytest.mark.parametrize("streams", [1, 2, 3, 8])
@@ -211,7 +215,7 @@ def test_split_steps_over_streams_give_identical_results(hip_lib, oracle, stream
     want = start.copy()
     oracle.run_random(want, start, ticks, seed, 0, 0, DIST_RANDOM, 800)
     with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800, streams=streams) as env:
-        assert env.launch_shape()[1] == streams
+        assert env.launch_shape()[2] == streams
         env.make_game(start)
         env.step_random(seed, DIST_RANDOM, ticks=ticks // 2)
         mid = env.get_state()          # joins the sub-streams
