@@ -45,6 +45,13 @@
 
 #include "pom_packed.h"
 
+#if defined(__clang__)
+#define POM_NOUNROLL _Pragma("nounroll")
+#else
+#define POM_NOUNROLL
+#endif
+/* Dynamic-trip loops are pinned: unrolled 4-8x by hipcc they blow the VGPR budget of the quad kernel (168 for three
+ * wavefronts per SIMD) into scratch without saving a single LDS round trip. */
 #define POM_N 11
 #define POM_Q 20
 #define POM_STACK_DEPTH 21 /* one frame per queued bomb + the initiating flame */
@@ -145,6 +152,7 @@ struct PomStepper {
     POM_HD int bomb_index(int pos) const
     {
         int r = 99; /* split: lane `sub` looks at offsets sub, sub+G, ...; the lowest hit of the group wins */
+        POM_NOUNROLL
         for (int i = a.sub(); i < L.bCnt; i += A::G) {
             if (pb_pos(bomb_at(i)) == pos) {
                 r = i;
@@ -155,6 +163,14 @@ struct PomStepper {
         return r == 99 ? -1 : r;
     }
     POM_HD void put_bomb_at(int i, int v) { a.put_bomb(wrap20(L.bIdx + i), v); }
+    /* the same scan done by ONE lane alone, for split code in which the lanes of a group look at different cells */
+    POM_HD int bomb_index_alone(int pos) const
+    {
+        POM_NOUNROLL
+        for (int i = 0; i < L.bCnt; i++)
+            if (pb_pos(bomb_at(i)) == pos) return i;
+        return -1;
+    }
 
     POM_HD int get_agent(int x, int y) const /* bboard.cpp:289-299 */
     {
@@ -193,6 +209,7 @@ struct PomStepper {
     {
         /* split: slot i-1 <- slot i for i = at+1+sub, +G, ...  Within one pass all reads are issued before all
          * writes (one ds_read, then one ds_write per wavefront), and slot i-1 was read one lane / one pass earlier */
+        POM_NOUNROLL
         for (int i = at + 1 + a.sub(); i < L.bCnt; i += A::G) {
             const int v = bomb_at(i);
             put_bomb_at(i - 1, v);
@@ -263,16 +280,24 @@ struct PomStepper {
          * sequential engine below runs (replicated). */
         {
             const int c0 = y * POM_N + x;
-            int touchy = 0;
+            int chains = 0, victims = 0;
             uint32_t lens = 0; /* reach of ray r in nibble r */
+            POM_NOUNROLL
             for (int r = a.sub(); r < 4; r += A::G) {
                 const int lim = ray_room(x, y, s, r);
                 int len = 0;
+                POM_NOUNROLL
                 for (int i = 1; i <= lim; i++) {
-                    const int e = a.cell(ray_cell(c0, r, i));
+                    const int c = ray_cell(c0, r, i);
+                    const int e = a.cell(c);
                     if (e == POM_C_BOMB || pc_is_agent(e)) {
-                        touchy = 1;
-                        break;
+                        /* SpawnFlameItem explodes the first queued bomb on this cell, if there is one (bboard.cpp:30-40) */
+                        const int cy = c / POM_N;
+                        if (bomb_index_alone((c - cy * POM_N) | (cy << 4)) >= 0) {
+                            chains = 1;
+                            break;
+                        }
+                        if (pc_is_agent(e)) victims |= 1 << (e & 3); /* killed, the ray goes on (bboard.cpp:26-29) */
                     }
                     if (e == POM_C_RIGID) break;
                     len = i;
@@ -280,10 +305,16 @@ struct PomStepper {
                 }
                 lens |= (uint32_t)len << (4 * r);
             }
-            if (!a.gor(touchy)) {
+            if (!a.gor(chains)) {
                 flame_prologue(x, y, strength);
+                victims = a.gor(victims);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if ((victims >> j) & 1) kill(j);
+                POM_NOUNROLL
                 for (int r = a.sub(); r < 4; r += A::G) {
                     const int len = (lens >> (4 * r)) & 0xF;
+                    POM_NOUNROLL
                     for (int i = 1; i <= len; i++) {
                         const int c = ray_cell(c0, r, i);
                         const int e = a.cell(c);
@@ -296,8 +327,10 @@ struct PomStepper {
         }
         flame_prologue(x, y, strength);
         int dir = 0, i = 1, sp = 0, resume = 0;
+        POM_NOUNROLL
         for (;;) {
             if (!resume) { /* skip exhausted rays: length s or the board edge, whichever is nearer */
+                POM_NOUNROLL
                 for (; dir < 4; dir++, i = 1) {
                     const int room = dir == 0 ? POM_N - 1 - x : dir == 1 ? x : dir == 2 ? POM_N - 1 - y : y;
                     if (i <= (room < s ? room : s)) break;
@@ -357,6 +390,7 @@ struct PomStepper {
         {   /* timeLeft-- of every queued flame; split over the lanes (offsets i and i+20 fall to the same lane) */
             int p = L.fIdx + a.sub();
             p = wrap20(p);
+            POM_NOUNROLL
             for (int i = a.sub(); i < L.fCnt; i += A::G) {
                 const int f = a.flame(p);
                 a.put_flame(p, (f & ~0xFF0000) | ((f - 0x10000) & 0xFF0000));
@@ -364,6 +398,7 @@ struct PomStepper {
             }
         }
         const int n = L.fCnt;
+        POM_NOUNROLL
         for (int k = 0; k < n; k++) {
             const int f = a.flame(L.fIdx);
             if (((f >> 16) & 0xFF) != 0) break; /* nothing pops, so flames[0] stays what it is for the remaining rounds */
@@ -379,8 +414,10 @@ struct PomStepper {
                     const int e = a.cell(c0);
                     if (pc_is_flame(e) && ((e & 0x3FFF) >> 3) == sig) a.set_cell(c0, pc_flag_item(e & 3));
                 }
+                POM_NOUNROLL
                 for (int r = a.sub(); r < 4; r += A::G) {
                     const int lim = ray_room(x, y, s, r);
+                    POM_NOUNROLL
                     for (int i = 1; i <= lim; i++) {
                         const int c = ray_cell(c0, r, i);
                         const int e = a.cell(c);
@@ -396,6 +433,7 @@ struct PomStepper {
     /* AgentBombChainReversion, step_utility.cpp:62-128; mvp = moves, one nibble per agent */
     POM_HD void chain_reversion(uint32_t mvp, int id)
     {
+        POM_NOUNROLL
         for (int hop = 0;; hop++) {
             if (hop >= 8) {
                 L.ub |= POM_UB_REVERT_LOOP;
@@ -409,6 +447,7 @@ struct PomStepper {
             const int origin_agent = get_agent(ox, oy);
             const int okey = (ox + 1) | ((oy + 1) << 4);
             int bd = -1;
+            POM_NOUNROLL
             for (int i = 0; i < L.bCnt; i++) {
                 if (a.bdest(i) == okey) {
                     bd = i;
@@ -458,13 +497,15 @@ struct PomStepper {
         const int b = bomb_at(k);
         const int key = bomb_target_key(b);
         int collided = 0;
-        for (int i = k; i < L.bCnt; i++) {
+        POM_NOUNROLL
+        for (int i = k + a.sub(); i < L.bCnt; i += A::G) { /* split over the lanes; offset k itself can never hit */
             const int o = bomb_at(i);
             if (o != b && bomb_target_key(o) == key) {
-                set_bomb_at(i, pb_set(o, 0xF00000u, 0));
+                put_bomb_at(i, pb_set(o, 0xF00000u, 0));
                 collided = 1;
             }
         }
+        collided = a.gor(collided);
         if (collided && pb_dir(b) != 0) {
             const int nb = pb_set(b, 0xF00000u, 0);
             set_bomb_at(k, nb);
@@ -550,6 +591,7 @@ struct PomStepper {
         /* HasBomb(x, y) is only ever asked about the moving agent's own cell (step.cpp:89,127,152,172) and bombs
          * do not move during the agent loop: one pass over the queue answers it for all four agents */
         int on_bomb = 0;
+        POM_NOUNROLL
         for (int k = a.sub(); k < L.bCnt; k += A::G) { /* split over the lanes, OR-combined */
             const int bp = pb_pos(bomb_at(k));
 #pragma unroll
@@ -626,13 +668,7 @@ struct PomStepper {
                                 a.put_cell(dc, POM_C_AGENT | m);
                                 av = ag_setpos(av, ddx, ddy);
                                 if (ag_kick(av)) {
-                                    int bi = -1; /* GetBomb: the lanes are on different cells here, each scans for itself */
-                                    for (int k = 0; k < L.bCnt; k++) {
-                                        if (pb_pos(bomb_at(k)) == (ddx | (ddy << 4))) {
-                                            bi = k;
-                                            break;
-                                        }
-                                    }
+                                    const int bi = bomb_index_alone(ddx | (ddy << 4)); /* GetBomb; the lanes are on different cells */
                                     if (bi < 0) ubm |= POM_UB_NULL_BOMB; /* step.cpp:167 dereferences nullptr */
                                     else put_bomb_at(bi, pb_set(bomb_at(bi), 0xF00000u, (uint32_t)mvm << 20));
                                 }
@@ -653,6 +689,7 @@ struct PomStepper {
         if (!agents_done) {
             int root_idx = 0;
             int i = ouroboros ? 0 : (int)(roots & 0xF);
+            POM_NOUNROLL
             for (int n = 0; n < 4; n++) {
                 if (i == 0xF) {
                     root_idx++;
@@ -761,6 +798,7 @@ struct PomStepper {
              * if neither, loop B below cannot see a collision and collapses to one cell test per bomb. */
             int moving = 0, shared = 0;
             uint32_t occ[4] = {0, 0, 0, 0};
+            POM_NOUNROLL
             for (int k = a.sub(); k < L.bCnt; k += A::G) { /* split: each lane its own slots, combined below */
                 const int b = pb_set(bomb_at(k), 0xF000000u, 0);
                 put_bomb_at(k, b);
@@ -786,7 +824,30 @@ struct PomStepper {
                 shared = a.gor(shared) | (a.gadd(mine) != all);
                 moving = a.gor(moving);
             }
-            /* bomb loop A, step.cpp:195-227 */
+            /* bomb loop A, step.cpp:195-227.  A resting bomb's "target" is its own cell: it is blocked iff an agent item (or,
+             * never in practice, a static item) shows there; setting an idle bomb idle changes nothing, so the loop only
+             * matters when some agent that moved this tick has to be bounced back.  Split: look first. */
+            int loop_a = 1;
+            if (!moving) {
+                int bounce = 0;
+                POM_NOUNROLL
+                for (int k = a.sub(); k < L.bCnt; k += A::G) {
+                    const int b = bomb_at(k);
+                    const int bx = pb_x(b), by = pb_y(b);
+                    const int e = a.cell(by * POM_N + bx);
+                    if (pc_is_static_block(e) || pc_is_agent(e)) {
+                        const int ag = get_agent(bx, by);
+                        if (ag > -1) {
+                            const int m = (mvp >> (4 * ag)) & 0xF;
+                            const int was = (oldp >> (8 * ag)) & 0xFF;
+                            bounce |= m != POM_MOVE_IDLE && m != POM_MOVE_BOMB && (bx | (by << 4)) != was;
+                        }
+                    }
+                }
+                loop_a = a.gor(bounce);
+            }
+            if (loop_a)
+            POM_NOUNROLL
             for (int k = 0; k < L.bCnt; k++) {
                 const int b = bomb_at(k);
                 const int bx = pb_x(b), by = pb_y(b), d = pb_dir(b);
@@ -818,17 +879,20 @@ struct PomStepper {
                  * Split: first only look (does any bomb sit in a flame?); without a detonation the writes are
                  * independent and done in parallel, with one the queue is walked in order */
                 int in_flame = 0;
+                POM_NOUNROLL
                 for (int k = a.sub(); k < L.bCnt; k += A::G) {
                     const int b = bomb_at(k);
                     in_flame |= pc_is_flame(a.cell(pb_y(b) * POM_N + pb_x(b)));
                 }
                 if (!a.gor(in_flame)) {
+                    POM_NOUNROLL
                     for (int k = a.sub(); k < L.bCnt; k += A::G) {
                         const int b = bomb_at(k);
                         const int c = pb_y(b) * POM_N + pb_x(b);
                         if (pc_is_walkable(a.cell(c))) a.put_cell(c, POM_C_BOMB);
                     }
                 } else {
+                    POM_NOUNROLL
                     for (int k = 0; k < L.bCnt; k++) {
                         const int b = bomb_at(k);
                         const int c = pb_y(b) * POM_N + pb_x(b);
@@ -838,6 +902,7 @@ struct PomStepper {
                     }
                 }
             } else
+            POM_NOUNROLL
             for (int k = 0; k < L.bCnt; k++) {
                 int b = bomb_at(k);
                 if (pb_dir(b) == 0) {
@@ -873,9 +938,11 @@ struct PomStepper {
             }
             POM_STAMP(L, POM_PH_BOMB_B);
             /* TickBombs, step_utility.cpp:224-245 */
+            POM_NOUNROLL
             for (int k = a.sub(); k < L.bCnt; k += A::G) /* split */
                 put_bomb_at(k, (int)((uint32_t)bomb_at(k) - (1u << 16)));
             const int n = L.bCnt;
+            POM_NOUNROLL
             for (int k = 0; k < n && L.bCnt > 0; k++) {
                 const int c = bomb_at(0);
                 if (pb_time(c) != 0) break;
