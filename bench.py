@@ -206,7 +206,7 @@ def main() -> None:
         traffic = None  # PMC-derived HBM bytes per launch come from the committed rocprofv3 passes, for this workload only
         tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tj) and args.envs == 65536 and tpl == 1 and args.kind == "ffa" and args.dist == "random":
-            traffic = json.load(open(tj))["hbm_bytes_per_launch"]
+            traffic = json.load(open(tj))["hbm_bytes_per_step"]  # all launches of one step
         line = {
             "metric": "env_steps_per_sec", "value": total_steps / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -168,7 +168,16 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : 2)) 
     static_assert(G == 1 || (G == 4 && EPW == 16), "a quad per env needs 16 envs per wavefront");
     __shared__ uint32_t tile[LDS_ROWS * EPW];
     const int lane = threadIdx.x;
-    const int64_t tile_id = p.block0 + blockIdx.x;
+    /* XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own
+     * L2).  With fewer than 64 envs per wavefront neighbouring tiles share 128-B lines of every record row, so they are
+     * given to workgroups of the SAME XCD: the second touch of a line is an L2 hit instead of a second HBM fetch
+     * (FETCH_SIZE per launch 21.4 MB -> footprint, profiles/).  Bijective for any grid size. */
+    int64_t tile_local;
+    {
+        const int64_t b = blockIdx.x, nb = gridDim.x, q = nb / 8, r = nb % 8, x = b % 8;
+        tile_local = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
+    }
+    const int64_t tile_id = p.block0 + tile_local;
     const int64_t np = p.n_pad;
     const bool env_mode = p.mode == POM_MODE_ENV;
     /* data movement: lane -> (env el, row group sub) so that one DMA / store instruction covers 64/EPW rows */
