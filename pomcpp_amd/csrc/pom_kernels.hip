@@ -23,17 +23,19 @@
 #include "pom_step_body.h"
 
 /* ---------------------------------------------------------------------------------------------
- * LDS tile of one wavefront: 127 rows x 64 lanes x 4 B = 32,512 B  (5 wavefronts per CU)
+ * LDS tile of one wavefront, [row][EPW] dwords.  Rows 0..111 mirror the HBM record row for row (pom_packed.h), so the
+ * whole record moves with unguarded groups of 64/EPW rows; then 5 rows of bomb-destination bytes and 21 rows of
+ * explosion frames: 138 rows = 35.3 / 17.7 / 8.8 KB for 64 / 32 / 16 envs per wavefront.
  * ------------------------------------------------------------------------------------------- */
 enum {
-    ROW_BOARD = 0,    /* 61 rows: two 16-bit cells per dword            */
-    ROW_BOMBS = 61,   /* 20 rows: raw bomb words, physical queue slots  */
-    ROW_FLAMES = 81,  /* 20 rows                                        */
-    ROW_BDEST = 101,  /*  5 rows: 20 bytes, bomb destination snapshot   */
-    ROW_STACK = 106,  /* 21 rows: explosion frames                      */
-    LDS_ROWS = 127
+    ROW_BOARD = POM_REC_BOARD,    /* 61 rows: two 16-bit cells per dword            */
+    ROW_BOMBS = POM_REC_BOMBS,    /* 20 rows: raw bomb words, physical queue slots  */
+    ROW_FLAMES = POM_REC_FLAMES,  /* 20 rows                                        */
+    ROW_BDEST = POM_REC_DWORDS,   /*  5 rows: 20 bytes, bomb destination snapshot   */
+    ROW_STACK = POM_REC_DWORDS + 5, /* 21 rows: explosion frames                    */
+    LDS_ROWS = POM_REC_DWORDS + 26
 };
-
+static_assert(POM_REC_DWORDS % 4 == 0, "the record moves in groups of up to 4 rows");
 
 /*
  * EPW = envs per wavefront (64, 32 or 16), G = lanes that work on one env during the tick (pom_step_body.h):
@@ -122,48 +124,53 @@ __device__ __forceinline__ void dma_rows(const uint32_t* g, uint32_t* lds_base)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
 }
-template <int EPW, int REC0, int LDS0, int ROWS>
-__device__ __forceinline__ void load_segment(const uint32_t* col, int64_t np, uint32_t* tile, int sub)
+template <int EPW>
+__device__ __forceinline__ void load_tile(const uint32_t* col, int64_t np, uint32_t* tile, int sub)
 {
-    constexpr int G = 64 / EPW;
-    /* a rolled loop with a running pointer: fully unrolled, hipcc precomputes all 101 per-lane 64-bit
-     * addresses first (200+ VGPRs), which caps the occupancy the smaller EPW variants exist for */
-    const uint32_t* g = col + (int64_t)(REC0 + sub) * np;
-    const int64_t stride = (int64_t)G * np;
+    constexpr int GR = 64 / EPW; /* rows per instruction */
+    /* a rolled loop with a running pointer: fully unrolled, hipcc precomputes all per-lane 64-bit addresses first
+     * (200+ VGPRs) */
+    const uint32_t* g = col + (int64_t)sub * np;
+    const int64_t stride = (int64_t)GR * np;
 #pragma unroll 4
-    for (int r0 = 0; r0 < ROWS; r0 += G) {
-        if (G == 1 || r0 + sub < ROWS) dma_rows(g, tile + (LDS0 + r0) * EPW);
+    for (int r0 = 0; r0 < POM_REC_DWORDS; r0 += GR) {
+        dma_rows(g, tile + r0 * EPW);
         g += stride;
     }
 }
 template <int EPW>
-__device__ __forceinline__ void load_tile(const uint32_t* col, int64_t np, uint32_t* tile, int sub)
+__device__ __forceinline__ void store_tile(uint32_t* col, int64_t np, const uint32_t* tile, int sub, int el)
 {
-    load_segment<EPW, POM_REC_BOARD, ROW_BOARD, 61>(col, np, tile, sub);
-    load_segment<EPW, POM_REC_BOMBS, ROW_BOMBS, 20>(col, np, tile, sub);
-    load_segment<EPW, POM_REC_FLAMES, ROW_FLAMES, 20>(col, np, tile, sub);
-}
-template <int EPW, int REC0, int LDS0, int ROWS>
-__device__ __forceinline__ void store_segment(uint32_t* col, int64_t np, const uint32_t* tile, int sub, int el)
-{
-    constexpr int G = 64 / EPW;
-    uint32_t* g = col + (int64_t)(REC0 + sub) * np;
-    const int64_t stride = (int64_t)G * np;
-    const uint32_t* l = tile + (LDS0 + sub) * EPW + el;
+    constexpr int GR = 64 / EPW;
+    uint32_t* g = col + (int64_t)sub * np;
+    const int64_t stride = (int64_t)GR * np;
+    const uint32_t* l = tile + sub * EPW + el;
 #pragma unroll 8
-    for (int r0 = 0; r0 < ROWS; r0 += G) {
-        if (G == 1 || r0 + sub < ROWS) *g = l[r0 * EPW];
+    for (int r0 = 0; r0 < POM_REC_DWORDS; r0 += GR) {
+        *g = l[r0 * EPW];
         g += stride;
     }
 }
+/* the register-resident rows (timeStep, meta, agents) of one env, out of / into its tile column */
+__device__ __forceinline__ void lane_from_tile(PomLane& L, int& time_step, uint32_t& status, const uint32_t* t, int epw)
+{
+    uint32_t ag[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) ag[k] = t[(POM_REC_AGENTS + k) * epw];
+    const uint32_t m2 = t[POM_REC_META2 * epw];
+    pom_lane_load(L, t[POM_REC_META * epw], m2, ag);
+    time_step = (int)t[POM_REC_TIMESTEP * epw];
+    status = (m2 >> 8) & 0xFF;
+}
 
-/* the quad kernel needs 157 VGPRs: 3 wavefronts per SIMD without spilling (capping it at 128 for 4 costs 60 B/lane of
- * scratch and measured 12 % slower, profiles/r01_quad.txt) */
+/* occupancy target of the quad kernel.  It needs 107 VGPRs since its tile mirrors the whole record (no per-row global
+ * addresses live across the tick), so 4 wavefronts per SIMD fit anyway; the target only forbids the compiler to squeeze
+ * further (an earlier 157-VGPR version capped at 128 spilled 60 B/lane and ran 12 % slower, profiles/r01_quad.txt) */
 #ifndef POM_QUAD_WAVES
 #define POM_QUAD_WAVES 3
 #endif
 template <int EPW, int G>
-__global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : 2)) void pom_step_kernel(StepParams p)
+__global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW == 32 ? 2 : 1)) void pom_step_kernel(StepParams p)
 {
     static_assert(G == 1 || (G == 4 && EPW == 16), "a quad per env needs 16 envs per wavefront");
     __shared__ uint32_t tile[LDS_ROWS * EPW];
@@ -193,40 +200,21 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : 2)) 
     const bool runs = G == 1 ? sub == 0 : true;         /* the lanes that execute env e's tick */
     const bool valid = runs && e < p.n;
     uint32_t* t = tile + ec;
-    uint32_t* col = p.state + e;
-    const uint32_t* scol = p.snap + e;
 
 #if defined(POM_DIAG)
     const long long t_begin = (long long)clock64();
 #endif
-    uint32_t status = (col[POM_REC_META2 * np] >> 8) & 0xFF;
     long long c_steps = 0, c_episodes = 0, c_resets = 0, c_ub = 0;
 
-    /* a finished env restarts from its snapshot: pick the source column per lane, one pass */
-    bool reload = e < p.n && env_mode && p.auto_reset && (status & POM_ST_DONE);
-    const uint32_t* src = reload ? scol : col;
-    {
-        const bool reload_d = G == 1 ? reload
-                                     : (e_d < p.n && env_mode && p.auto_reset && ((col_d[POM_REC_META2 * np] >> 8) & POM_ST_DONE));
-        load_tile<EPW>(reload_d ? scol_d : col_d, np, tile, sub);
-    }
-    int time_step = 0;
-    uint32_t ag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    PomLane L;
-    {
-        uint32_t m = 0, m2 = 0;
-        if (runs) {
-            time_step = (int)src[POM_REC_TIMESTEP * np];
-#pragma unroll
-            for (int k = 0; k < 8; k++) ag[k] = src[(POM_REC_AGENTS + k) * np];
-            m = src[POM_REC_META * np];
-            m2 = src[POM_REC_META2 * np];
-        }
-        pom_lane_load(L, m, m2, ag);
-        status = (m2 >> 8) & 0xFF;
-    }
+    /* a finished env restarts from its snapshot: pick the source column per lane, one pass over the record */
+    bool reload_d = e_d < p.n && env_mode && p.auto_reset && ((col_d[POM_REC_META2 * np] >> 8) & POM_ST_DONE);
+    load_tile<EPW>(reload_d ? scol_d : col_d, np, tile, sub);
+    c_resets += __popcll(__ballot(reload_d && sub == 0));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the DMA rows have landed (one wavefront per workgroup: no barrier) */
-    c_resets += __popcll(__ballot(reload && owner));
+    PomLane L;
+    int time_step = 0;
+    uint32_t status = 0;
+    lane_from_tile(L, time_step, status, t, EPW);
 
     LdsEnv<EPW, G> acc{t, member};
     PomStepper<LdsEnv<EPW, G>> stepper(acc, L);
@@ -240,19 +228,12 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : 2)) 
         if (tk > 0) {
             /* the lanes that move env el's rows need the verdict of the lane that owns env el */
             const int done_d = __shfl((int)(status & POM_ST_DONE), G == 1 ? el : 4 * el);
-            const bool reload_d = e_d < p.n && env_mode && p.auto_reset && done_d;
-            reload = e < p.n && env_mode && p.auto_reset && (status & POM_ST_DONE) && runs;
-            if (reload_d) load_tile<EPW>(scol_d, np, tile, sub); /* EXEC-masked: only the restarting envs' columns are overwritten */
+            reload_d = e_d < p.n && env_mode && p.auto_reset && done_d;
+            const bool reload = e < p.n && env_mode && p.auto_reset && (status & POM_ST_DONE) && runs;
             if (__any(reload_d)) {
-                if (reload) {
-                    time_step = (int)scol[POM_REC_TIMESTEP * np];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) ag[k] = scol[(POM_REC_AGENTS + k) * np];
-                    const uint32_t m2 = scol[POM_REC_META2 * np];
-                    pom_lane_load(L, scol[POM_REC_META * np], m2, ag);
-                    status = (m2 >> 8) & 0xFF;
-                }
+                if (reload_d) load_tile<EPW>(scol_d, np, tile, sub); /* EXEC-masked: only the restarting envs' columns are overwritten */
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (reload) lane_from_tile(L, time_step, status, t, EPW);
             }
             c_resets += __popcll(__ballot(reload && owner));
         }
@@ -283,20 +264,18 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : 2)) 
         POM_STAMP(L, POM_PH_EPILOGUE);
     }
 
-    /* write back: LDS rows by all lanes, the register-resident rows by the owner */
-    store_segment<EPW, POM_REC_BOARD, ROW_BOARD, 61>(col_d, np, tile, sub, el);
-    store_segment<EPW, POM_REC_BOMBS, ROW_BOMBS, 20>(col_d, np, tile, sub, el);
-    store_segment<EPW, POM_REC_FLAMES, ROW_FLAMES, 20>(col_d, np, tile, sub, el);
+    /* write back: the owner puts the register-resident rows into the tile, then the whole record leaves in row groups */
     if (owner) {
-        col[POM_REC_TIMESTEP * np] = (uint32_t)time_step;
-        col[POM_REC_META * np] = pom_lane_meta(L);
-        col[POM_REC_META2 * np] = pom_lane_meta2(L, status);
+        t[POM_REC_TIMESTEP * EPW] = (uint32_t)time_step;
+        t[POM_REC_META * EPW] = pom_lane_meta(L);
+        t[POM_REC_META2 * EPW] = pom_lane_meta2(L, status);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            col[(POM_REC_AGENTS + 2 * i) * np] = (uint32_t)L.a0[i];
-            col[(POM_REC_AGENTS + 2 * i + 1) * np] = (uint32_t)L.a1[i];
+            t[(POM_REC_AGENTS + 2 * i) * EPW] = (uint32_t)L.a0[i];
+            t[(POM_REC_AGENTS + 2 * i + 1) * EPW] = (uint32_t)L.a1[i];
         }
     }
+    store_tile<EPW>(col_d, np, tile, sub, el);
 
 #if defined(POM_DIAG)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
