@@ -25,7 +25,7 @@
 
 enum { POM_DIST_HARMLESS = 0, POM_DIST_RANDOM = 1, POM_DIST_STRESS = 2 };
 
-POM_HD uint64_t pom_splitmix64(uint64_t z)
+POM_HD uint64_t pom_splitmix64(uint64_t z) /* host-side seeding helper, not on the per-tick path */
 {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -33,10 +33,24 @@ POM_HD uint64_t pom_splitmix64(uint64_t z)
     return z ^ (z >> 31);
 }
 
+/* murmur3's 32-bit finaliser: 2 multiplies, 3 xor-shifts — 32-bit ops only, which is what a gfx950 VALU lane has */
+POM_HD uint32_t pom_fmix32(uint32_t h)
+{
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
 /* one 64-bit draw per (seed, env, tick); 16 bits per agent */
 POM_HD uint64_t pom_rng_draw(uint64_t seed, uint32_t env, uint32_t tick)
 {
-    return pom_splitmix64(pom_splitmix64(seed ^ ((uint64_t)tick << 32 | env)) + seed);
+    const uint32_t k = (uint32_t)seed ^ (env * 0x9E3779B1u) ^ (tick * 0x7FEB352Du + (uint32_t)(seed >> 32));
+    const uint32_t lo = pom_fmix32(k);
+    const uint32_t hi = pom_fmix32(lo ^ 0x68E31DA4u ^ env);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
 POM_HD int32_t pom_rng_pick(uint32_t r16, int dist)

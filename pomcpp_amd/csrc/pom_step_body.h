@@ -549,38 +549,51 @@ struct PomStepper {
             dy[i] = py[i] + mv_dy(mv[i]);
             oldp |= (uint32_t)(px[i] | (py[i] << 4)) << (8 * i);
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-#pragma unroll
-            for (int j = i; j < 4; j++) {
-                if (dx[i] == px[j] && dy[i] == py[j] && dx[j] == px[i] && dy[j] == py[i]) {
-                    dx[i] = px[i]; dy[i] = py[i];
-                    dx[j] = px[j]; dy[j] = py[j];
-                }
-            }
-        }
-        /* ResolveDependencies (step_utility.cpp:172-205); dependency / roots as nibbles, 0xF = -1 */
-        uint32_t dep = 0xFFFF, roots = 0xFFFF;
-        int nroots = 0;
+        /* Does any agent's destination touch another agent's cell (dead agents included: SURVEY Q9)?  If not — the usual
+         * case, the agents are far apart — FixSwitchMove changes nothing and ResolveDependencies makes everyone a root in
+         * index order; the literal pairwise logic below only runs for the envs that need it. */
+        uint32_t dep = 0xFFFF, roots = 0x3210;
+        int nroots = 4;
         int deadmask = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) deadmask |= ag_dead(L.a0[i]) << i;
+        int contact = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int is_root = 1;
-            if (!((deadmask >> i) & 1)) {
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (j == i) continue;
-                    if (is_root && !((deadmask >> j) & 1) && dx[i] == px[j] && dy[i] == py[j]) {
-                        dep = (dep & ~(0xFu << (4 * j))) | ((uint32_t)i << (4 * j));
-                        is_root = 0;
+            for (int j = 0; j < 4; j++)
+                if (i != j) contact |= (dx[i] == px[j]) & (dy[i] == py[j]);
+        if (contact) {
+            roots = 0xFFFF;
+            nroots = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+#pragma unroll
+                for (int j = i; j < 4; j++) {
+                    if (dx[i] == px[j] && dy[i] == py[j] && dx[j] == px[i] && dy[j] == py[i]) {
+                        dx[i] = px[i]; dy[i] = py[i];
+                        dx[j] = px[j]; dy[j] = py[j];
                     }
                 }
             }
-            if (is_root) {
-                roots = (roots & ~(0xFu << (4 * nroots))) | ((uint32_t)i << (4 * nroots));
-                nroots++;
+            /* ResolveDependencies (step_utility.cpp:172-205); dependency / roots as nibbles, 0xF = -1 */
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int is_root = 1;
+                if (!((deadmask >> i) & 1)) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (j == i) continue;
+                        if (is_root && !((deadmask >> j) & 1) && dx[i] == px[j] && dy[i] == py[j]) {
+                            dep = (dep & ~(0xFu << (4 * j))) | ((uint32_t)i << (4 * j));
+                            is_root = 0;
+                        }
+                    }
+                }
+                if (is_root) {
+                    roots = (roots & ~(0xFu << (4 * nroots))) | ((uint32_t)i << (4 * nroots));
+                    nroots++;
+                }
             }
         }
         const int ouroboros = nroots == 0;
@@ -796,7 +809,7 @@ struct PomStepper {
             /* ResetBombFlags + FillBombDestPos, step_utility.cpp:331-337,146-152.  The same pass notes whether any
              * bomb of this env is moving and whether two bombs share a cell (121-bit occupancy in 4 registers):
              * if neither, loop B below cannot see a collision and collapses to one cell test per bomb. */
-            int moving = 0, shared = 0;
+            int moving = 0, shared = 0, bounce = 0;
             uint32_t occ[4] = {0, 0, 0, 0};
             POM_NOUNROLL
             for (int k = a.sub(); k < L.bCnt; k += A::G) { /* split: each lane its own slots, combined below */
@@ -813,7 +826,21 @@ struct PomStepper {
                 occ[1] |= w == 1 ? m : 0u;
                 occ[2] |= w == 2 ? m : 0u;
                 occ[3] |= w >= 3 ? m : 0u;
+                /* loop A, looked at in the same pass (only meaningful if nothing moves, see below): a resting bomb under an
+                 * agent that walked onto it this tick means a bounce-back */
+                if (idx < POM_CELLS) {
+                    const int e = a.cell(idx);
+                    if (pc_is_static_block(e) || pc_is_agent(e)) {
+                        const int ag = get_agent(pb_x(b), pb_y(b));
+                        if (ag > -1) {
+                            const int m2 = (mvp >> (4 * ag)) & 0xF;
+                            const int was = (oldp >> (8 * ag)) & 0xFF;
+                            bounce |= m2 != POM_MOVE_IDLE && m2 != POM_MOVE_BOMB && pb_pos(b) != was;
+                        }
+                    }
+                }
             }
+            bounce = a.gor(bounce);
             if (A::G > 1) { /* two lanes' bombs share a cell iff the lanes' cell sets overlap: |union| < sum of |set| */
                 int mine = 0, all = 0;
 #pragma unroll
@@ -827,25 +854,7 @@ struct PomStepper {
             /* bomb loop A, step.cpp:195-227.  A resting bomb's "target" is its own cell: it is blocked iff an agent item (or,
              * never in practice, a static item) shows there; setting an idle bomb idle changes nothing, so the loop only
              * matters when some agent that moved this tick has to be bounced back.  Split: look first. */
-            int loop_a = 1;
-            if (!moving) {
-                int bounce = 0;
-                POM_NOUNROLL
-                for (int k = a.sub(); k < L.bCnt; k += A::G) {
-                    const int b = bomb_at(k);
-                    const int bx = pb_x(b), by = pb_y(b);
-                    const int e = a.cell(by * POM_N + bx);
-                    if (pc_is_static_block(e) || pc_is_agent(e)) {
-                        const int ag = get_agent(bx, by);
-                        if (ag > -1) {
-                            const int m = (mvp >> (4 * ag)) & 0xF;
-                            const int was = (oldp >> (8 * ag)) & 0xFF;
-                            bounce |= m != POM_MOVE_IDLE && m != POM_MOVE_BOMB && (bx | (by << 4)) != was;
-                        }
-                    }
-                }
-                loop_a = a.gor(bounce);
-            }
+            const int loop_a = moving | bounce;
             if (loop_a)
             POM_NOUNROLL
             for (int k = 0; k < L.bCnt; k++) {
