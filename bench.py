@@ -165,6 +165,28 @@ def main() -> None:
         torch.cuda.synchronize()
 
     tpl = args.ticks_per_launch
+    tuned = None
+    if args.streams == 0:
+        # Untimed: how many sub-batches per step?  More parts overlap more load/store with compute, but ROCm maps all streams
+        # of the process onto 4 hardware queues and parts that share a queue serialize (profiles/r01_streams.txt) — how many
+        # are free depends on the process (torch, RCCL), so measure instead of guessing.  Results do not depend on the choice.
+        tuned = {}
+        for k in (2, 3, 1):
+            env.set_streams(k)
+            for _ in range(15):
+                env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)
+            env.sync()
+            t_a = time.perf_counter()
+            for _ in range(60):
+                env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)
+            env.sync()
+            tuned[k] = (time.perf_counter() - t_a) / 60 * 1e3
+        best = min(tuned, key=tuned.get)
+        if world > 1:  # every rank must run the same shape: take the vote of the slowest rank's best
+            votes = torch.tensor([tuned[1], tuned[2], tuned[3]], dtype=torch.float64, device=device)
+            dist.all_reduce(votes, op=dist.ReduceOp.MAX)
+            best = int(torch.argmin(votes).item()) + 1
+        env.set_streams(best)
     for _ in range(args.warmup):
         env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)
     env.counters_into(counters.data_ptr())
@@ -217,6 +239,7 @@ def main() -> None:
                             f"(RandomAgent distribution), auto-reset, {args.max_steps}-tick cap",
                 "envs_per_gpu": args.envs, "global_envs": plan["global_envs"], "ticks_per_launch": tpl,
                 "envs_per_wave": epw, "lanes_per_env": lpe, "launches_per_step": parts,
+                "launches_per_step_tuning_ms": tuned,
                 "parallelism": f"env-shard x{world}", "episodes_finished": int(counters[1].item()),
             },
             "roofline": {

@@ -103,6 +103,9 @@ int pom_batch_sync(PomBatch* h);
 /* order everything stepped so far before whatever is queued next on the handle's stream, without blocking the host
  * (steps run on internal sub-streams; every other call of this API does this implicitly) */
 int pom_batch_flush(PomBatch* h);
+/* change the number of sub-batches a step is issued as (1..8, see PomBatchOptions.streams); results do not depend on it,
+ * the best value depends on how many hardware queues the process has free — a caller may try a few and keep the fastest */
+int pom_batch_set_streams(PomBatch* h, int32_t streams);
 /* per-launch timing with HIP events on the launch streams: enable, step (at most 256 launches are kept), read the mean */
 int pom_batch_profile(PomBatch* h, int enable);
 int pom_batch_profile_read(PomBatch* h, double* mean_ms, int64_t* launches);

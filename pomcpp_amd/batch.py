@@ -82,6 +82,7 @@ def load_library() -> C.CDLL:
     lib.pom_batch_reset_counters.argtypes = [P]
     lib.pom_batch_sync.argtypes = [P]
     lib.pom_batch_flush.argtypes = [P]
+    lib.pom_batch_set_streams.argtypes = [P, I32]
     lib.pom_batch_profile.argtypes = [P, C.c_int]
     lib.pom_batch_profile_read.argtypes = [P, C.POINTER(C.c_double), C.POINTER(I64)]
     lib.pom_batch_launch_shape.argtypes = [P, C.POINTER(I32), C.POINTER(I32), C.POINTER(I32)]
@@ -208,6 +209,9 @@ class BatchEnvironment:
     def flush(self) -> None:
         """Make the handle's stream wait for all steps issued so far (host does not block)."""
         _check(self._lib, self._lib.pom_batch_flush(self._h))
+
+    def set_streams(self, streams: int) -> None:
+        _check(self._lib, self._lib.pom_batch_set_streams(self._h, streams))
 
     def profile(self, enable: bool) -> None:
         _check(self._lib, self._lib.pom_batch_profile(self._h, int(enable)))

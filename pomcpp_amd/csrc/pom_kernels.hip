@@ -422,6 +422,7 @@ struct PomBatch {
 
 static int fork_parts(PomBatch* h);
 static int join_parts(PomBatch* h);
+static int ensure_sub_streams(PomBatch* h, int parts);
 
 extern "C" {
 
@@ -571,17 +572,9 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
         }
         h->own_stream = true;
     }
-    if (h->parts > 1) {
-        hipError_t e_ = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
-        for (int k = 0; k < h->parts && e_ == hipSuccess; k++) {
-            e_ = hipStreamCreateWithFlags(&h->sub[k], hipStreamNonBlocking);
-            if (e_ == hipSuccess) e_ = hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming);
-        }
-        if (e_ != hipSuccess) {
-            set_err("sub-stream setup", e_);
-            pom_batch_destroy(h);
-            return POM_E_HIP;
-        }
+    if (ensure_sub_streams(h, h->parts) != POM_OK) {
+        pom_batch_destroy(h);
+        return POM_E_HIP;
     }
     const size_t rec_bytes = (size_t)POM_REC_DWORDS * 4 * (size_t)h->n_pad;
     ALLOC(h->state, rec_bytes);
@@ -675,6 +668,17 @@ int pom_batch_snapshot(PomBatch* h)
     if (int jr = join_parts(h)) return jr;
     pom_snapshot_kernel<<<dim3((unsigned)((h->n_pad + 255) / 256)), dim3(256), 0, h->stream>>>(h->state, h->snap, h->n_pad);
     HIPCHK(hipGetLastError());
+    return POM_OK;
+}
+
+static int ensure_sub_streams(PomBatch* h, int parts)
+{
+    if (parts <= 1) return POM_OK;
+    if (!h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int k = 0; k < parts; k++) {
+        if (!h->sub[k]) HIPCHK(hipStreamCreateWithFlags(&h->sub[k], hipStreamNonBlocking));
+        if (!h->ev_join[k]) HIPCHK(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
+    }
     return POM_OK;
 }
 
@@ -878,6 +882,18 @@ int pom_diag_read(PomBatch* h, long long out[POM_PH_N])
     return POM_OK;
 }
 #endif
+
+int pom_batch_set_streams(PomBatch* h, int32_t streams)
+{
+    if (!h || streams < 1 || streams > PomBatch::MAX_PARTS) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
+    const int64_t tiles = h->n_pad / h->epw;
+    const int want = (int64_t)streams > tiles ? (int)tiles : streams;
+    if (int er = ensure_sub_streams(h, want)) return er;
+    h->parts = want;
+    return POM_OK;
+}
 
 int pom_batch_flush(PomBatch* h)
 {

@@ -222,7 +222,9 @@ def test_split_steps_over_streams_give_identical_results(hip_lib, oracle, stream
         env.make_game(mid)             # re-upload: snapshot becomes `mid`, but nothing restarts in the next 30 ticks unless done
         env.make_game(start)           # back to the original snapshot ...
         env.set_tick(0)
-        env.step_random(seed, DIST_RANDOM, ticks=ticks)   # ... and replay the whole run
+        env.step_random(seed, DIST_RANDOM, ticks=ticks // 3)   # ... and replay the whole run,
+        env.set_streams(1 + streams % 3)                       # changing the split on the way
+        env.step_random(seed, DIST_RANDOM, ticks=ticks - ticks // 3)
         assert _digest(env.get_state()) == _digest(want)
         assert env.counters()[CNT_STEPS] == n * (ticks + ticks // 2)
     rng = np.random.default_rng(streams)
