@@ -78,3 +78,55 @@ int ref_resolve_dependencies(void* s, const int* xy, int* dependency, int* chain
 }
 
 }
+
+/* ---- SimpleAgent: the reference's own policy object behind a C window ------------------------------
+ * src/agents/simple_agent.cpp + src/bboard/strategy.cpp compiled unmodified.  The agent draws from a std::mt19937_64
+ * seeded by random_device (simple_agent.cpp:17-22); for a reproducible comparison the shim reseeds that public member
+ * and, before each act(), peeks the value the next intDist(rng) call WOULD return on a copy of the generator — act() makes
+ * at most one draw — so the restatement can be given the identical draw as an input. */
+#include "agents.hpp"
+
+extern "C" {
+
+void* ref_simple_new(int id, unsigned long long seed)
+{
+    agents::SimpleAgent* a = new agents::SimpleAgent();
+    a->id = id;
+    a->rng = std::mt19937_64(seed);
+    return a;
+}
+void ref_simple_delete(void* p) { delete static_cast<agents::SimpleAgent*>(p); }
+int ref_simple_peek_draw(void* p)
+{
+    agents::SimpleAgent* a = static_cast<agents::SimpleAgent*>(p);
+    std::mt19937_64 r2 = a->rng;
+    std::uniform_int_distribution<int> d2 = a->intDist;
+    return d2(r2);
+}
+int ref_simple_act(void* p, const void* state) { return int(static_cast<agents::SimpleAgent*>(p)->act(static_cast<const State*>(state))); }
+/* agent memory that survives between act() calls: recentPositions (4 x {x,y}, index, count), moveQueue (4 moves, index, count) */
+void ref_simple_memory(void* p, int* out16)
+{
+    agents::SimpleAgent* a = static_cast<agents::SimpleAgent*>(p);
+    for (int i = 0; i < 4; i++) {
+        out16[2 * i] = a->recentPositions.queue[i].x;
+        out16[2 * i + 1] = a->recentPositions.queue[i].y;
+    }
+    out16[8] = a->recentPositions.index;
+    out16[9] = a->recentPositions.count;
+    for (int i = 0; i < 4; i++) out16[10 + i] = int(a->moveQueue.queue[i]);
+    out16[14] = a->moveQueue.index;
+    out16[15] = a->moveQueue.count;
+}
+void ref_simple_set_memory(void* p, const int* in16)
+{
+    agents::SimpleAgent* a = static_cast<agents::SimpleAgent*>(p);
+    for (int i = 0; i < 4; i++) a->recentPositions.queue[i] = {in16[2 * i], in16[2 * i + 1]};
+    a->recentPositions.index = in16[8];
+    a->recentPositions.count = in16[9];
+    for (int i = 0; i < 4; i++) a->moveQueue.queue[i] = Move(in16[10 + i]);
+    a->moveQueue.index = in16[14];
+    a->moveQueue.count = in16[15];
+}
+
+}
