@@ -87,7 +87,20 @@ int pom_batch_step_device(PomBatch* h, const int32_t* moves_dev);
 /* `ticks` ticks with the pom_rng.h move stream (seed, env_offset+env, tick); ticks_per_launch >= 1 keeps
  * the env tile resident in LDS for that many ticks per kernel launch (1 = state round-trips HBM each tick) */
 int pom_batch_step_random(PomBatch* h, uint64_t seed, int32_t dist, int32_t ticks, int32_t ticks_per_launch);
-/* the tick counter that keys the synthetic stream (advanced by step_random) */
+/* SimpleAgent policy on the device (agents::SimpleAgent, include/agents.hpp:55-76, src/agents/simple_agent.cpp):
+ * pom_batch_policy_simple asks all four agents of every env for a Move as Environment::Step does (environment.cpp:139-146:
+ * live agents only, a dead agent's entry is IDLE) into the handle's move buffer and updates the agents' memory
+ * (recentPositions, moveQueue); pom_batch_step_policy ticks with those moves; pom_batch_step_simple does both `ticks` times.
+ * The one random draw an act() may make comes from the pom_rng.h stream keyed (seed, env_offset+env, tick), uniform 0..4.
+ * An env that the next step will restart is read from its snapshot and gets fresh agents; pom_batch_upload resets the agents
+ * of the uploaded envs.  moves_out_host (nullable): int32[n_envs][4], synchronises. */
+int pom_batch_policy_simple(PomBatch* h, uint64_t seed, int32_t* moves_out_host);
+int pom_batch_step_policy(PomBatch* h);
+int pom_batch_step_simple(PomBatch* h, uint64_t seed, int32_t ticks);
+/* agent memory of envs [first, first+count): 16 int32 per agent, 4 agents per env: recentPositions {x,y}x4, index, count,
+ * moveQueue x4, index, count (the members of SimpleAgent that survive between act() calls) */
+int pom_batch_policy_memory(PomBatch* h, int64_t first, int64_t count, int32_t* out16);
+/* the tick counter that keys the synthetic stream (advanced by step_random / step_policy / step_simple) */
 int pom_batch_set_tick(PomBatch* h, int64_t tick);
 
 /* per-env results for [first, first+count): any output pointer may be NULL.

@@ -265,6 +265,21 @@ int32_t pom_oracle_simple_act(const void* state, int id, PomSimpleMem* mem, int 
     return mv;
 }
 
+/* one round of act() for n envs: what pom_batch_policy_simple computes.  done[e] != 0 marks a finished env (all IDLE). */
+void pom_oracle_simple_policy(const void* states, PomSimpleMem* mems, int n, uint64_t seed, int first_env, int tick,
+                              const int32_t* done, int32_t* moves_out)
+{
+    const PomState* s = (const PomState*)states;
+    for (int e = 0; e < n; e++) {
+        const uint64_t r = pom_rng_draw(seed, (uint32_t)(first_env + e), (uint32_t)tick);
+        for (int i = 0; i < 4; i++) {
+            const int draw = (int)((((uint32_t)(r >> (16 * i)) & 0xFFFFu) * 5u) >> 16);
+            const int skip = (done && done[e]) || s[e].agents[i].dead;
+            moves_out[4 * e + i] = skip ? POM_MOVE_IDLE : pom_oracle_simple_act(&s[e], i, &mems[4 * e + i], draw);
+        }
+    }
+}
+
 int64_t pom_oracle_run_simple(void* states, const void* initial, PomSimpleMem* mems, int n, int ticks, uint64_t seed,
                               int first_env, int tick0, int max_steps)
 {

@@ -24,6 +24,10 @@ typedef struct PomSimpleMem {
  * intDist(rng) call returns (uniform 0..4).  Returns the Move and updates the memory. */
 int32_t pom_oracle_simple_act(const void* state, int id, PomSimpleMem* mem, int draw);
 
+/* one round of act() for n envs (what pom_batch_policy_simple computes); done[e] != 0 marks a finished env (all IDLE) */
+void pom_oracle_simple_policy(const void* states, PomSimpleMem* mems, int n, uint64_t seed, int first_env, int tick,
+                              const int32_t* done, int32_t* moves_out);
+
 /* Environment::Step with four SimpleAgents for n envs (environment.cpp:139-169): act for the alive agents (a dead agent's
  * Move entry is IDLE), then the tick; draws from the pom_rng.h stream.  mems: n x 4.  Returns env-steps executed. */
 int64_t pom_oracle_run_simple(void* states, const void* initial, PomSimpleMem* mems, int n, int ticks, uint64_t seed,

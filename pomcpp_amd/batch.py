@@ -76,6 +76,10 @@ def load_library() -> C.CDLL:
     lib.pom_batch_step_device.argtypes = [P, VP]
     lib.pom_batch_step_random.argtypes = [P, U64, I32, I32, I32]
     lib.pom_batch_set_tick.argtypes = [P, I64]
+    lib.pom_batch_policy_simple.argtypes = [P, U64, VP]
+    lib.pom_batch_step_policy.argtypes = [P]
+    lib.pom_batch_step_simple.argtypes = [P, U64, I32]
+    lib.pom_batch_policy_memory.argtypes = [P, I64, I64, VP]
     lib.pom_batch_status.argtypes = [P, I64, I64, VP, VP, VP, VP, VP, VP]
     lib.pom_batch_counters.argtypes = [P, VP]
     lib.pom_batch_counters_device.argtypes = [P, VP]
@@ -168,6 +172,25 @@ class BatchEnvironment:
 
     def step_random(self, seed: int, dist: int = DIST_RANDOM, ticks: int = 1, ticks_per_launch: int = 1) -> None:
         _check(self._lib, self._lib.pom_batch_step_random(self._h, seed, dist, ticks, ticks_per_launch))
+
+    # ---- SimpleAgent policy on the device (agents::SimpleAgent) -------------------------------------
+    def policy_simple(self, seed: int, want_moves: bool = False):
+        """act() of all four agents of every env into the internal move buffer; optionally returns int32[n,4]."""
+        out = np.zeros((self.n, 4), dtype=np.int32) if want_moves else None
+        _check(self._lib, self._lib.pom_batch_policy_simple(self._h, seed, out.ctypes.data if want_moves else None))
+        return out
+
+    def step_policy(self) -> None:
+        _check(self._lib, self._lib.pom_batch_step_policy(self._h))
+
+    def step_simple(self, seed: int, ticks: int = 1) -> None:
+        _check(self._lib, self._lib.pom_batch_step_simple(self._h, seed, ticks))
+
+    def policy_memory(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        count = self.n - first if count is None else count
+        out = np.zeros((count, 4, 16), dtype=np.int32)
+        _check(self._lib, self._lib.pom_batch_policy_memory(self._h, first, count, out.ctypes.data))
+        return out
 
     def set_tick(self, tick: int) -> None:
         _check(self._lib, self._lib.pom_batch_set_tick(self._h, tick))

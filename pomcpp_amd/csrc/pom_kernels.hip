@@ -20,6 +20,7 @@
 
 #include "pom_batch.h"
 #include "pom_packed.h"
+#include "pom_policy_body.h"
 #include "pom_step_body.h"
 
 /* ---------------------------------------------------------------------------------------------
@@ -292,6 +293,104 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW 
     }
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * SimpleAgent policy (pom_policy_body.h): one lane per AGENT, the quad 4e..4e+3 = the four agents of env e,
+ * 16 envs per wavefront.  The wavefront DMAs record rows 0..91 (board, meta, agents, bombs) of its 16 envs into a shared
+ * tile; each lane additionally owns a column of a [61][64] reachability map (distance:8 | predecessor:8 per cell, two
+ * cells per dword) and of a [31][64] BFS queue (one byte per entry) — 29.5 KB per wavefront.  Output: Move[4] per env into
+ * the handle's move buffer, agent memory (2 dwords per agent) updated in place.  A finished env that the next step will
+ * restart is read from its snapshot column and gets fresh (zero) agent memory, so policy and tick see the same game.
+ * ------------------------------------------------------------------------------------------- */
+enum { POL_ROWS = 92, POL_RM_ROWS = 61, POL_Q_ROWS = 31 };
+
+struct PolicyStore {
+    const uint32_t* t; /* &tile[env_in_wave], row stride 16 dwords */
+    uint32_t* rmcol;   /* &rmap[lane], row stride 64 dwords */
+    uint32_t* qcol;    /* &queue[lane], row stride 64 dwords */
+    __device__ int cell(int c) const { return reinterpret_cast<const uint16_t*>(t)[(c >> 1) * 32 + (c & 1)]; }
+    __device__ int bomb(int s) const { return (int)t[(POM_REC_BOMBS + s) * 16]; }
+    __device__ int rm(int c) const { return reinterpret_cast<const uint16_t*>(rmcol)[(c >> 1) * 128 + (c & 1)]; }
+    __device__ void set_rm(int c, int v) { reinterpret_cast<uint16_t*>(rmcol)[(c >> 1) * 128 + (c & 1)] = (uint16_t)v; }
+    __device__ void clear_rm()
+    {
+#pragma unroll
+        for (int k = 0; k < POL_RM_ROWS; k++) rmcol[k * 64] = 0;
+    }
+    __device__ int qe(int i) const { return reinterpret_cast<const uint8_t*>(qcol)[(i >> 2) * 256 + (i & 3)]; }
+    __device__ void set_qe(int i, int c) { reinterpret_cast<uint8_t*>(qcol)[(i >> 2) * 256 + (i & 3)] = (uint8_t)c; }
+};
+
+struct PolicyParams {
+    const uint32_t* state;
+    const uint32_t* snap;
+    uint32_t* agent_mem; /* [2][4 * n_pad] */
+    int32_t* moves;      /* [n_pad][4] */
+    int64_t n, n_pad, env_offset, block0;
+    uint64_t seed;
+    uint32_t tick;
+    int32_t mode, auto_reset;
+};
+
+__global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
+{
+    __shared__ uint32_t tile[POL_ROWS * 16];
+    __shared__ uint32_t rmap[POL_RM_ROWS * 64];
+    __shared__ uint32_t queue[POL_Q_ROWS * 64];
+    const int lane = threadIdx.x;
+    const int64_t np = p.n_pad;
+    int64_t tile_local;
+    {
+        const int64_t b = blockIdx.x, nb = gridDim.x, q = nb / 8, r = nb % 8, x = b % 8;
+        tile_local = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
+    }
+    const int64_t tile_id = p.block0 + tile_local;
+    const bool env_mode = p.mode == POM_MODE_ENV;
+    /* data movement: lane -> (env lane%16, row group lane/16) */
+    const int el = lane & 15, sub = lane >> 4;
+    const int64_t e_d = tile_id * 16 + el;
+    const bool restart_d = e_d < p.n && env_mode && p.auto_reset && ((p.state[POM_REC_META2 * np + e_d] >> 8) & POM_ST_DONE);
+    {
+        const uint32_t* g = (restart_d ? p.snap : p.state) + e_d + (int64_t)sub * np;
+#pragma unroll 4
+        for (int r0 = 0; r0 < POL_ROWS; r0 += 4) {
+            dma_rows(g, tile + r0 * 16);
+            g += 4 * np;
+        }
+    }
+    /* the policy: lane -> (env lane/4, agent lane%4) */
+    const int ec = lane >> 2, id = lane & 3;
+    const int64_t e = tile_id * 16 + ec;
+    const int64_t slot = e * 4 + id; /* = tile_id * 64 + lane */
+    uint32_t m0 = p.agent_mem[slot], m1 = p.agent_mem[4 * np + slot];
+    const bool restart = __shfl((int)restart_d, ec) != 0;
+    if (restart) m0 = m1 = 0; /* a new game gets fresh agents */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t* t = tile + ec;
+    PomPolicyEnv E;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        E.a0[i] = (int)t[(POM_REC_AGENTS + 2 * i) * 16];
+        E.a1[i] = (int)t[(POM_REC_AGENTS + 2 * i + 1) * 16];
+    }
+    const uint32_t meta = t[POM_REC_META * 16], meta2 = t[POM_REC_META2 * 16];
+    E.bIdx = (int)((meta >> 8) & 0xFF);
+    E.bCnt = (int)((meta >> 16) & 0xFF);
+    const bool frozen = env_mode && ((meta2 >> 8) & POM_ST_DONE); /* finished and not restarted: Environment::Step returns */
+    int mv = POM_MOVE_IDLE;
+    if (e < p.n && !frozen && !ag_dead(sel4(id, E.a0))) { /* act() is only asked of live agents, environment.cpp:139-146 */
+        PolicyStore st{t, rmap + lane, queue + lane};
+        PomSimplePolicy<PolicyStore> pol(st, E, id, m0, m1);
+        const uint64_t r = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick);
+        const int draw = (int)((((uint32_t)(r >> (16 * id)) & 0xFFFFu) * 5u) >> 16);
+        mv = pol.act(draw);
+        m0 = pol.m0;
+        m1 = pol.m1;
+    }
+    p.moves[slot] = mv;
+    p.agent_mem[slot] = m0;
+    p.agent_mem[4 * np + slot] = m1;
+}
+
 /* ---- boundary kernels ----------------------------------------------------------------------- */
 __global__ void pom_pack_kernel(const int32_t* __restrict__ aos, int64_t first, int64_t count, uint32_t* state, uint32_t* snap,
                                 int64_t np, int* first_bad)
@@ -396,6 +495,7 @@ struct PomBatch {
     uint32_t* state = nullptr;
     uint32_t* snap = nullptr;
     int32_t* moves_dev = nullptr;   /* n_pad x 4 */
+    uint32_t* agent_mem = nullptr;  /* SimpleAgent memory, [2][4 * n_pad], allocated on first use */
     int32_t* staging = nullptr;     /* staging_envs x 251 dwords (AoS), also status scratch */
     int64_t staging_envs = 0;
     int64_t* wave_counters = nullptr;
@@ -452,6 +552,7 @@ int pom_batch_destroy(PomBatch* h)
     (void)hipFree(h->state);
     (void)hipFree(h->snap);
     (void)hipFree(h->moves_dev);
+    (void)hipFree(h->agent_mem);
     (void)hipFree(h->staging);
     (void)hipFree(h->wave_counters);
     (void)hipFree(h->totals_dev);
@@ -634,6 +735,10 @@ int pom_batch_upload(PomBatch* h, const void* states, int64_t first, int64_t cou
             bad_env = first + off + fb;
             HIPCHK(hipMemcpyAsync(h->first_bad, &big, sizeof big, hipMemcpyHostToDevice, h->stream));
         }
+    }
+    if (h->agent_mem) { /* uploaded envs start new games: fresh agents */
+        HIPCHK(hipMemsetAsync(h->agent_mem + first * 4, 0, (size_t)count * 16, h->stream));
+        HIPCHK(hipMemsetAsync(h->agent_mem + 4 * h->n_pad + first * 4, 0, (size_t)count * 16, h->stream));
     }
     if (bad_env >= 0) {
         snprintf(g_err, sizeof g_err, "pom_batch_upload: env %lld holds a value outside the representable game states "
@@ -892,6 +997,104 @@ int pom_batch_set_streams(PomBatch* h, int32_t streams)
     const int want = (int64_t)streams > tiles ? (int)tiles : streams;
     if (int er = ensure_sub_streams(h, want)) return er;
     h->parts = want;
+    return POM_OK;
+}
+
+static int launch_policy(PomBatch* h, uint64_t seed)
+{
+    if (!h->agent_mem) {
+        HIPCHK(hipMalloc((void**)&h->agent_mem, (size_t)h->n_pad * 32));
+        HIPCHK(hipMemsetAsync(h->agent_mem, 0, (size_t)h->n_pad * 32, h->stream));
+    }
+    PolicyParams p;
+    p.state = h->state;
+    p.snap = h->snap;
+    p.agent_mem = h->agent_mem;
+    p.moves = h->moves_dev;
+    p.n = h->n;
+    p.n_pad = h->n_pad;
+    p.env_offset = h->env_offset;
+    p.seed = seed;
+    p.tick = (uint32_t)h->tick;
+    p.mode = h->mode;
+    p.auto_reset = h->auto_reset;
+    /* same split and the same streams as the tick, so that part k's policy -> tick -> policy chain pipelines */
+    const int64_t tiles = h->n_pad / 16, step_tiles = h->n_pad / h->epw;
+    int rc = fork_parts(h);
+    if (rc) return rc;
+    for (int k = 0; k < h->parts; k++) {
+        /* the tick's part k covers envs [step_tiles*k/parts, ...) * epw: use the same env boundaries */
+        const int64_t e0 = step_tiles * k / h->parts * h->epw, e1 = step_tiles * (k + 1) / h->parts * h->epw;
+        const int64_t b0 = e0 / 16, b1 = e1 / 16;
+        if (b1 <= b0) continue;
+        (void)tiles;
+        p.block0 = b0;
+        hipStream_t st = h->parts == 1 ? h->stream : h->sub[k];
+        pom_policy_kernel<<<dim3((unsigned)(b1 - b0)), dim3(64), 0, st>>>(p);
+        HIPCHK(hipGetLastError());
+    }
+    return POM_OK;
+}
+
+int pom_batch_policy_simple(PomBatch* h, uint64_t seed, int32_t* moves_out_host)
+{
+    if (!h) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = launch_policy(h, seed);
+    if (rc) return rc;
+    if (moves_out_host) {
+        if (int jr = join_parts(h)) return jr;
+        HIPCHK(hipMemcpyAsync(moves_out_host, h->moves_dev, (size_t)h->n * 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return POM_OK;
+}
+
+int pom_batch_step_policy(PomBatch* h)
+{
+    if (!h) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = launch_step(h, h->moves_dev, 0, 0, 1);
+    if (rc) return rc;
+    h->tick += 1;
+    return POM_OK;
+}
+
+int pom_batch_step_simple(PomBatch* h, uint64_t seed, int32_t ticks)
+{
+    if (!h || ticks < 0) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    for (int32_t t = 0; t < ticks; t++) {
+        int rc = launch_policy(h, seed);
+        if (!rc) rc = launch_step(h, h->moves_dev, 0, 0, 1);
+        if (rc) return rc;
+        h->tick += 1;
+    }
+    return POM_OK;
+}
+
+int pom_batch_policy_memory(PomBatch* h, int64_t first, int64_t count, int32_t* out16)
+{
+    int rc = check_range(h, first, count);
+    if (rc || !out16) return rc ? rc : POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
+    if (!h->agent_mem) {
+        memset(out16, 0, (size_t)count * 4 * 16 * sizeof(int32_t));
+        return POM_OK;
+    }
+    uint32_t* tmp = new (std::nothrow) uint32_t[(size_t)count * 8];
+    if (!tmp) return POM_E_NOMEM;
+    hipError_t e1 = hipMemcpyAsync(tmp, h->agent_mem + first * 4, (size_t)count * 16, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e2 = hipMemcpyAsync(tmp + count * 4, h->agent_mem + 4 * h->n_pad + first * 4, (size_t)count * 16, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e3 = hipStreamSynchronize(h->stream);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        delete[] tmp;
+        set_err("policy memory download", e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3);
+        return POM_E_HIP;
+    }
+    for (int64_t k = 0; k < count * 4; k++) pom_policy_mem_unpack(tmp[k], tmp[count * 4 + k], out16 + 16 * k);
+    delete[] tmp;
     return POM_OK;
 }
 

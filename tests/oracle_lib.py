@@ -42,6 +42,11 @@ class Oracle:
             lib.pom_oracle_fix_switch_move.argtypes = [VP, VP]
             lib.pom_oracle_resolve_dependencies.argtypes = [VP, VP, VP, VP]
             lib.pom_oracle_resolve_dependencies.restype = I
+            lib.pom_oracle_simple_act.argtypes = [VP, I, VP, I]
+            lib.pom_oracle_simple_act.restype = C.c_int32
+            lib.pom_oracle_simple_policy.argtypes = [VP, VP, I, C.c_uint64, I, I, VP, VP]
+            lib.pom_oracle_run_simple.argtypes = [VP, VP, VP, I, I, C.c_uint64, I, I, I]
+            lib.pom_oracle_run_simple.restype = C.c_int64
             Oracle._lib = lib
         self.lib = Oracle._lib
 
@@ -79,3 +84,18 @@ class Oracle:
         assert states.flags["C_CONTIGUOUS"] and initial.flags["C_CONTIGUOUS"]
         return int(self.lib.pom_oracle_run_random(states.ctypes.data, initial.ctypes.data, states.size, ticks, seed,
                                                   first_env, tick0, dist, max_steps))
+
+    # ---- SimpleAgent policy (oracle/pom_policy_oracle.c); agent memory as int32[n, 4, 16] ----
+    def simple_policy(self, states: np.ndarray, mems: np.ndarray, seed: int, first_env: int, tick: int, done=None) -> np.ndarray:
+        assert mems.dtype == np.int32 and mems.shape == (states.size, 4, 16) and mems.flags["C_CONTIGUOUS"]
+        moves = np.zeros((states.size, 4), dtype=np.int32)
+        d = None if done is None else np.ascontiguousarray(done, dtype=np.int32)
+        self.lib.pom_oracle_simple_policy(states.ctypes.data, mems.ctypes.data, states.size, seed, first_env, tick,
+                                          None if d is None else d.ctypes.data, moves.ctypes.data)
+        return moves
+
+    def run_simple(self, states: np.ndarray, initial: np.ndarray, mems: np.ndarray, ticks: int, seed: int, first_env: int, tick0: int,
+                   max_steps: int) -> int:
+        assert mems.dtype == np.int32 and mems.shape == (states.size, 4, 16)
+        return int(self.lib.pom_oracle_run_simple(states.ctypes.data, initial.ctypes.data, mems.ctypes.data, states.size, ticks, seed,
+                                                  first_env, tick0, max_steps))

@@ -1,0 +1,99 @@
+"""the SimpleAgent policy.  CPU: the device policy body (host build) vs the policy oracle under play.
+GPU: pom_batch_policy_simple / step_simple through the C-ABI vs the oracle — moves, agent memory and states, bit-exact."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pomcpp_amd as pa
+from pomcpp_amd.state import Move
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "build")
+INC = ["-I" + os.path.join(ROOT, p) for p in ("include", "pomcpp_amd/csrc", "oracle")]
+
+
+@pytest.mark.parametrize("scenario", [1, 2])
+def test_device_policy_body_matches_oracle_under_play(scenario):
+    os.makedirs(BUILD, exist_ok=True)
+    run = lambda *a: subprocess.run(list(a), check=True, cwd=ROOT)
+    run("g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", *INC, "-c", "tests/emul/pom_policy_emul.cpp", "-o", "build/pom_policy_emul.o")
+    run("gcc", "-O2", "-std=c11", *INC, "-c", "oracle/pom_policy_oracle.c", "-o", "build/pom_policy_oracle.o")
+    run("gcc", "-O2", "-std=c11", *INC, "-c", "oracle/pom_oracle.c", "-o", "build/pom_oracle_p.o")
+    run("g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", *INC, "tests/emul/emul_policy_fuzz.cpp", "build/pom_policy_emul.o",
+        "build/pom_policy_oracle.o", "build/pom_oracle_p.o", "-o", "build/emul_policy_fuzz")
+    out = subprocess.run([os.path.join(BUILD, "emul_policy_fuzz"), str(scenario), "100000", "3"], capture_output=True, text=True)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-2000:]
+
+
+def test_oracle_policy_basics(oracle):
+    """Hand-checkable situations: an agent next to a wood bombs it; an agent on a ticking bomb walks away."""
+    s = pa.new_states(1)
+    pa.put_agents_in_corners(s[0])
+    pa.put_item(s[0], 1, 0, pa.Item.WOOD)
+    mem = np.zeros((1, 4, 16), dtype=np.int32)
+    mv = oracle.simple_policy(s, mem, seed=1, first_env=0, tick=0)
+    assert mv[0, 0] == Move.BOMB                      # IsAdjacentItem(WOOD) -> BOMB (simple_agent.cpp:100-103)
+    assert mem[0, 0, 9] == 1 and mem[0, 0, 0:2].tolist() == [0, 0]   # recentPositions got its cell
+    pa.plant_bomb(s[0], 10, 10, 2, True, 3)           # a bomb under agent 2, 3 ticks left
+    mv = oracle.simple_policy(s, mem, seed=1, first_env=0, tick=1)
+    assert mv[0, 2] in (Move.UP, Move.LEFT)           # in danger: MoveTowardsSafePlace / a safe direction
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,streams", [("ffa", 1), ("ffa", 2), ("stress", 1)])
+def test_gpu_policy_moves_memory_and_states_match_oracle(hip_lib, oracle, kind, streams):
+    from pomcpp_amd.batch import BatchEnvironment, MODE_ENV
+    n, ticks, seed = 1500, 120, 77
+    start = pa.make_boards(n, seed=13, kind=kind)
+    # make agents meet early in a third of the envs so that the enemy / loop-breaking branches run
+    for e in range(0, n, 3):
+        if start[e]["board"][5, 4] == 0 and start[e]["board"][5, 6] == 0:
+            start[e]["board"][0, 0] = 0
+            start[e]["board"][0, 10] = 0
+            pa.put_agent(start[e], 4, 5, 0)
+            pa.put_agent(start[e], 6, 5, 1)
+    ref = start.copy()
+    mem = np.zeros((n, 4, 16), dtype=np.int32)
+    status = [dict(done=0, winner=-1, draw=0) for _ in range(n)]
+    hist = np.zeros(6, dtype=np.int64)
+    with BatchEnvironment(n, mode=MODE_ENV, auto_reset=False, streams=streams) as env:
+        env.make_game(start)
+        for t in range(ticks):
+            got_mv = env.policy_simple(seed, want_moves=True)
+            done = np.array([s["done"] for s in status], dtype=np.int32)
+            want_mv = oracle.simple_policy(ref, mem, seed, 0, t, done)
+            assert np.array_equal(got_mv, want_mv), f"tick {t}: moves differ in envs {np.nonzero((got_mv != want_mv).any(1))[0][:8]}"
+            assert np.array_equal(env.policy_memory(), mem), f"tick {t}: agent memory differs"
+            hist += np.bincount(want_mv.ravel(), minlength=6)
+            env.step_policy()
+            for e in range(n):
+                oracle.env_step(ref[e:e + 1], want_mv[e], status[e])
+        got = env.get_state()
+    ref["agents"]["pad"] = 0
+    assert got.tobytes() == ref.tobytes()
+    assert hist.min() > 0  # every kind of move was played
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,streams", [(4096 + 5, 1), (4096 + 5, 3)])
+def test_gpu_step_simple_with_autoreset_matches_oracle(hip_lib, oracle, n, streams):
+    from pomcpp_amd.batch import BatchEnvironment, MODE_ENV, CNT_STEPS, CNT_RESETS
+    ticks, seed = 150, 5
+    start = pa.make_boards(n, seed=4)
+    want = start.copy()
+    mem = np.zeros((n, 4, 16), dtype=np.int32)
+    steps = oracle.run_simple(want, start, mem, ticks, seed, 0, 0, 800)
+    want["agents"]["pad"] = 0
+    with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800, streams=streams) as env:
+        env.make_game(start)
+        env.step_simple(seed, ticks)
+        got = env.get_state()
+        assert got.tobytes() == want.tobytes()
+        assert np.array_equal(env.policy_memory(), mem)
+        cnt = env.counters()
+        assert cnt[CNT_STEPS] == steps == n * ticks and cnt[CNT_RESETS] > 0
+        # uploading envs again gives them fresh agents
+        env.make_game(start[:10], first=0)
+        assert not env.policy_memory(0, 10).any() and env.policy_memory(10, 5).any()
