@@ -120,6 +120,8 @@ def main() -> None:
     ap.add_argument("--ticks-per-launch", type=int, default=1)
     ap.add_argument("--max-steps", type=int, default=800)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--policy", default="random", choices=["random", "simple"],
+                    help="random: Move[4] from the counter stream (--dist); simple: the device SimpleAgent policy (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=0, help="sub-batches per step (0 = library default)")
     ap.add_argument("--envs-per-wave", type=int, default=0)
@@ -165,6 +167,15 @@ def main() -> None:
         torch.cuda.synchronize()
 
     tpl = args.ticks_per_launch
+    if args.policy == "simple":
+        if tpl != 1:
+            raise SystemExit("--policy simple runs one tick per launch")
+
+        def one_step():
+            env.step_simple(args.seed, 1)
+    else:
+        def one_step():
+            env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)
     tuned = None
     if args.streams == 0:
         # Untimed: how many sub-batches per step?  More parts overlap more load/store with compute, but ROCm maps all streams
@@ -174,11 +185,11 @@ def main() -> None:
         for k in (2, 3, 1):
             env.set_streams(k)
             for _ in range(15):
-                env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)
+                one_step()
             env.sync()
             t_a = time.perf_counter()
             for _ in range(60):
-                env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)
+                one_step()
             env.sync()
             tuned[k] = (time.perf_counter() - t_a) / 60 * 1e3
         best = min(tuned, key=tuned.get)
@@ -188,7 +199,7 @@ def main() -> None:
             best = int(torch.argmin(votes).item()) + 1
         env.set_streams(best)
     for _ in range(args.warmup):
-        env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)
+        one_step()
     env.counters_into(counters.data_ptr())
     reduce_counters(counters, dist)  # warm the RCCL communicator outside the timed region
     env.reset_counters()
@@ -198,7 +209,7 @@ def main() -> None:
     t0 = time.perf_counter()
     ev0.record(stream)
     for _ in range(args.steps):
-        env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)
+        one_step()
     env.flush()  # steps run as sub-batches on internal streams: order them before the event on this stream
     ev1.record(stream)
     env.counters_into(counters.data_ptr())
@@ -213,10 +224,24 @@ def main() -> None:
     epw, lpe, parts = env.launch_shape()
     env.profile(True)
     for _ in range(max(1, 256 // parts)):
-        env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)
+        env.step_random(args.seed, dist_id, ticks=tpl, ticks_per_launch=tpl)  # the tick kernel alone
     launch_ms, n_launch = env.profile_read()
     env.profile(False)
 
+    # BASELINE config 3 beside the headline (rank 0 of a single-GPU run, untimed region): the same envs driven by the device
+    # SimpleAgent policy, act x4 + Step per env-step as Environment::Step does
+    config3 = None
+    if world == 1 and args.policy == "random" and tpl == 1:
+        for _ in range(10):
+            env.step_simple(args.seed, 1)
+        env.sync()
+        t_c = time.perf_counter()
+        n_c = 40
+        env.step_simple(args.seed, n_c)
+        env.sync()
+        dt_c = time.perf_counter() - t_c
+        config3 = {"workload": f"{args.envs} envs, 4x SimpleAgent policy on the device + Step", "value": plan["n_envs"] * n_c / dt_c,
+                   "unit": "env-steps/s", "ms_per_step": dt_c / n_c * 1e3, "steps": n_c}
     total_steps = int(counters[CNT_STEPS].item())
     expect = plan["global_envs"] * args.steps * tpl
     if total_steps != expect:
@@ -235,8 +260,11 @@ def main() -> None:
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {
-                "workload": f"{args.envs} concurrent 11x11 FFA envs per GPU, {args.kind} boards, uniform-{args.dist} Move[4] "
-                            f"(RandomAgent distribution), auto-reset, {args.max_steps}-tick cap",
+                "workload": f"{args.envs} concurrent 11x11 FFA envs per GPU, {args.kind} boards, "
+                            + (f"uniform-{args.dist} Move[4] (RandomAgent distribution)" if args.policy == "random"
+                               else "4x SimpleAgent policy on the device (act x4 + Step per env-step, as Environment::Step)")
+                            + f", auto-reset, {args.max_steps}-tick cap",
+                "policy": args.policy,
                 "envs_per_gpu": args.envs, "global_envs": plan["global_envs"], "ticks_per_launch": tpl,
                 "envs_per_wave": epw, "lanes_per_env": lpe, "launches_per_step": parts,
                 "launches_per_step_tuning_ms": tuned,
@@ -252,6 +280,8 @@ def main() -> None:
                            "achieved": (algo_bytes / parts) / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else None},
             },
         }
+        if config3:
+            line["config3_simple_agent"] = config3
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(start, args.seed, dist_id, args.max_steps)
         print(json.dumps(line), flush=True)
