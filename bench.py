@@ -146,6 +146,9 @@ def main() -> None:
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # create RCCL's communicator and streams now: they take hardware queues, which the stream tuning below must see
+        dist.all_reduce(torch.zeros(1, device=device))
+        torch.cuda.synchronize()
     dist_id = {"harmless": 0, "random": 1, "stress": 2}[args.dist]
     plan = shard_plan(rank, world, args.envs)
 

@@ -296,28 +296,27 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW 
 /* ---------------------------------------------------------------------------------------------
  * SimpleAgent policy (pom_policy_body.h): one lane per AGENT, the quad 4e..4e+3 = the four agents of env e,
  * 16 envs per wavefront.  The wavefront DMAs record rows 0..91 (board, meta, agents, bombs) of its 16 envs into a shared
- * tile; each lane additionally owns a column of a [61][64] reachability map (distance:8 | predecessor:8 per cell, two
- * cells per dword) and of a [31][64] BFS queue (one byte per entry) — 29.5 KB per wavefront.  Output: Move[4] per env into
- * the handle's move buffer, agent memory (2 dwords per agent) updated in place.  A finished env that the next step will
+ * tile; per env the four lanes together prepare a danger map ([121][16] dwords, LDS atomic min) and two cell sets.  The
+ * reachability search runs on 121-bit cell sets in registers, so a wavefront needs only 14 KB of LDS.  Output: Move[4] per env
+ * into the handle's move buffer, agent memory (2 dwords per agent) updated in place.  A finished env that the next step will
  * restart is read from its snapshot column and gets fresh (zero) agent memory, so policy and tick see the same game.
  * ------------------------------------------------------------------------------------------- */
-enum { POL_ROWS = 92, POL_RM_ROWS = 61, POL_Q_ROWS = 31 };
+enum { POL_ROWS = 92 };
 
 struct PolicyStore {
     const uint32_t* t; /* &tile[env_in_wave], row stride 16 dwords */
-    uint32_t* rmcol;   /* &rmap[lane], row stride 64 dwords */
-    uint32_t* qcol;    /* &queue[lane], row stride 64 dwords */
+    int* dcol;         /* &danger[env_in_wave], row stride 16 */
+    uint32_t* scol;    /* &sets[env_in_wave], row stride 16 */
+    int who;           /* lane % 4 */
+    __device__ int member() const { return who; }
+    __device__ int danger(int c) const { return dcol[c * 16]; }
+    __device__ void danger_init(int c) { dcol[c * 16] = POM_DANGER_NONE; }
+    __device__ void danger_min(int c, int tm) { atomicMin(&dcol[c * 16], tm); } /* the env's lanes rasterise different bombs */
+    __device__ uint32_t setw(int k) const { return scol[k * 16]; }
+    __device__ void set_or(int k, uint32_t bits) { atomicOr(&scol[k * 16], bits); }
+    __device__ void set_zero(int k) { scol[k * 16] = 0; }
     __device__ int cell(int c) const { return reinterpret_cast<const uint16_t*>(t)[(c >> 1) * 32 + (c & 1)]; }
     __device__ int bomb(int s) const { return (int)t[(POM_REC_BOMBS + s) * 16]; }
-    __device__ int rm(int c) const { return reinterpret_cast<const uint16_t*>(rmcol)[(c >> 1) * 128 + (c & 1)]; }
-    __device__ void set_rm(int c, int v) { reinterpret_cast<uint16_t*>(rmcol)[(c >> 1) * 128 + (c & 1)] = (uint16_t)v; }
-    __device__ void clear_rm()
-    {
-#pragma unroll
-        for (int k = 0; k < POL_RM_ROWS; k++) rmcol[k * 64] = 0;
-    }
-    __device__ int qe(int i) const { return reinterpret_cast<const uint8_t*>(qcol)[(i >> 2) * 256 + (i & 3)]; }
-    __device__ void set_qe(int i, int c) { reinterpret_cast<uint8_t*>(qcol)[(i >> 2) * 256 + (i & 3)] = (uint8_t)c; }
 };
 
 struct PolicyParams {
@@ -334,8 +333,8 @@ struct PolicyParams {
 __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
 {
     __shared__ uint32_t tile[POL_ROWS * 16];
-    __shared__ uint32_t rmap[POL_RM_ROWS * 64];
-    __shared__ uint32_t queue[POL_Q_ROWS * 64];
+    __shared__ int danger[POM_CELLS * 16];
+    __shared__ uint32_t sets[8 * 16];
     const int lane = threadIdx.x;
     const int64_t np = p.n_pad;
     int64_t tile_local;
@@ -377,8 +376,12 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
     E.bCnt = (int)((meta >> 16) & 0xFF);
     const bool frozen = env_mode && ((meta2 >> 8) & POM_ST_DONE); /* finished and not restarted: Environment::Step returns */
     int mv = POM_MOVE_IDLE;
+    PolicyStore st{t, danger + ec, sets + ec, id};
+    if (e < p.n && !frozen) { /* all four lanes of the env, dead agents' lanes included */
+        pom_policy_prepare_clear(st);
+        pom_policy_prepare_fill(st, E);
+    }
     if (e < p.n && !frozen && !ag_dead(sel4(id, E.a0))) { /* act() is only asked of live agents, environment.cpp:139-146 */
-        PolicyStore st{t, rmap + lane, queue + lane};
         PomSimplePolicy<PolicyStore> pol(st, E, id, m0, m1);
         const uint64_t r = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick);
         const int draw = (int)((((uint32_t)(r >> (16 * id)) & 0xFFFFu) * 5u) >> 16);

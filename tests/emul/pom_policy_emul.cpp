@@ -10,15 +10,18 @@
 struct PolicyArrays {
     uint16_t cells[122];
     int bombs[20];
-    uint16_t rmap[POM_CELLS];
-    uint8_t queue[POM_CELLS + 4];
+    int dmap[POM_CELLS];
+    uint32_t sets[8];
+    int who; /* which of the env's four lanes is executing */
+    int member() const { return who; }
+    int danger(int c) const { return dmap[c]; }
+    void danger_init(int c) { dmap[c] = POM_DANGER_NONE; }
+    void danger_min(int c, int t) { dmap[c] = t < dmap[c] ? t : dmap[c]; }
+    uint32_t setw(int k) const { return sets[k]; }
+    void set_or(int k, uint32_t bits) { sets[k] |= bits; }
+    void set_zero(int k) { sets[k] = 0; }
     int cell(int c) const { return cells[c]; }
     int bomb(int s) const { return bombs[s]; }
-    int rm(int c) const { return rmap[c]; }
-    void set_rm(int c, int v) { rmap[c] = (uint16_t)v; }
-    void clear_rm() { std::memset(rmap, 0, sizeof rmap); }
-    int qe(int i) const { return queue[i]; }
-    void set_qe(int i, int c) { queue[i] = (uint8_t)c; }
 };
 
 extern "C" {
@@ -48,6 +51,10 @@ int pom_emul_simple_act(const void* state_1004, int id, int32_t* mem16, int draw
     for (int i = 0; i < 4; i++) m0 |= (uint32_t)((mem16[2 * i] & 0xF) | ((mem16[2 * i + 1] & 0xF) << 4)) << (8 * i);
     m1 = (uint32_t)(mem16[8] & 3) | ((uint32_t)(mem16[9] & 7) << 2) | ((uint32_t)(mem16[15] & 7) << 17);
     for (int i = 0; i < 4; i++) m1 |= (uint32_t)(mem16[10 + i] & 7) << (5 + 3 * i);
+    /* on the device the env's four lanes do this together, phase by phase */
+    for (st.who = 0; st.who < 4; st.who++) pom_policy_prepare_clear(st);
+    for (st.who = 0; st.who < 4; st.who++) pom_policy_prepare_fill(st, E);
+    st.who = id;
     PomSimplePolicy<PolicyArrays> pol(st, E, id, m0, m1);
     const int mv = pol.act(draw);
     pom_policy_mem_unpack(pol.m0, pol.m1, mem16);
