@@ -313,8 +313,8 @@ struct PolicyStore {
     __device__ void danger_init(int c) { dcol[c * 16] = POM_DANGER_NONE; }
     __device__ void danger_min(int c, int tm) { atomicMin(&dcol[c * 16], tm); } /* the env's lanes rasterise different bombs */
     __device__ uint32_t setw(int k) const { return scol[k * 16]; }
-    __device__ void set_or(int k, uint32_t bits) { atomicOr(&scol[k * 16], bits); }
-    __device__ void set_zero(int k) { scol[k * 16] = 0; }
+    __device__ void set_put(int k, uint32_t bits) { scol[k * 16] = bits; }
+    __device__ uint32_t board_word(int k) const { return t[k * 16]; }
     __device__ int cell(int c) const { return reinterpret_cast<const uint16_t*>(t)[(c >> 1) * 32 + (c & 1)]; }
     __device__ int bomb(int s) const { return (int)t[(POM_REC_BOMBS + s) * 16]; }
 };
@@ -328,13 +328,16 @@ struct PolicyParams {
     uint64_t seed;
     uint32_t tick;
     int32_t mode, auto_reset;
+#if defined(POM_DIAG)
+    long long* diag; /* POM_PP_N accumulators per wavefront, diagnostic build only */
+#endif
 };
 
 __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
 {
     __shared__ uint32_t tile[POL_ROWS * 16];
-    __shared__ int danger[POM_CELLS * 16];
-    __shared__ uint32_t sets[8 * 16];
+    __shared__ int danger[128 * 16]; /* 121 cells; the safe-set pass reads whole 32-cell words */
+    __shared__ uint32_t sets[12 * 16];
     const int lane = threadIdx.x;
     const int64_t np = p.n_pad;
     int64_t tile_local;
@@ -344,6 +347,9 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
     }
     const int64_t tile_id = p.block0 + tile_local;
     const bool env_mode = p.mode == POM_MODE_ENV;
+#if defined(POM_DIAG)
+    long long t_last = (long long)clock64(), t_acc[POM_PP_N] = {0, 0, 0, 0, 0, 0, 0};
+#endif
     /* data movement: lane -> (env lane%16, row group lane/16) */
     const int el = lane & 15, sub = lane >> 4;
     const int64_t e_d = tile_id * 16 + el;
@@ -377,21 +383,55 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
     const bool frozen = env_mode && ((meta2 >> 8) & POM_ST_DONE); /* finished and not restarted: Environment::Step returns */
     int mv = POM_MOVE_IDLE;
     PolicyStore st{t, danger + ec, sets + ec, id};
+    POM_PSTAMP(POM_PP_LOAD);
     if (e < p.n && !frozen) { /* all four lanes of the env, dead agents' lanes included */
+#if defined(POM_POL_DUP)
+        if (POM_POL_DUP == 1) {
+            pom_policy_prepare_clear(st);
+            pom_policy_prepare_fill(st, E);
+            pom_policy_prepare_safe(st);
+            asm volatile("" ::: "memory");
+        }
+#endif
         pom_policy_prepare_clear(st);
         pom_policy_prepare_fill(st, E);
+        pom_policy_prepare_safe(st);
     }
+    POM_PSTAMP(POM_PP_PREPARE);
     if (e < p.n && !frozen && !ag_dead(sel4(id, E.a0))) { /* act() is only asked of live agents, environment.cpp:139-146 */
         PomSimplePolicy<PolicyStore> pol(st, E, id, m0, m1);
+#if defined(POM_DIAG)
+        pol.t_last = t_last;
+        for (int k = 0; k < POM_PP_N; k++) pol.t_acc[k] = 0;
+#endif
         const uint64_t r = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick);
         const int draw = (int)((((uint32_t)(r >> (16 * id)) & 0xFFFFu) * 5u) >> 16);
         mv = pol.act(draw);
         m0 = pol.m0;
         m1 = pol.m1;
+#if defined(POM_DIAG)
+        t_last = pol.t_last;
+        for (int k = POM_PP_PREDICATES; k <= POM_PP_TAIL; k++) t_acc[k] = pol.t_acc[k];
+#endif
     }
     p.moves[slot] = mv;
     p.agent_mem[slot] = m0;
     p.agent_mem[4 * np + slot] = m1;
+#if defined(POM_DIAG)
+    POM_PSTAMP(POM_PP_STORE);
+    /* a lane that skipped a phase books the wavefront's time on its next stamp: per phase, the lanes that ran it agree, so
+     * take the largest (an idle wavefront's act phases read 0) */
+    for (int k = 0; k < POM_PP_N; k++) {
+        long long v = t_acc[k];
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long w = __shfl_xor(v, o);
+            v = w > v ? w : v;
+        }
+        t_acc[k] = v;
+    }
+    if (lane == 0 && p.diag)
+        for (int k = 0; k < POM_PP_N; k++) p.diag[tile_id * POM_PP_N + k] += t_acc[k];
+#endif
 }
 
 /* ---- boundary kernels ----------------------------------------------------------------------- */
@@ -520,6 +560,7 @@ struct PomBatch {
     int prof_n = 0;
 #if defined(POM_DIAG)
     long long* diag = nullptr;
+    long long* diag_pol = nullptr;
 #endif
 };
 
@@ -991,6 +1032,24 @@ int pom_diag_read(PomBatch* h, long long out[POM_PH_N])
 }
 #endif
 
+#if defined(POM_DIAG)
+extern "C" int pom_diag_policy_read(PomBatch* h, long long out[POM_PP_N])
+{
+    if (!h || !h->diag_pol) return POM_E_ARG;
+    const size_t nw = (size_t)(h->n_pad / 16);
+    if (int jr = join_parts(h)) return jr;
+    long long* tmp = new long long[nw * POM_PP_N];
+    HIPCHK(hipMemcpyAsync(tmp, h->diag_pol, nw * POM_PP_N * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemsetAsync(h->diag_pol, 0, nw * POM_PP_N * 8, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < POM_PP_N; k++) out[k] = 0;
+    for (size_t w = 0; w < nw; w++)
+        for (int k = 0; k < POM_PP_N; k++) out[k] += tmp[w * POM_PP_N + k];
+    delete[] tmp;
+    return POM_OK;
+}
+#endif
+
 int pom_batch_set_streams(PomBatch* h, int32_t streams)
 {
     if (!h || streams < 1 || streams > PomBatch::MAX_PARTS) return POM_E_ARG;
@@ -1021,6 +1080,14 @@ static int launch_policy(PomBatch* h, uint64_t seed)
     p.tick = (uint32_t)h->tick;
     p.mode = h->mode;
     p.auto_reset = h->auto_reset;
+#if defined(POM_DIAG)
+    if (!h->diag_pol) {
+        HIPCHK(hipMalloc((void**)&h->diag_pol, (size_t)(h->n_pad / 16) * POM_PP_N * 8));
+        HIPCHK(hipMemsetAsync(h->diag_pol, 0, (size_t)(h->n_pad / 16) * POM_PP_N * 8, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    p.diag = h->diag_pol;
+#endif
     /* same split and the same streams as the tick, so that part k's policy -> tick -> policy chain pipelines */
     const int64_t tiles = h->n_pad / 16, step_tiles = h->n_pad / h->epw;
     int rc = fork_parts(h);

@@ -13,10 +13,11 @@
  * policy ever asks of it is (a) "is this cell reachable" and (b) MoveTowardsPosition: follow the predecessors from a target
  * back to the source and report on which side of the source the path starts.  A FIFO search with a fixed neighbour order
  * (DOWN, UP, RIGHT, LEFT: strategy.cpp:83-90) gives every cell the lexicographically smallest of its shortest paths, so the
- * side the path starts on is the smallest label among the cell's neighbours of the previous level.  That is a flood fill: four
- * 121-bit cell sets in registers (one per first step), each level dilated by shifts and masks and claimed in priority order.
- * No queue, no per-cell map, no LDS traffic; ~300 VALU per level instead of ~100 per CELL.  It is only run for agents whose
- * decision reads it, at one program point.
+ * answer to (b) is: of the source's neighbours that lie on SOME shortest path to the target, the first in that order.  Both are
+ * flood fills on 121-bit cell sets in registers, one dilation (4 multi-word shifts + masks) per level: (a) forwards from the
+ * source until nothing grows — only the danger branch needs it; (b) backwards from the ONE target the decision is about, until
+ * the flood first touches neighbours of the source — as many levels as the target is far.  No queue, no per-cell map, no LDS
+ * traffic, ~90 VALU per level instead of ~100 per CELL; (b) sits at one program point for both branches that need it.
  *
  * Agent memory, 2 dwords: m0 = recentPositions.queue[0..3], a byte each: x:4 | y:4 two's-complement nibbles (-1 .. 11);
  *                         m1 = recentPositions.index:2 | count:3 @2 | moveQueue.queue[0..3] 3 bits each @5 | moveQueue.count:3 @17
@@ -28,8 +29,11 @@
  *
  * Store interface P:  int cell(int c)            16-bit board code (pom_packed.h), c = y*11+x
  *                     int bomb(int slot)         raw bomb word of physical slot
- *                     int danger(int c) / void danger_init(int c) / void danger_min(int c, int t)     per-env danger map
- *                     uint32_t setw(int k) / void set_or(int k, uint32_t bits) / void set_zero(int k)   per-env bit sets, k = 0..7
+ *                     uint32_t board_word(int k) board dword k = cells 2k (low half) and 2k+1; k up to 63 must be readable
+ *                     int danger(int c) / void danger_init(int c) / void danger_min(int c, int t)     per-env danger map, 128
+ *                                                entries (c up to 127 must be readable)
+ *                     uint32_t setw(int k) / void set_put(int k, uint32_t bits)   per-env cell sets, words
+ *                                                k = 0..3 walkable, 4..7 agents, 8..11 "safe" (_safe_condition(IsInDanger))
  *                     int member()               which of the env's 4 lanes this is
  */
 #ifndef POM_POLICY_BODY_H_
@@ -44,55 +48,89 @@ struct PomPolicyEnv { /* what the policy reads of the env besides board and bomb
 
 enum { POM_DANGER_NONE = 99 };
 
-/* Shared preparation, executed by all four lanes of an env (member m takes cells / bombs m, m+4, ...).  Two phases: every
- * lane must have finished clearing before any lane accumulates (on the device the wavefront runs them back to back in
- * lock-step; a sequential host emulation runs phase 0 for all four members, then phase 1). */
+/* POM_DIAG builds (scripts/policy_stamps.py, never shipped): s_memtime deltas per phase of the policy kernel */
+enum { POM_PP_LOAD = 0, POM_PP_PREPARE, POM_PP_PREDICATES, POM_PP_TARGET, POM_PP_PATH, POM_PP_TAIL, POM_PP_STORE, POM_PP_N };
+#if defined(POM_DIAG) && defined(__HIP_DEVICE_COMPILE__)
+#define POM_PSTAMP(k)                                 \
+    do {                                              \
+        const long long now_ = (long long)clock64();  \
+        t_acc[k] += now_ - t_last;                    \
+        t_last = now_;                                \
+    } while (0)
+#else
+#define POM_PSTAMP(k) ((void)0)
+#endif
+/* POM_POL_DUP=k builds (scripts/policy_dup.py, never shipped) run section k twice, results unchanged: the extra time is what
+ * the section costs on the real workload (the kernel is VALU-issue-bound, so elapsed-time stamps mislead) */
+#if defined(POM_POL_DUP) && defined(__HIP_DEVICE_COMPILE__)
+#define POM_DUP(k, stmt, out)                                                        \
+    do {                                                                             \
+        if (POM_POL_DUP == (k)) {                                                    \
+            stmt;                                                                    \
+            asm volatile("" : "+v"(out), "+v"(walk.w[0]), "+v"(walk.w[1]), "+v"(walk.w[2]), "+v"(walk.w[3])::"memory"); \
+        }                                                                            \
+    } while (0)
+#else
+#define POM_DUP(k, stmt, out) ((void)0)
+#endif
+
+/* Shared preparation, executed by all four lanes of an env.  The 121-bit sets are four words and the env has four lanes:
+ * member m builds word m of every set (cells 32m .. 32m+31) with plain stores, from whole board dwords (two cells each).  The
+ * danger map is cleared and rasterised by bombs m, m+4, ...  Three phases — every lane must have finished one before any lane
+ * starts the next (on the device the wavefront runs them back to back in lock-step; a sequential host emulation runs each
+ * phase for all four members in turn). */
 template <class P>
 POM_HD void pom_policy_prepare_clear(P& p)
 {
     const int m = p.member();
-    if (m == 0)
-        for (int k = 0; k < 8; k++) p.set_zero(k);
-    POM_NOUNROLL
-    for (int c = m; c < POM_CELLS; c += 4) p.danger_init(c);
+#pragma unroll
+    for (int i = 0; i < 31; i++) {
+        const int c = m + 4 * i;
+        if (i < 30 || c < POM_CELLS) p.danger_init(c);
+    }
 }
 template <class P>
 POM_HD void pom_policy_prepare_fill(P& p, const PomPolicyEnv& E)
 {
     const int m = p.member();
-    /* walkable (IS_WALKABLE, bboard.hpp:81-84) -> words 0..3, agent cells (item >= AGENT0) -> words 4..7 */
-    uint32_t w[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
-    POM_NOUNROLL
-    for (int c = m; c < POM_CELLS; c += 4) {
-        const int e = p.cell(c);
-        const uint32_t bit = 1u << (c & 31);
-        const int k = c >> 5;
-        const uint32_t wb = pc_is_walkable(e) ? bit : 0u, gb = pc_is_agent(e) ? bit : 0u;
-        w[0] |= k == 0 ? wb : 0u; w[1] |= k == 1 ? wb : 0u; w[2] |= k == 2 ? wb : 0u; w[3] |= k == 3 ? wb : 0u;
-        g[0] |= k == 0 ? gb : 0u; g[1] |= k == 1 ? gb : 0u; g[2] |= k == 2 ? gb : 0u; g[3] |= k == 3 ? gb : 0u;
-    }
+    /* walkable (IS_WALKABLE, bboard.hpp:81-84: passage or a power-up) -> word m, agent cells (item >= AGENT0) -> word 4+m */
+    uint32_t w = 0, g = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        p.set_or(k, w[k]);
-        p.set_or(4 + k, g[k]);
+    for (int i = 0; i < 16; i++) {
+        const uint32_t d = p.board_word(16 * m + i); /* cells 32m+2i (low half) and 32m+2i+1; m = 3 runs past the board ... */
+        const uint32_t lo = d & 0xFFFFu, hi = d >> 16;
+        const uint32_t wl = (lo == 0u) | ((lo - 6u) < 3u), wh = (hi == 0u) | ((hi - 6u) < 3u);
+        w |= (wl << (2 * i)) | (wh << (2 * i + 1));
+        g |= ((lo >> 15) << (2 * i)) | ((hi >> 15) << (2 * i + 1));
     }
+    const uint32_t keep = m == 3 ? 0x01FFFFFFu : ~0u; /* ... into dwords that are not cells: 121 = 96 + 25 */
+    p.set_put(m, w & keep);
+    p.set_put(4 + m, g & keep);
     /* IsInDanger for every cell at once: min BMB_TIME over the bombs whose cross (IsInBombRange, strategy.hpp:163-169: the
      * +-strength row and column segments through the bomb, walls ignored) covers the cell */
     POM_NOUNROLL
     for (int i = m; i < E.bCnt; i += 4) {
         const int b = p.bomb(wrap20(E.bIdx + i));
         const int bx = pb_x(b), by = pb_y(b), s = pb_strength(b), t = pb_time(b);
-        const int x0 = bx - s < 0 ? 0 : bx - s, x1 = bx + s > POM_N - 1 ? POM_N - 1 : bx + s;
-        const int y0 = by - s < 0 ? 0 : by - s, y1 = by + s > POM_N - 1 ? POM_N - 1 : by + s;
-        if (by < POM_N) {
-            POM_NOUNROLL
-            for (int x = x0; x <= x1; x++) p.danger_min(by * POM_N + x, t);
-        }
-        if (bx < POM_N) {
-            POM_NOUNROLL
-            for (int y = y0; y <= y1; y++) p.danger_min(y * POM_N + bx, t);
+        if (bx >= POM_N || by >= POM_N) continue; /* upload validates live bombs; a stale word cannot index the map */
+        POM_NOUNROLL
+        for (int k = -s; k <= s; k++) {
+            const int x = bx + k, y = by + k;
+            if (x >= 0 && x < POM_N) p.danger_min(by * POM_N + x, t);
+            if (y >= 0 && y < POM_N) p.danger_min(y * POM_N + bx, t);
         }
     }
+}
+/* third phase, after every lane's bombs are in the danger map: the cells that pass _safe_condition(IsInDanger(x, y), 2),
+ * i.e. whose entry is not 1 (IsInDanger reports a minimum of 0 as "no danger"); word 8+m */
+template <class P>
+POM_HD void pom_policy_prepare_safe(P& p)
+{
+    const int m = p.member();
+    uint32_t sb = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) sb |= (uint32_t)(p.danger(32 * m + i) != 1) << i; /* the map has 128 rows: no cell past 120 matters */
+    p.set_put(8 + m, m == 3 ? sb & 0x01FFFFFFu : sb);
 }
 
 /* a set of board cells: bit c = y*11+x of a 121-bit number in four words */
@@ -111,6 +149,24 @@ struct PomCells {
         const int k = c >> 5;
         const uint32_t b = 1u << (c & 31);
         w[0] |= k == 0 ? b : 0u; w[1] |= k == 1 ? b : 0u; w[2] |= k == 2 ? b : 0u; w[3] |= k == 3 ? b : 0u;
+    }
+    POM_HD void add_range(int start, int len) /* cells start .. start+len-1, 1 <= len <= 11 */
+    {
+        const uint32_t run = (1u << len) - 1u;
+        const int k = start >> 5, sh = start & 31;
+        const uint32_t lo = run << sh, hi = sh + len > 32 ? run >> (32 - sh) : 0u;
+        w[0] |= k == 0 ? lo : 0u;
+        w[1] |= k == 1 ? lo : k == 0 ? hi : 0u;
+        w[2] |= k == 2 ? lo : k == 1 ? hi : 0u;
+        w[3] |= k == 3 ? lo : k == 2 ? hi : 0u;
+    }
+    POM_HD int lowest() const /* smallest member, -1 if empty */
+    {
+        if (w[0]) return __builtin_ctz(w[0]);
+        if (w[1]) return 32 + __builtin_ctz(w[1]);
+        if (w[2]) return 64 + __builtin_ctz(w[2]);
+        if (w[3]) return 96 + __builtin_ctz(w[3]);
+        return -1;
     }
     POM_HD void remove(int c)
     {
@@ -155,14 +211,25 @@ struct PomSimplePolicy {
     const PomPolicyEnv& E;
     int id, sx, sy; /* me, and where I stand (the search's source) */
     uint32_t m0, m1;
-    PomCells first[4]; /* cells whose path from me starts DOWN / UP / RIGHT / LEFT; their union = the reachable cells */
+    PomCells walk, agents; /* the env's walkable and agent cells (prepared once per env) */
+    PomCells all;          /* the cells FillRMap reaches (GetDistance != 0); built by forward_reach() */
+#if defined(POM_DIAG)
+    long long t_last, t_acc[POM_PP_N];
+#endif
     POM_HD PomSimplePolicy(P& p_, const PomPolicyEnv& e_, int id_, uint32_t m0_, uint32_t m1_)
         : p(p_), E(e_), id(id_), sx(0), sy(0), m0(m0_), m1(m1_)
     {
-        first[0] = first[1] = first[2] = first[3] = PomCells::zero();
+        all = PomCells::zero();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            walk.w[k] = p.setw(k);
+            agents.w[k] = p.setw(4 + k);
+        }
         const int av = sel4(id, E.a0);
         sx = ag_x(av);
         sy = ag_y(av);
+        agents.remove(sy * POM_N + sx); /* FillRMap never re-enters its source (strategy.cpp:83-90) */
+        walk.remove(sy * POM_N + sx);
     }
 
     /* ---- memory fields ---- */
@@ -190,53 +257,58 @@ struct PomSimplePolicy {
     POM_HD static int safe(int danger, int min) { return danger == 0 || danger >= min; } /* _safe_condition, strategy.cpp:199-202 */
     POM_HD int walkable_at(int x, int y) const { return !oob(x, y) && pc_is_walkable(p.cell(y * POM_N + x)); } /* _CheckPos */
 
-    /* FillRMap, strategy.cpp:59-93, as a flood fill (see the file comment).  A cell can be entered if it is walkable or holds an
-     * agent (strategy.cpp:43-44); agents are reached but not passed (:50-53); the source is never re-entered (:83-90). */
-    POM_HD void build_map()
+    /* (a) FillRMap, strategy.cpp:59-93: which cells get a distance.  A cell can be entered if it is walkable or holds an agent
+     * (:43-44); the search continues only through walkable cells, agents are reached but not passed (:50-53). */
+    POM_HD void forward_reach()
     {
-        PomCells agents, open;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            agents.w[k] = p.setw(4 + k);
-            open.w[k] = p.setw(k) | agents.w[k];
-        }
-        const int src = sy * POM_N + sx;
-        open.remove(src);
-        PomCells front[4];
-        /* level 1: the source's own neighbours, claimed in the order DOWN, UP, RIGHT, LEFT */
-        const int nx[4] = {sx, sx, sx + 1, sx - 1}, ny[4] = {sy + 1, sy - 1, sy, sy};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            first[k] = PomCells::zero();
-            const int n = ny[k] * POM_N + nx[k];
-            if (!oob(nx[k], ny[k]) && open.has(n)) {
-                first[k].add(n);
-                open.remove(n);
-            }
-            front[k] = first[k].minus(agents);
-        }
+        PomCells front = PomCells::zero();
+        front.add(sy * POM_N + sx);
+        all = PomCells::zero();
         POM_NOUNROLL
         for (int level = 0; level < POM_CELLS; level++) {
-            int grew = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { /* priority = label order: the smallest first step wins a cell */
-                const PomCells got = front[k].neighbours() & open;
-                open = open.minus(got);
-                first[k] = first[k] | got;
-                front[k] = got.minus(agents);
-                grew |= got.any();
-            }
-            if (!grew) break;
+            const PomCells nb = front.neighbours().minus(all);
+            const PomCells grown = nb & walk;
+            all = all | grown | (nb & agents);
+            front = grown;
+            if (!grown.any()) break;
         }
     }
-    POM_HD int reached(int c) const { return first[0].has(c) | first[1].has(c) | first[2].has(c) | first[3].has(c); }
-    POM_HD int move_towards(int tx, int ty) const /* MoveTowardsPosition, strategy.cpp:99-121 */
+    /* (b) MoveTowardsPosition, strategy.cpp:99-121, for target (tx, ty) != source: the Move of the first step, IDLE if the
+     * search never reached the target.  Backwards from the target through walkable cells; the first level that touches walkable
+     * neighbours of the source decides, DOWN before UP before RIGHT before LEFT (the order FillRMap tries them in). */
+    POM_HD int move_towards(int tx, int ty) const
     {
-        const int c = ty * POM_N + tx;
-        if (first[0].has(c)) return POM_MOVE_DOWN;
-        if (first[1].has(c)) return POM_MOVE_UP;
-        if (first[2].has(c)) return POM_MOVE_RIGHT;
-        if (first[3].has(c)) return POM_MOVE_LEFT;
+        const int t = ty * POM_N + tx;
+        const int nx[4] = {sx, sx, sx + 1, sx - 1}, ny[4] = {sy + 1, sy - 1, sy, sy};
+        const int mvk[4] = {POM_MOVE_DOWN, POM_MOVE_UP, POM_MOVE_RIGHT, POM_MOVE_LEFT};
+        int found = POM_MOVE_IDLE, enterable = walk.has(t) | agents.has(t);
+        PomCells gates = PomCells::zero(); /* the source's walkable neighbours */
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            if (oob(nx[k], ny[k])) continue;
+            const int n = ny[k] * POM_N + nx[k];
+            if (n == t && enterable) found = mvk[k]; /* the target is next to me */
+            if (walk.has(n)) gates.add(n);
+        }
+        if (found == POM_MOVE_IDLE && enterable && gates.any()) {
+            PomCells seen = PomCells::zero(), front = PomCells::zero();
+            seen.add(t);
+            front.add(t);
+            POM_NOUNROLL
+            for (int level = 0; level < POM_CELLS; level++) {
+                front = front.neighbours().minus(seen) & walk;
+                if (!front.any()) break;
+                seen = seen | front;
+                const PomCells hit = front & gates;
+                if (hit.any()) {
+#pragma unroll
+                    for (int k = 3; k >= 0; k--)
+                        if (!oob(nx[k], ny[k]) && hit.has(ny[k] * POM_N + nx[k])) found = mvk[k];
+                    break;
+                }
+            }
+        }
+        if (found != POM_MOVE_IDLE) return found;
         /* unreached target: its map entry is 0, i.e. "distance 0, predecessor cell 0".  The reference takes cell 0 for the
          * source if the agent stands there and answers by comparing coordinates (:107-113); otherwise IDLE (:115-118) */
         if (sx == 0 && sy == 0) {
@@ -245,36 +317,45 @@ struct PomSimplePolicy {
         }
         return POM_MOVE_IDLE;
     }
-    POM_HD int move_towards_safe_place(int radius) /* strategy.cpp:123-140: the window's upper bounds are `radius` (sic) */
+    /* MoveTowardsSafePlace, strategy.cpp:123-140.  The reference scans y from sy-radius while y < radius, x from sx-radius while
+     * x < radius (sic: the upper bounds are `radius`, not origin + radius), skips cells off the board or further than `radius`
+     * in Manhattan distance, and takes the first reachable cell that passes _safe_condition.  Scan order = ascending cell index,
+     * so: window set (one run of cells per row) & reachable & safe, lowest member. */
+    POM_HD int safe_place(int radius) /* the cell MoveTowardsSafePlace heads for, -1 if none */
     {
-        const int y0 = sy - radius < 0 ? 0 : sy - radius, y1 = radius < POM_N ? radius : POM_N;
-        const int x0 = sx - radius < 0 ? 0 : sx - radius, x1 = radius < POM_N ? radius : POM_N;
+        const int lim = radius < POM_N ? radius : POM_N; /* exclusive upper bound of x and of y */
+        PomCells win = PomCells::zero();
+        const int y0 = sy - radius < 0 ? 0 : sy - radius;
         POM_NOUNROLL
-        for (int y = y0; y < y1; y++) {
-            POM_NOUNROLL
-            for (int x = x0; x < x1; x++) {
-                const int dx_ = x - sx, dy_ = y - sy;
-                if ((dx_ < 0 ? -dx_ : dx_) + (dy_ < 0 ? -dy_ : dy_) > radius) continue;
-                if (reached(y * POM_N + x) && safe(in_danger(x, y), 2)) return move_towards(x, y);
-            }
+        for (int y = y0; y < lim; y++) {
+            const int dy_ = y - sy;
+            const int rem = radius - (dy_ < 0 ? -dy_ : dy_);
+            if (rem < 0) continue;
+            const int x0 = sx - rem < 0 ? 0 : sx - rem;
+            const int x1 = sx + rem < lim - 1 ? sx + rem : lim - 1;
+            if (x0 <= x1) win.add_range(y * POM_N + x0, x1 - x0 + 1);
         }
-        return POM_MOVE_IDLE;
+        PomCells safe_cells;
+#pragma unroll
+        for (int k = 0; k < 4; k++) safe_cells.w[k] = p.setw(8 + k);
+        return (win & all & safe_cells).lowest();
     }
     POM_HD int manhattan_to(int j) const
     {
         const int dx_ = ag_x(E.a0[j]) - sx, dy_ = ag_y(E.a0[j]) - sy;
         return (dx_ < 0 ? -dx_ : dx_) + (dy_ < 0 ? -dy_ : dy_);
     }
-    POM_HD int move_towards_enemy(int radius) /* strategy.cpp:165-192 */
+    POM_HD int enemy_cell(int radius) const /* the cell MoveTowardsEnemy heads for (strategy.cpp:165-192), -1 if none */
     {
+        int c = -1;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 3; j >= 0; j--) {
             const int av = E.a0[j];
             if ((ag_x(av) == sx && ag_y(av) == sy) || ag_dead(av)) continue;
             if (manhattan_to(j) > radius) continue;
-            return move_towards(ag_x(av), ag_y(av));
+            c = ag_y(av) * POM_N + ag_x(av);
         }
-        return POM_MOVE_IDLE;
+        return c;
     }
     POM_HD int adjacent_enemy(int distance) const /* IsAdjacentEnemy, strategy.cpp:297-313 */
     {
@@ -329,6 +410,7 @@ struct PomSimplePolicy {
     }
     POM_HD int one_safe_step(int draw) /* the common tail of _Decide and _MoveSafeOneSpace, simple_agent.cpp:37-48,105-121 */
     {
+        POM_DUP(5, (mq_set_count(0), safe_directions(), sort_directions()), m1);
         mq_set_count(0);
         safe_directions();
         sort_directions();
@@ -340,28 +422,46 @@ struct PomSimplePolicy {
         const int av = sel4(id, E.a0), a1v = sel4(id, E.a1);
         const int danger = in_danger(sx, sy);
         const int can_bomb = pom_sext8((uint32_t)av >> 16) < pom_sext16((uint32_t)a1v);
-        const int adj1 = adjacent_enemy(1), near = adjacent_enemy(7), looping = has_rp_loop();
-        /* The reachability map is read by MoveTowardsSafePlace (danger) and MoveTowardsEnemy (an enemy within 7, nothing more
-         * urgent); it has no other effect, so it is built only for those agents — and at ONE program point: built lazily
-         * inside the two branches, a wavefront would run the whole search twice under different lane masks. */
-        if (danger > 0 || (can_bomb && !adj1 && near && !looping)) build_map();
+        int adj1 = adjacent_enemy(1), near = adjacent_enemy(7), looping = has_rp_loop();
+        POM_DUP(6, (adj1 = adjacent_enemy(1) + 2 * adjacent_enemy(7) + 4 * has_rp_loop()), adj1);
+        POM_PSTAMP(POM_PP_PREDICATES);
+        /* Which cell, if any, does this decision want a path to?  In danger: the first safe reachable cell of the scan window
+         * (needs the reachable set); else, allowed to bomb, an enemy within 7 and nothing more urgent: that enemy.  The path
+         * question itself is then asked at ONE program point for both kinds of agents of the wavefront. */
+        int target = -1;
+        const int chasing = danger == 0 && can_bomb && !adj1 && near && !looping;
         if (danger > 0) {
-            const int mv = move_towards_safe_place(danger);
-            const int px = sx + mv_dx(mv), py = sy + mv_dy(mv);
-            if (walkable_at(px, py) && safe(in_danger(px, py), 2)) return mv;
-            return one_safe_step(draw);
+            POM_DUP(2, (forward_reach(), all.w[0] ^= all.w[1] ^ all.w[2] ^ all.w[3]), all.w[0]);
+            forward_reach();
+            POM_DUP(3, target = safe_place(danger), target);
+            target = safe_place(danger);
+        } else if (chasing) {
+            target = enemy_cell(7);
         }
-        if (can_bomb) {
-            if (adj1) return POM_MOVE_BOMB;
-            if (near && looping) return draw % 4;
-            if (near) {
-                const int mv = move_towards_enemy(7);
-                const int px = sx + mv_dx(mv), py = sy + mv_dy(mv);
-                if (walkable_at(px, py) && safe(in_danger(px, py), 5)) return mv;
-            }
-            if (adjacent_wood()) return POM_MOVE_BOMB;
+        POM_PSTAMP(POM_PP_TARGET);
+        int mv = POM_MOVE_IDLE;
+        if (target >= 0) {
+            const int ty = target / POM_N;
+            POM_DUP(4, mv = move_towards(target - ty * POM_N, ty), mv);
+            mv = move_towards(target - ty * POM_N, ty);
         }
-        return one_safe_step(draw);
+        POM_PSTAMP(POM_PP_PATH);
+        /* the three ways out of _Decide that do not end in _MoveSafeOneSpace's tail; everything else falls through to it, at
+         * one program point (three inlined copies under three lane masks would cost the wavefront three times) */
+        const int px = sx + mv_dx(mv), py = sy + mv_dy(mv);
+        const int step_ok = walkable_at(px, py);
+        const int d_next = step_ok ? in_danger(px, py) : 0;
+        int out = -1;
+        if (danger > 0) {
+            if (step_ok && safe(d_next, 2)) out = mv;
+        } else if (can_bomb) {
+            if (adj1) out = POM_MOVE_BOMB;
+            else if (near && looping) out = draw % 4;
+            else if (near && step_ok && safe(d_next, 5)) out = mv;
+            else if (adjacent_wood()) out = POM_MOVE_BOMB;
+        }
+        if (out < 0) out = one_safe_step(draw);
+        return out;
     }
     POM_HD int act(int draw) /* SimpleAgent::act, simple_agent.cpp:123-137 */
     {
@@ -376,6 +476,7 @@ struct PomSimplePolicy {
         m0 = (m0 & ~(0xFFu << (8 * slot))) | ((uint32_t)key << (8 * slot));
         cnt++;
         m1 = (m1 & ~31u) | (uint32_t)idx | ((uint32_t)cnt << 2);
+        POM_PSTAMP(POM_PP_TAIL);
         return mv;
     }
 };

@@ -8,19 +8,19 @@
 #include "pom_policy_body.h"
 
 struct PolicyArrays {
-    uint16_t cells[122];
+    uint16_t cells[128];
     int bombs[20];
-    int dmap[POM_CELLS];
-    uint32_t sets[8];
+    int dmap[128];
+    uint32_t sets[12];
     int who; /* which of the env's four lanes is executing */
     int member() const { return who; }
     int danger(int c) const { return dmap[c]; }
     void danger_init(int c) { dmap[c] = POM_DANGER_NONE; }
     void danger_min(int c, int t) { dmap[c] = t < dmap[c] ? t : dmap[c]; }
     uint32_t setw(int k) const { return sets[k]; }
-    void set_or(int k, uint32_t bits) { sets[k] |= bits; }
-    void set_zero(int k) { sets[k] = 0; }
+    void set_put(int k, uint32_t bits) { sets[k] = bits; }
     int cell(int c) const { return cells[c]; }
+    uint32_t board_word(int k) const { return (uint32_t)cells[2 * k] | ((uint32_t)cells[2 * k + 1] << 16); }
     int bomb(int s) const { return bombs[s]; }
 };
 
@@ -38,6 +38,11 @@ int pom_emul_simple_act(const void* state_1004, int id, int32_t* mem16, int draw
         st.cells[2 * r] = (uint16_t)(rec[POM_REC_BOARD + r] & 0xFFFF);
         st.cells[2 * r + 1] = (uint16_t)(rec[POM_REC_BOARD + r] >> 16);
     }
+    for (int r = 61; r < 64; r++) { /* dwords 61..63 of the record follow the board in the tile: the body must mask them */
+        st.cells[2 * r] = (uint16_t)(rec[r] & 0xFFFF);
+        st.cells[2 * r + 1] = (uint16_t)(rec[r] >> 16);
+    }
+    for (int c = POM_CELLS; c < 128; c++) st.dmap[c] = (c * 7) % 3; /* rows past the map: arbitrary */
     for (int k = 0; k < 20; k++) st.bombs[k] = (int)rec[POM_REC_BOMBS + k];
     PomPolicyEnv E;
     for (int i = 0; i < 4; i++) {
@@ -54,6 +59,7 @@ int pom_emul_simple_act(const void* state_1004, int id, int32_t* mem16, int draw
     /* on the device the env's four lanes do this together, phase by phase */
     for (st.who = 0; st.who < 4; st.who++) pom_policy_prepare_clear(st);
     for (st.who = 0; st.who < 4; st.who++) pom_policy_prepare_fill(st, E);
+    for (st.who = 0; st.who < 4; st.who++) pom_policy_prepare_safe(st);
     st.who = id;
     PomSimplePolicy<PolicyArrays> pol(st, E, id, m0, m1);
     const int mv = pol.act(draw);
