@@ -125,9 +125,34 @@ int pom_batch_profile_read(PomBatch* h, double* mean_ms, int64_t* launches);
 /* how a step is issued: envs per wavefront, lanes per env and kernel launches (sub-batches) per step */
 int pom_batch_launch_shape(PomBatch* h, int32_t* envs_per_wave, int32_t* lanes_per_env, int32_t* launches_per_step);
 
+/* the hipStream_t the handle's work is ordered on (the one given at creation, or the library's own), so that a caller can
+ * order its own device work against steps and observations with events instead of pom_batch_sync */
+int pom_batch_stream(PomBatch* h, void** stream);
+
 /* zero-copy view for device-side consumers (policies, observation kernels): SoA records,
  * dword d of env e at base[d * n_pad + e]; layout in pomcpp_amd/csrc/pom_packed.h */
 int pom_batch_device_view(PomBatch* h, void** base, int64_t* n_pad, int32_t* rec_dwords);
+
+/*
+ * Observation export: the current state of every env as dense planes for a training loop, written by one
+ * kernel straight into caller-owned DEVICE memory (e.g. a torch tensor's data_ptr) on the handle's stream.  The reference has
+ * no such function; the planes restate what its agents read off a State (Item codes and IS_* helpers bboard.hpp:54-109, Bomb
+ * accessors :261-335, FLAME_ID :98-101, AgentInfo :228-245), one value per cell, row-major [y][x]:
+ *    0 passage   1 rigid   2 wood (any flag)   3 Item::BOMB   4 flames   5 extra-bomb   6 incr-range   7 kick      (0 / 1)
+ *    8..11       the cell shows agent 0..3 (per_agent: 8 = the viewer, 9..11 = agents id+1, id+2, id+3 mod 4)      (0 / 1)
+ *    12 13 14    BMB_STRENGTH, BMB_TIME, BMB_DIR of the first live bomb in queue order on the cell (State::GetBomb order,
+ *                bboard.cpp:277-287); also set under an agent, where the board shows no bomb
+ *    15          timeLeft (clamped to 0..255) of the first live flame whose centre is the cell's FLAME_ID, on flame cells
+ * planes:  [n][16][11][11] (per_agent = 0) or [n][4][16][11][11] (per_agent = 1: dead agents' views are written too), of
+ *          uint8, IEEE half or float (all values are small integers, exact in each).
+ * agent_attrs (nullable): int32 [n][4][8] = x, y, alive, ammo (maxBombCount - bombCount), bombCount, maxBombCount,
+ *          bombStrength, canKick.   env_attrs (nullable): int32 [n][4] = timeStep, aliveAgents, status (1 done | 2 draw |
+ *          4 timed out), winner (-1 = none) — the values pom_batch_status reports.
+ */
+enum { POM_OBS_U8 = 0, POM_OBS_F16 = 1, POM_OBS_F32 = 2 };
+enum { POM_OBS_PLANES = 16, POM_OBS_AGENT_ATTRS = 8, POM_OBS_ENV_ATTRS = 4 };
+int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_agent, int32_t* agent_attrs_dev,
+                      int32_t* env_attrs_dev);
 
 /* bboard::Step for a single host State on the GPU (a batch of one, device 0): the literal drop-in */
 int pom_step(void* state_1004, const int32_t moves[4]);

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Optional
 
 import numpy as np
@@ -56,6 +57,13 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch-ROCm wheels carry their own HIP runtime.  A process that is going to use both (observe(), bench.py) must load
+    # torch's first so that this library binds to the same runtime; the other order leaves torch without a device.
+    if "torch" not in sys.modules and not os.environ.get("POM_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     path = library_path()
     if not os.path.exists(path):
         raise ImportError(
@@ -69,6 +77,8 @@ def load_library() -> C.CDLL:
     lib.pom_batch_destroy.argtypes = [P]
     lib.pom_batch_size.argtypes = [P]
     lib.pom_batch_size.restype = I64
+    lib.pom_batch_observe.argtypes = [P, VP, I32, I32, VP, VP]
+    lib.pom_batch_stream.argtypes = [P, C.POINTER(C.c_void_p)]
     lib.pom_batch_upload.argtypes = [P, VP, I64, I64]
     lib.pom_batch_download.argtypes = [P, VP, I64, I64]
     lib.pom_batch_snapshot.argtypes = [P]
@@ -119,6 +129,7 @@ class BatchEnvironment:
         self._lib = load_library()
         self._h = C.c_void_p()
         self.n = int(n_envs)
+        self.device = int(device)
         o = _Options(C.sizeof(_Options), device, stream, mode, int(auto_reset), max_steps, env_offset, envs_per_wave, streams,
                      lanes_per_env, 0)
         _check(self._lib, self._lib.pom_batch_create(C.byref(self._h), self.n, C.byref(o)))
@@ -213,6 +224,42 @@ class BatchEnvironment:
 
     def get_winner(self) -> np.ndarray:
         return self.status()["winner"]
+
+    # ---- observation export ---------------------------------------------------------
+    def observe(self, per_agent: bool = False, dtype: str = "uint8", attrs: bool = True, out=None):
+        """Planes of every env as torch tensors on the handle's device, written by one kernel on the handle's stream
+        (pom_batch_observe; plane list in include/pom_batch.h).  Returns (planes, agent_attrs, env_attrs): planes
+        [n,16,11,11] or [n,4,16,11,11]; agent_attrs int32 [n,4,8]; env_attrs int32 [n,4] (None, None if attrs=False).
+        `out` reuses a planes tensor from an earlier call.  torch is only the owner of the device memory here."""
+        import torch
+        kinds = {"uint8": (0, torch.uint8), "float16": (1, torch.float16), "float32": (2, torch.float32)}
+        if dtype not in kinds:
+            raise ValueError(f"dtype must be one of {sorted(kinds)}")
+        code, tdt = kinds[dtype]
+        dev = torch.device("cuda", self.device)
+        shape = (self.n, 4, 16, 11, 11) if per_agent else (self.n, 16, 11, 11)
+        if out is None:
+            out = torch.empty(shape, dtype=tdt, device=dev)
+        elif tuple(out.shape) != shape or out.dtype != tdt or not out.is_contiguous() or out.device != dev:
+            raise ValueError("out does not match the requested view")
+        a_attrs = torch.empty((self.n, 4, 8), dtype=torch.int32, device=dev) if attrs else None
+        e_attrs = torch.empty((self.n, 4), dtype=torch.int32, device=dev) if attrs else None
+        # the kernel runs on the handle's stream, the tensors live on torch's current stream: order the two with events
+        mine, theirs = torch.cuda.ExternalStream(self.stream_handle(), device=dev), torch.cuda.current_stream(dev)
+        if mine.cuda_stream != theirs.cuda_stream:
+            mine.wait_stream(theirs)
+        _check(self._lib, self._lib.pom_batch_observe(self._h, out.data_ptr(), code, int(per_agent),
+                                                      a_attrs.data_ptr() if attrs else None,
+                                                      e_attrs.data_ptr() if attrs else None))
+        if mine.cuda_stream != theirs.cuda_stream:
+            theirs.wait_stream(mine)
+        return out, a_attrs, e_attrs
+
+    def stream_handle(self) -> int:
+        """the hipStream_t (as an integer) this handle's work is ordered on"""
+        s = C.c_void_p()
+        _check(self._lib, self._lib.pom_batch_stream(self._h, C.byref(s)))
+        return s.value or 0
 
     # ---- counters / plumbing ------------------------------------------------------------------------
     def counters(self) -> np.ndarray:

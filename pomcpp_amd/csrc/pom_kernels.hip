@@ -434,6 +434,175 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
 #endif
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Observation export (row f4, pom_batch.h pom_batch_observe).  A wavefront takes a tile of 16 envs into LDS as the tick does,
+ * then four envs at a time: zero a 4 x 1936-byte staging area, scatter one byte per cell / bomb (each cell sets exactly one
+ * of the planes 0..11), and stream the area out — for uint8 global views a straight 16-byte copy, fully coalesced; other
+ * element types and the per-agent plane order are a byte gather with conversion.  HBM-write-bound: 1936 B x elements per env.
+ * ------------------------------------------------------------------------------------------- */
+enum { OBS_ENV_BYTES = POM_OBS_PLANES * POM_CELLS, OBS_PASS_ENVS = 4 };
+static_assert(OBS_ENV_BYTES % 16 == 0, "an env's planes are a whole number of 16-byte stores");
+
+struct ObserveParams {
+    const uint32_t* state;
+    int64_t n, n_pad, block0;
+    void* planes;
+    int32_t* agent_attrs;
+    int32_t* env_attrs;
+    int32_t dtype, per_agent;
+};
+
+__device__ __forceinline__ int obs_plane_of(int code) /* which of the planes 0..11 a cell code sets, -1 = none (fog, ...) */
+{
+    if (code == 0) return 0;
+    if (code == 1) return 1;
+    if (pc_is_wood(code)) return 2;
+    if (code == POM_C_BOMB) return 3;
+    if (pc_is_flame(code)) return 4;
+    if (pc_is_powerup(code)) return code - 1; /* 6, 7, 8 -> 5, 6, 7 */
+    if (pc_is_agent(code)) return 8 + (code & 3);
+    return -1;
+}
+
+template <class T>
+__device__ __forceinline__ T obs_convert(uint32_t v);
+template <>
+__device__ __forceinline__ uint8_t obs_convert<uint8_t>(uint32_t v) { return (uint8_t)v; }
+template <>
+__device__ __forceinline__ _Float16 obs_convert<_Float16>(uint32_t v) { return (_Float16)(float)v; }
+template <>
+__device__ __forceinline__ float obs_convert<float>(uint32_t v) { return (float)v; }
+
+/* the generic way out of the staging area: element type T, `views` plane orders per env */
+template <class T>
+__device__ __forceinline__ void obs_gather_out(const ObserveParams& p, const uint8_t* stage_b, int64_t e0, int lane)
+{
+    const int views = p.per_agent ? 4 : 1;
+    constexpr int GROUPS = OBS_ENV_BYTES / 4; /* 4 elements per lane and store */
+    T* out = reinterpret_cast<T*>(p.planes);
+    POM_NOUNROLL
+    for (int g = lane; g < OBS_PASS_ENVS * views * GROUPS; g += 64) {
+        const int ev = g / GROUPS, gi = g - ev * GROUPS; /* (env, view) pair and group within it */
+        const int ei = p.per_agent ? ev >> 2 : ev, a = p.per_agent ? ev & 3 : 0;
+        if (e0 + ei >= p.n) continue;
+        T v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int el = 4 * gi + k, pl = el / POM_CELLS, off = el - pl * POM_CELLS;
+            const int src = (pl >= 8 && pl < 12) ? 8 + ((pl - 8 + a) & 3) : pl;
+            v[k] = obs_convert<T>(stage_b[ei * OBS_ENV_BYTES + src * POM_CELLS + off]);
+        }
+        T* dst = out + ((e0 + ei) * views + a) * (int64_t)OBS_ENV_BYTES + 4 * gi;
+        struct alignas(4 * sizeof(T)) Pack { T v[4]; };
+        *reinterpret_cast<Pack*>(dst) = Pack{{v[0], v[1], v[2], v[3]}};
+    }
+}
+
+__global__ __launch_bounds__(64) void pom_observe_kernel(ObserveParams p)
+{
+    __shared__ uint32_t tile[POM_REC_DWORDS * 16];
+    __shared__ uint4 stage[OBS_PASS_ENVS * OBS_ENV_BYTES / 16];
+    const int lane = threadIdx.x;
+    const int64_t np = p.n_pad;
+    int64_t tile_local;
+    {
+        const int64_t b = blockIdx.x, nb = gridDim.x, q = nb / 8, r = nb % 8, x = b % 8;
+        tile_local = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
+    }
+    const int64_t tile_id = p.block0 + tile_local;
+    load_tile<16>(p.state + tile_id * 16 + (lane & 15), np, tile, lane >> 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint8_t* stage_b = reinterpret_cast<uint8_t*>(stage);
+    const uint16_t* tile_h = reinterpret_cast<const uint16_t*>(tile);
+
+    for (int q = 0; q < 16 / OBS_PASS_ENVS; q++) {
+        const int64_t e0 = tile_id * 16 + q * OBS_PASS_ENVS;
+        if (e0 >= p.n) break;
+        constexpr int VECS = OBS_PASS_ENVS * OBS_ENV_BYTES / 16; /* 484 */
+#pragma unroll
+        for (int i = 0; i < (VECS + 63) / 64; i++)
+            if (lane + 64 * i < VECS) stage[lane + 64 * i] = make_uint4(0, 0, 0, 0);
+        __syncthreads(); /* one wavefront per workgroup: orders the phases' LDS traffic, costs no wait */
+        /* cells: one byte each into the plane its code names; flame cells also look their flame up */
+#pragma unroll
+        for (int i = 0; i < (OBS_PASS_ENVS * POM_CELLS + 63) / 64; i++) {
+            const int idx = lane + 64 * i;
+            if (idx >= OBS_PASS_ENVS * POM_CELLS) break;
+            const int ei = idx / POM_CELLS, c = idx - ei * POM_CELLS, ec = q * OBS_PASS_ENVS + ei;
+            const int code = tile_h[(c >> 1) * 32 + 2 * ec + (c & 1)];
+            const int pl = obs_plane_of(code);
+            uint8_t* o = stage_b + ei * OBS_ENV_BYTES + c;
+            if (pl >= 0) o[pl * POM_CELLS] = 1;
+            if (pl == 4) {
+                const int id = (code & 0x3FFF) >> 3;
+                const uint32_t m = tile[POM_REC_META * 16 + ec], m2 = tile[POM_REC_META2 * 16 + ec];
+                const int fIdx = (int)(m >> 24), fCnt = (int)(m2 & 0xFF);
+                POM_NOUNROLL
+                for (int k = 0; k < fCnt && k < POM_Q; k++) {
+                    const uint32_t f = tile[(POM_REC_FLAMES + wrap20(fIdx + k)) * 16 + ec];
+                    if ((int)(f & 0xFF) + POM_N * (int)((f >> 8) & 0xFF) == id) {
+                        const int tl = pom_sext8(f >> 16);
+                        o[15 * POM_CELLS] = (uint8_t)(tl < 0 ? 0 : tl);
+                        break;
+                    }
+                }
+            }
+        }
+        /* bombs: the first live bomb on a cell speaks for it */
+#pragma unroll
+        for (int i = 0; i < (OBS_PASS_ENVS * POM_Q + 63) / 64; i++) {
+            const int idx = lane + 64 * i;
+            if (idx >= OBS_PASS_ENVS * POM_Q) break;
+            const int ei = idx / POM_Q, k = idx - ei * POM_Q, ec = q * OBS_PASS_ENVS + ei;
+            const uint32_t m = tile[POM_REC_META * 16 + ec];
+            const int bIdx = (int)((m >> 8) & 0xFF), bCnt = (int)((m >> 16) & 0xFF);
+            if (k >= bCnt) continue;
+            const int b = (int)tile[(POM_REC_BOMBS + wrap20(bIdx + k)) * 16 + ec];
+            int first = 1;
+            POM_NOUNROLL
+            for (int j = 0; j < k; j++) first &= pb_pos((int)tile[(POM_REC_BOMBS + wrap20(bIdx + j)) * 16 + ec]) != pb_pos(b);
+            if (!first || pb_x(b) >= POM_N || pb_y(b) >= POM_N) continue;
+            uint8_t* o = stage_b + ei * OBS_ENV_BYTES + pb_y(b) * POM_N + pb_x(b);
+            o[12 * POM_CELLS] = (uint8_t)pb_strength(b);
+            o[13 * POM_CELLS] = (uint8_t)pb_time(b);
+            o[14 * POM_CELLS] = (uint8_t)pb_dir(b);
+        }
+        /* out */
+        __syncthreads();
+        if (p.dtype == POM_OBS_U8 && !p.per_agent) {
+            uint4* out = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(p.planes) + e0 * OBS_ENV_BYTES);
+#pragma unroll
+            for (int i = 0; i < (VECS + 63) / 64; i++) {
+                const int idx = lane + 64 * i;
+                if (idx < VECS && e0 + idx / (OBS_ENV_BYTES / 16) < p.n) out[idx] = stage[idx];
+            }
+        } else if (p.dtype == POM_OBS_U8) {
+            obs_gather_out<uint8_t>(p, stage_b, e0, lane);
+        } else if (p.dtype == POM_OBS_F16) {
+            obs_gather_out<_Float16>(p, stage_b, e0, lane);
+        } else {
+            obs_gather_out<float>(p, stage_b, e0, lane);
+        }
+        __syncthreads();
+    }
+    /* attributes: lane -> (env lane/4, agent lane%4), 32 contiguous bytes each */
+    const int ec = lane >> 2, id = lane & 3;
+    const int64_t e = tile_id * 16 + ec;
+    if (e < p.n && p.agent_attrs) {
+        const uint32_t a0 = tile[(POM_REC_AGENTS + 2 * id) * 16 + ec], a1 = tile[(POM_REC_AGENTS + 2 * id + 1) * 16 + ec];
+        const int bc = pom_sext8(a0 >> 16), mx = pom_sext16(a1);
+        int4* o = reinterpret_cast<int4*>(p.agent_attrs + (e * 4 + id) * POM_OBS_AGENT_ATTRS);
+        o[0] = make_int4((int)(a0 & 0xFF), (int)((a0 >> 8) & 0xFF), (int)!((a0 >> 25) & 1), mx - bc);
+        o[1] = make_int4(bc, mx, (int)(a1 >> 16), (int)((a0 >> 24) & 1));
+    }
+    if (lane < 16 && tile_id * 16 + lane < p.n && p.env_attrs) {
+        const uint32_t m = tile[POM_REC_META * 16 + lane], st = (tile[POM_REC_META2 * 16 + lane] >> 8) & 0xFF;
+        const int status = (int)((st & POM_ST_DONE) ? 1 : 0) | (int)((st & POM_ST_DRAW) ? 2 : 0) | (int)((st & POM_ST_TIMEOUT) ? 4 : 0);
+        reinterpret_cast<int4*>(p.env_attrs)[tile_id * 16 + lane] =
+            make_int4((int)tile[POM_REC_TIMESTEP * 16 + lane], pom_sext8(m), status, (int)((st >> POM_ST_WINNER_SHIFT) & 7) - 1);
+    }
+}
+
 /* ---- boundary kernels ----------------------------------------------------------------------- */
 __global__ void pom_pack_kernel(const int32_t* __restrict__ aos, int64_t first, int64_t count, uint32_t* state, uint32_t* snap,
                                 int64_t np, int* first_bad)
@@ -998,6 +1167,41 @@ int pom_batch_sync(PomBatch* h)
     HIPCHK(hipSetDevice(h->device));
     if (int jr = join_parts(h)) return jr;
     HIPCHK(hipStreamSynchronize(h->stream));
+    return POM_OK;
+}
+
+int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_agent, int32_t* agent_attrs_dev,
+                      int32_t* env_attrs_dev)
+{
+    if (!h || !planes_dev || dtype < POM_OBS_U8 || dtype > POM_OBS_F32) return POM_E_ARG;
+    const int64_t esz = dtype == POM_OBS_U8 ? 1 : dtype == POM_OBS_F16 ? 2 : 4;
+    if (((uintptr_t)planes_dev & (4 * esz - 1)) || ((uintptr_t)agent_attrs_dev & 15) || ((uintptr_t)env_attrs_dev & 15) ||
+        (dtype == POM_OBS_U8 && !per_agent && ((uintptr_t)planes_dev & 15)))
+    {
+        snprintf(g_err, sizeof g_err, "pom_batch_observe: output pointers must be 16-byte aligned");
+        return POM_E_ARG;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
+    ObserveParams p;
+    p.state = h->state;
+    p.n = h->n;
+    p.n_pad = h->n_pad;
+    p.block0 = 0;
+    p.planes = planes_dev;
+    p.agent_attrs = agent_attrs_dev;
+    p.env_attrs = env_attrs_dev;
+    p.dtype = dtype;
+    p.per_agent = per_agent ? 1 : 0;
+    pom_observe_kernel<<<dim3((unsigned)((h->n + 15) / 16)), dim3(64), 0, h->stream>>>(p);
+    HIPCHK(hipGetLastError());
+    return POM_OK;
+}
+
+int pom_batch_stream(PomBatch* h, void** stream)
+{
+    if (!h || !stream) return POM_E_ARG;
+    *stream = (void*)h->stream;
     return POM_OK;
 }
 

@@ -1,0 +1,126 @@
+"""Observation export: pom_batch_observe against the numpy restatement oracle/pom_observe_oracle.py,
+bit-exact (uint8 / half / float hold the same small integers), through the C-ABI via the ctypes wrapper."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import pomcpp_amd as pa
+from pomcpp_amd.state import Item
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle():
+    spec = importlib.util.spec_from_file_location("pom_observe_oracle", os.path.join(ROOT, "oracle", "pom_observe_oracle.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_oracle_planes_on_a_hand_made_state():
+    """the restatement itself, on a state whose planes can be read off by eye"""
+    from pomcpp_amd.state import new_states
+    ob = _oracle()
+    s = new_states(1)
+    b = s["board"][0]
+    b[0, 0] = Item.AGENT0
+    b[2, 3] = Item.RIGID
+    b[4, 5] = Item.WOOD + 2
+    b[6, 6] = Item.BOMB
+    b[7, 1] = Item.KICK
+    b[9, 9] = Item.FLAMES + ((9 + 11 * 9) << 3) + 1
+    s["bombs_queue"][0, 0] = 6 + (6 << 4) + (1 << 8) + (3 << 12) + (7 << 16) + (4 << 20)
+    s["bombs_queue"][0, 1] = 0 + (0 << 4) + (0 << 8) + (2 << 12) + (9 << 16)       # under agent 0
+    s["bombs_queue"][0, 2] = 6 + (6 << 4) + (2 << 8) + (5 << 12) + (1 << 16)       # second bomb on (6,6): hidden
+    s["bombs_count"][0] = 3
+    s["flames_queue"][0, 0]["x"] = 9
+    s["flames_queue"][0, 0]["y"] = 9
+    s["flames_queue"][0, 0]["timeLeft"] = 3
+    s["flames_count"][0] = 1
+    s["agents"][0, 0]["bombCount"] = 1
+    pl, attrs, _ = ob.observe(s)
+    assert pl.shape == (1, 16, 11, 11) and pl.dtype == np.uint8
+    assert pl[0, 8, 0, 0] == 1 and pl[0, 1, 2, 3] == 1 and pl[0, 2, 4, 5] == 1 and pl[0, 3, 6, 6] == 1
+    assert pl[0, 7, 7, 1] == 1 and pl[0, 4, 9, 9] == 1 and pl[0, 15, 9, 9] == 3
+    assert (pl[0, 12, 6, 6], pl[0, 13, 6, 6], pl[0, 14, 6, 6]) == (3, 7, 4)
+    assert (pl[0, 12, 0, 0], pl[0, 13, 0, 0]) == (2, 9)
+    assert pl[0, :12].sum(axis=0).max() == 1 and pl[0, 0].sum() == 121 - 6
+    assert attrs[0, 0].tolist() == [0, 0, 1, 0, 1, 1, 1, 0]
+    v, _, _ = ob.observe(s, per_agent=True)
+    assert v.shape == (1, 4, 16, 11, 11) and v[0, 0, 8, 0, 0] == 1 and v[0, 1, 11, 0, 0] == 1 and v[0, 3, 9, 0, 0] == 1
+
+
+def _played_states(n, ticks, kind="ffa", seed=3):
+    from pomcpp_amd.batch import BatchEnvironment, MODE_ENV
+    env = BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=300)
+    env.make_game(pa.make_boards(n, seed=seed, kind=kind))
+    env.step_random(seed, 2 if kind == "stress" else 1, ticks=ticks)
+    return env
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,ticks", [("ffa", 200, 0), ("ffa", 1000, 57), ("stress", 777, 23), ("stress", 64, 5), ("ffa", 5, 120)])
+def test_planes_match_the_oracle(hip_lib, kind, n, ticks):
+    ob = _oracle()
+    env = _played_states(n, ticks, kind)
+    states = env.get_state()
+    want, want_attrs, want_env = ob.observe(states)
+    got, attrs, eattrs = env.observe()
+    assert got.shape == (n, 16, 11, 11)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(attrs.cpu().numpy(), want_attrs)
+    st = env.status()
+    e = eattrs.cpu().numpy()
+    assert np.array_equal(e[:, :2], want_env)
+    assert np.array_equal(e[:, 2] & 1, st["done"]) and np.array_equal((e[:, 2] >> 1) & 1, st["draw"]) and np.array_equal(e[:, 3], st["winner"])
+    # the stress boards must actually exercise the bomb / flame planes
+    if kind == "stress" and ticks > 10:
+        assert want[:, 12].any() and want[:, 14].any() and want[:, 15].any() and want[:, 4].any()
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per_agent", [False, True])
+@pytest.mark.parametrize("dtype", ["uint8", "float16", "float32"])
+def test_views_and_element_types(hip_lib, per_agent, dtype):
+    ob = _oracle()
+    env = _played_states(333, 40, "stress", seed=9)
+    want, _, _ = ob.observe(env.get_state(), per_agent=per_agent, dtype=getattr(np, dtype))
+    got, a, e = env.observe(per_agent=per_agent, dtype=dtype, attrs=False)
+    assert a is None and e is None
+    assert got.dtype.itemsize == np.dtype(dtype).itemsize
+    assert np.array_equal(got.cpu().numpy(), want)
+    again, _, _ = env.observe(per_agent=per_agent, dtype=dtype, attrs=False, out=got)
+    assert again.data_ptr() == got.data_ptr() and np.array_equal(again.cpu().numpy(), want)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_observation_follows_the_game(hip_lib):
+    """observe -> step -> observe on the stream the steps run on: planes always describe the state a download returns"""
+    ob = _oracle()
+    env = _played_states(4096 + 17, 0)
+    for t in range(6):
+        env.step_simple(11, 7)
+        got, _, _ = env.observe()
+        want, _, _ = ob.observe(env.get_state())
+        assert np.array_equal(got.cpu().numpy(), want), t
+    env.close()
+
+
+@pytest.mark.gpu
+def test_bad_arguments_are_refused(hip_lib):
+    import torch
+    from pomcpp_amd.batch import PomError
+    env = _played_states(64, 0)
+    buf = torch.empty(64 * 16 * 121 + 16, dtype=torch.uint8, device="cuda")
+    from pomcpp_amd.batch import _check
+    with pytest.raises(PomError):  # misaligned planes pointer
+        _check(env._lib, env._lib.pom_batch_observe(env._h, buf.data_ptr() + 1, 0, 0, None, None))
+    with pytest.raises(PomError):  # unknown element type
+        _check(env._lib, env._lib.pom_batch_observe(env._h, buf.data_ptr(), 7, 0, None, None))
+    with pytest.raises(ValueError):
+        env.observe(dtype="int64")
+    env.close()
