@@ -124,6 +124,9 @@ def main() -> None:
                     help="random: Move[4] from the counter stream (--dist); simple: the device SimpleAgent policy (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=0, help="sub-batches per step (0 = library default)")
+    ap.add_argument("--fresh-boards", action="store_true",
+                    help="boards drawn on the device (pom_batch_generate) and a new one per episode instead of the snapshot replay "
+                         "BASELINE's configs prescribe (SURVEY §8 f3)")
     ap.add_argument("--envs-per-wave", type=int, default=0)
     ap.add_argument("--lanes-per-env", type=int, default=0)
     args = ap.parse_args()
@@ -152,7 +155,9 @@ def main() -> None:
     dist_id = {"harmless": 0, "random": 1, "stress": 2}[args.dist]
     plan = shard_plan(rank, world, args.envs)
 
-    start = pa.make_boards(plan["n_envs"], seed=args.seed * 1000003 + rank, kind=args.kind)
+    if args.fresh_boards and args.kind != "ffa":
+        raise SystemExit("--fresh-boards draws ffa boards")
+    start = None if args.fresh_boards else pa.make_boards(plan["n_envs"], seed=args.seed * 1000003 + rank, kind=args.kind)
     # torch's default stream is handle 0, which the C-ABI reads as "create your own": run everything on an
     # explicit torch stream so the HIP events below bracket exactly the stream the kernels are launched on
     stream = torch.cuda.Stream(device=device)
@@ -160,8 +165,13 @@ def main() -> None:
     assert stream.cuda_stream != 0
     env = BatchEnvironment(plan["n_envs"], device=local_rank, mode=MODE_ENV, auto_reset=True, max_steps=args.max_steps,
                            env_offset=plan["first_env"], stream=stream.cuda_stream, streams=args.streams,
-                           envs_per_wave=args.envs_per_wave, lanes_per_env=args.lanes_per_env)
-    env.make_game(start)
+                           envs_per_wave=args.envs_per_wave, lanes_per_env=args.lanes_per_env,
+                           fresh_boards=args.fresh_boards, board_seed=args.seed)
+    if args.fresh_boards:
+        env.generate(args.seed)
+        start = env.get_state()  # for the CPU baseline leg and config 3
+    else:
+        env.make_game(start)
     counters = torch.zeros(4, dtype=torch.int64, device=device)
 
     def barrier() -> None:
@@ -185,16 +195,25 @@ def main() -> None:
         # of the process onto 4 hardware queues and parts that share a queue serialize (profiles/r01_streams.txt) — how many
         # are free depends on the process (torch, RCCL), so measure instead of guessing.  Results do not depend on the choice.
         tuned = {}
+        for k in (3, 2, 1):  # first touch of a sub-stream creates its hardware queue (~10 ms once): keep that out of the timings
+            env.set_streams(k)
+            for _ in range(5):
+                one_step()
+            env.sync()
         for k in (2, 3, 1):
             env.set_streams(k)
-            for _ in range(15):
-                one_step()
-            env.sync()
-            t_a = time.perf_counter()
-            for _ in range(60):
-                one_step()
-            env.sync()
-            tuned[k] = (time.perf_counter() - t_a) / 60 * 1e3
+            best_k = None
+            for _ in range(2):  # the better of two short runs: one stall must not decide the shape
+                for _ in range(10):
+                    one_step()
+                env.sync()
+                t_a = time.perf_counter()
+                for _ in range(40):
+                    one_step()
+                env.sync()
+                dt = (time.perf_counter() - t_a) / 40 * 1e3
+                best_k = dt if best_k is None else min(best_k, dt)
+            tuned[k] = best_k
         best = min(tuned, key=tuned.get)
         if world > 1:  # every rank must run the same shape: take the vote of the slowest rank's best
             votes = torch.tensor([tuned[1], tuned[2], tuned[3]], dtype=torch.float64, device=device)
@@ -272,7 +291,8 @@ def main() -> None:
                 "workload": f"{args.envs} concurrent 11x11 FFA envs per GPU, {args.kind} boards, "
                             + (f"uniform-{args.dist} Move[4] (RandomAgent distribution)" if args.policy == "random"
                                else "4x SimpleAgent policy on the device (act x4 + Step per env-step, as Environment::Step)")
-                            + f", auto-reset, {args.max_steps}-tick cap",
+                            + (", auto-reset onto a fresh device-generated board" if args.fresh_boards else ", auto-reset")
+                            + f", {args.max_steps}-tick cap",
                 "policy": args.policy,
                 "envs_per_gpu": args.envs, "global_envs": plan["global_envs"], "ticks_per_launch": tpl,
                 "envs_per_wave": epw, "lanes_per_env": lpe, "launches_per_step": parts,
@@ -282,7 +302,7 @@ def main() -> None:
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": f"pom_step_kernel<{epw}, {lpe}>", "step_ms": step_ms, "algorithmic_bytes_per_step": algo_bytes,
+                "kernel": f"pom_step_kernel<{epw}, {lpe}, {'true' if args.fresh_boards else 'false'}>", "step_ms": step_ms, "algorithmic_bytes_per_step": algo_bytes,
                 # one step = `launches_per_step` concurrent launches; per launch: bytes / mean duration (matches rocprofv3's AverageNs)
                 "launches_per_step": parts,
                 "launch": {"algorithmic_bytes": algo_bytes // parts, "ms": launch_ms, "timed_launches": n_launch,

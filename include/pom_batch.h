@@ -59,7 +59,10 @@ typedef struct PomBatchOptions {
                               one part's load/store overlaps the others' compute (results are identical) */
     int32_t lanes_per_env; /* 0 = default (4: a quad of adjacent lanes runs each env's tick and splits its order-free parts,
                               needs envs_per_wave 16); 1 = one lane per env */
-    int32_t reserved_;
+    int32_t fresh_boards;  /* with auto_reset: a finished env starts its next game on a newly generated board (pom_boardgen.h:
+                              board_seed, env_offset + env, games played) instead of replaying its snapshot; drawn on the
+                              device inside the tick, the host is not involved */
+    uint64_t board_seed;   /* seed of those boards; pom_batch_generate replaces it */
 } PomBatchOptions;
 
 typedef struct PomBatch PomBatch;
@@ -80,6 +83,12 @@ int pom_batch_upload(PomBatch* h, const void* states, int64_t first, int64_t cou
 int pom_batch_download(PomBatch* h, void* states, int64_t first, int64_t count);
 /* make the current device state the reset snapshot */
 int pom_batch_snapshot(PomBatch* h);
+/* start boards without the host: every env gets the board (board_seed, env_offset + env, episode 0) of pom_boardgen.h — the
+ * reference's InitState distribution (bboard.cpp:339-382: cells passage 5/7, rigid 1/7, wood 1/7, half the woods flagged,
+ * agents in the corners) — as its state and its reset snapshot, generated on the device; the agents' memory starts afresh */
+int pom_batch_generate(PomBatch* h, uint64_t board_seed);
+/* games started so far by envs [first, first+count) (0 = still the first one), uint32 each */
+int pom_batch_episodes(PomBatch* h, int64_t first, int64_t count, uint32_t* out);
 
 /* one tick with explicit moves: int32[n_envs][4], host or device memory */
 int pom_batch_step(PomBatch* h, const int32_t* moves_host);

@@ -41,7 +41,7 @@ class _Options(C.Structure):
         ("struct_size", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p),
         ("mode", C.c_int32), ("auto_reset", C.c_int32), ("max_steps", C.c_int32),
         ("env_offset", C.c_int64), ("envs_per_wave", C.c_int32), ("streams", C.c_int32),
-        ("lanes_per_env", C.c_int32), ("reserved_", C.c_int32),
+        ("lanes_per_env", C.c_int32), ("fresh_boards", C.c_int32), ("board_seed", C.c_uint64),
     ]
 
 
@@ -79,6 +79,8 @@ def load_library() -> C.CDLL:
     lib.pom_batch_size.restype = I64
     lib.pom_batch_observe.argtypes = [P, VP, I32, I32, VP, VP]
     lib.pom_batch_stream.argtypes = [P, C.POINTER(C.c_void_p)]
+    lib.pom_batch_generate.argtypes = [P, U64]
+    lib.pom_batch_episodes.argtypes = [P, I64, I64, VP]
     lib.pom_batch_upload.argtypes = [P, VP, I64, I64]
     lib.pom_batch_download.argtypes = [P, VP, I64, I64]
     lib.pom_batch_snapshot.argtypes = [P]
@@ -125,13 +127,13 @@ def step_one(state: np.ndarray, moves) -> None:
 class BatchEnvironment:
     def __init__(self, n_envs: int, device: int = 0, mode: int = MODE_ENV, auto_reset: bool = False,
                  max_steps: int = 0, env_offset: int = 0, stream: Optional[int] = None, envs_per_wave: int = 0,
-                 streams: int = 0, lanes_per_env: int = 0):
+                 streams: int = 0, lanes_per_env: int = 0, fresh_boards: bool = False, board_seed: int = 0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.n = int(n_envs)
         self.device = int(device)
         o = _Options(C.sizeof(_Options), device, stream, mode, int(auto_reset), max_steps, env_offset, envs_per_wave, streams,
-                     lanes_per_env, 0)
+                     lanes_per_env, int(fresh_boards), board_seed)
         _check(self._lib, self._lib.pom_batch_create(C.byref(self._h), self.n, C.byref(o)))
 
     def close(self) -> None:
@@ -158,6 +160,17 @@ class BatchEnvironment:
         _check(self._lib, self._lib.pom_batch_upload(self._h, st.ctypes.data, first, st.size))
 
     upload = make_game
+
+    def generate(self, board_seed: int) -> None:
+        """Start boards drawn on the device (pom_batch_generate, include/pom_boardgen.h): InitState's distribution, no host."""
+        _check(self._lib, self._lib.pom_batch_generate(self._h, board_seed))
+
+    def episodes(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        """games started so far per env (0 = still the first)"""
+        count = self.n - first if count is None else count
+        out = np.zeros(count, dtype=np.uint32)
+        _check(self._lib, self._lib.pom_batch_episodes(self._h, first, count, out.ctypes.data))
+        return out
 
     def get_state(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
         count = self.n - first if count is None else count

@@ -19,6 +19,7 @@
 #include <new>
 
 #include "pom_batch.h"
+#include "pom_boardgen_body.h"
 #include "pom_packed.h"
 #include "pom_policy_body.h"
 #include "pom_step_body.h"
@@ -109,10 +110,42 @@ struct StepParams {
     uint32_t tick0;
     int32_t dist, ticks, mode, auto_reset, max_steps;
     int64_t block0; /* this launch covers tiles block0 .. block0 + gridDim.x - 1 (sub-batch of a split step) */
+    uint32_t* episode;   /* games started so far per env (fresh boards: keys the next board) */
+    uint64_t board_seed;
+    int32_t fresh;       /* a restarting env gets the next board of pom_boardgen.h instead of its snapshot */
 #if defined(POM_DIAG)
     long long* diag; /* POM_PH_N accumulators per wavefront, diagnostic build only */
 #endif
 };
+
+/*
+ * One env's start board (pom_boardgen.h), drawn by the whole wavefront into column `col` (= &tile[env_in_wave]) of an
+ * [row][EPW] tile with ROWS rows.  `key` must be wave-uniform.  Lane l draws cells l and l+64; the two ballots of "wood" are
+ * the wood set, so the flag pass runs on uniform values (scalar unit) and only its few cell writes touch a lane.
+ */
+template <int EPW, int ROWS>
+__device__ __forceinline__ void pom_boardgen_wave(uint32_t* col, uint32_t key, int lane)
+{
+    uint16_t* cells = reinterpret_cast<uint16_t*>(col);
+    const uint32_t k0 = pom_board_cell_kind(key, lane);
+    cells[(lane >> 1) * (2 * EPW) + (lane & 1)] = (uint16_t)pom_board_cell_code(k0);
+    const int c1 = lane + 64;
+    uint32_t k1 = 0u;
+    if (c1 < POM_CELLS) {
+        k1 = pom_board_cell_kind(key, c1);
+        cells[(c1 >> 1) * (2 * EPW) + (c1 & 1)] = (uint16_t)pom_board_cell_code(k1);
+    }
+    const uint64_t w0 = __ballot(k0 == 2u), w1 = __ballot(k1 == 2u);
+    const int r = POM_REC_TIMESTEP + lane;
+    if (r < ROWS) col[r * EPW] = pom_fresh_row(r);
+    pom_board_flags(key, w0, w1, [&](int c, int code) {
+        if (lane == 0) cells[(c >> 1) * (2 * EPW) + (c & 1)] = (uint16_t)code;
+    });
+    if (lane < POM_AGENT_COUNT) {
+        const int c = pom_corner_cell(lane);
+        cells[(c >> 1) * (2 * EPW) + (c & 1)] = (uint16_t)(POM_C_AGENT | lane);
+    }
+}
 
 /*
  * HBM -> LDS without touching VGPRs: `global_load_lds_dword` takes a per-lane global address and writes LDS
@@ -170,7 +203,7 @@ __device__ __forceinline__ void lane_from_tile(PomLane& L, int& time_step, uint3
 #ifndef POM_QUAD_WAVES
 #define POM_QUAD_WAVES 3
 #endif
-template <int EPW, int G>
+template <int EPW, int G, bool FRESH>
 __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW == 32 ? 2 : 1)) void pom_step_kernel(StepParams p)
 {
     static_assert(G == 1 || (G == 4 && EPW == 16), "a quad per env needs 16 envs per wavefront");
@@ -208,7 +241,7 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW 
     long long c_steps = 0, c_episodes = 0, c_resets = 0, c_ub = 0;
 
     /* a finished env restarts from its snapshot: pick the source column per lane, one pass over the record */
-    bool reload_d = e_d < p.n && env_mode && p.auto_reset && ((col_d[POM_REC_META2 * np] >> 8) & POM_ST_DONE);
+    bool reload_d = e_d < p.n && env_mode && p.auto_reset && !FRESH && ((col_d[POM_REC_META2 * np] >> 8) & POM_ST_DONE);
     load_tile<EPW>(reload_d ? scol_d : col_d, np, tile, sub);
     c_resets += __popcll(__ballot(reload_d && sub == 0));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the DMA rows have landed (one wavefront per workgroup: no barrier) */
@@ -226,7 +259,29 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW 
 #endif
 
     for (int tk = 0; tk < p.ticks; tk++) {
-        if (tk > 0) {
+        if (FRESH) { /* a separate instantiation: the replay kernel carries none of this */
+            /* fresh boards: a finished env starts its next game on the board (board_seed, env, games played) of
+             * pom_boardgen.h, drawn into its tile column by the whole wavefront, one restarting env after the other —
+             * the one place, first tick included */
+            const bool reload = e < p.n && env_mode && p.auto_reset && (status & POM_ST_DONE) && runs;
+            uint64_t todo = __ballot(reload && owner);
+            while (todo) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)todo) - 1); /* an owner lane */
+                todo &= todo - 1;
+                const int ec_u = G == 1 ? src : src >> 2;
+                uint32_t ep = 0;
+                if (lane == src) {
+                    ep = p.episode[e] + 1u;
+                    p.episode[e] = ep;
+                }
+                ep = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)ep, src));
+                const uint32_t key = pom_board_key(p.board_seed, (uint32_t)(p.env_offset + tile_id * EPW + ec_u), ep);
+                pom_boardgen_wave<EPW, POM_REC_DWORDS>(tile + ec_u, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), lane);
+            }
+            asm volatile("" ::: "memory"); /* other lanes wrote this lane's column: no read of it may be scheduled earlier */
+            if (reload) lane_from_tile(L, time_step, status, t, EPW); /* the register-resident rows, from the new record */
+            c_resets += __popcll(__ballot(reload && owner));
+        } else if (tk > 0) {
             /* the lanes that move env el's rows need the verdict of the lane that owns env el */
             const int done_d = __shfl((int)(status & POM_ST_DONE), G == 1 ? el : 4 * el);
             reload_d = e_d < p.n && env_mode && p.auto_reset && done_d;
@@ -328,6 +383,9 @@ struct PolicyParams {
     uint64_t seed;
     uint32_t tick;
     int32_t mode, auto_reset;
+    const uint32_t* episode; /* fresh boards: a restarting env is judged on the board the tick will generate for it */
+    uint64_t board_seed;
+    int32_t fresh;
 #if defined(POM_DIAG)
     long long* diag; /* POM_PP_N accumulators per wavefront, diagnostic build only */
 #endif
@@ -355,7 +413,7 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
     const int64_t e_d = tile_id * 16 + el;
     const bool restart_d = e_d < p.n && env_mode && p.auto_reset && ((p.state[POM_REC_META2 * np + e_d] >> 8) & POM_ST_DONE);
     {
-        const uint32_t* g = (restart_d ? p.snap : p.state) + e_d + (int64_t)sub * np;
+        const uint32_t* g = (restart_d && !p.fresh ? p.snap : p.state) + e_d + (int64_t)sub * np;
 #pragma unroll 4
         for (int r0 = 0; r0 < POL_ROWS; r0 += 4) {
             dma_rows(g, tile + r0 * 16);
@@ -370,6 +428,19 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
     const bool restart = __shfl((int)restart_d, ec) != 0;
     if (restart) m0 = m1 = 0; /* a new game gets fresh agents */
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.fresh) { /* the same board the tick kernel is about to draw for a restarting env; the tick counts the episode */
+        uint64_t todo = __ballot(restart && id == 0 && e < p.n);
+        while (todo) {
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)todo) - 1);
+            todo &= todo - 1;
+            const int ec_u = src >> 2;
+            const uint32_t ep = p.episode[tile_id * 16 + ec_u] + 1u;
+            const uint32_t key = pom_board_key(p.board_seed, (uint32_t)(p.env_offset + tile_id * 16 + ec_u),
+                                               (uint32_t)__builtin_amdgcn_readfirstlane((int)ep));
+            pom_boardgen_wave<16, POL_ROWS>(tile + ec_u, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), lane);
+        }
+        asm volatile("" ::: "memory");
+    }
     const uint32_t* t = tile + ec;
     PomPolicyEnv E;
 #pragma unroll
@@ -603,6 +674,25 @@ __global__ __launch_bounds__(64) void pom_observe_kernel(ObserveParams p)
     }
 }
 
+/* every env's first board (episode 0) into its state and snapshot columns, through an LDS tile so that the records leave in
+ * the tick's coalesced row groups */
+__global__ __launch_bounds__(64) void pom_generate_kernel(uint32_t* state, uint32_t* snap, uint32_t* episode, int64_t n, int64_t np,
+                                                          int64_t env_offset, uint64_t board_seed)
+{
+    __shared__ uint32_t tile[POM_REC_DWORDS * 16];
+    const int lane = threadIdx.x;
+    const int64_t tile_id = blockIdx.x;
+    for (int ec = 0; ec < 16 && tile_id * 16 + ec < n; ec++)
+        pom_boardgen_wave<16, POM_REC_DWORDS>(tile + ec, pom_board_key(board_seed, (uint32_t)(env_offset + tile_id * 16 + ec), 0u), lane);
+    if (tile_id * 16 + lane < n && lane < 16) episode[tile_id * 16 + lane] = 0u;
+    __syncthreads();
+    const int el = lane & 15, sub = lane >> 4;
+    if (tile_id * 16 + el < n) {
+        store_tile<16>(state + tile_id * 16 + el, np, tile, sub, el);
+        store_tile<16>(snap + tile_id * 16 + el, np, tile, sub, el);
+    }
+}
+
 /* ---- boundary kernels ----------------------------------------------------------------------- */
 __global__ void pom_pack_kernel(const int32_t* __restrict__ aos, int64_t first, int64_t count, uint32_t* state, uint32_t* snap,
                                 int64_t np, int* first_bad)
@@ -708,6 +798,9 @@ struct PomBatch {
     uint32_t* snap = nullptr;
     int32_t* moves_dev = nullptr;   /* n_pad x 4 */
     uint32_t* agent_mem = nullptr;  /* SimpleAgent memory, [2][4 * n_pad], allocated on first use */
+    uint32_t* episode = nullptr;    /* games started per env (fresh boards) */
+    uint64_t board_seed = 0;
+    int fresh = 0;
     int32_t* staging = nullptr;     /* staging_envs x 251 dwords (AoS), also status scratch */
     int64_t staging_envs = 0;
     int64_t* wave_counters = nullptr;
@@ -766,6 +859,7 @@ int pom_batch_destroy(PomBatch* h)
     (void)hipFree(h->snap);
     (void)hipFree(h->moves_dev);
     (void)hipFree(h->agent_mem);
+    (void)hipFree(h->episode);
     (void)hipFree(h->staging);
     (void)hipFree(h->wave_counters);
     (void)hipFree(h->totals_dev);
@@ -865,6 +959,8 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
     h->auto_reset = o.auto_reset;
     h->max_steps = o.max_steps;
     h->env_offset = o.env_offset;
+    h->fresh = o.fresh_boards != 0;
+    h->board_seed = o.board_seed;
     h->staging_envs = h->n_pad < 16384 ? h->n_pad : 16384;
 #define ALLOC(ptr, bytes)                                              \
     do {                                                               \
@@ -898,12 +994,14 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
     ALLOC(h->wave_counters, (size_t)h->n_waves * POM_CNT_N * 8);
     ALLOC(h->totals_dev, POM_CNT_N * 8);
     ALLOC(h->first_bad, sizeof(int));
+    ALLOC(h->episode, (size_t)h->n_pad * 4);
 #undef ALLOC
     /* all-zero records are inert blank boards; padded envs are marked finished */
     hipError_t e1 = hipMemsetAsync(h->state, 0, rec_bytes, h->stream);
     hipError_t e2 = hipMemsetAsync(h->snap, 0, rec_bytes, h->stream);
     hipError_t e3 = hipMemsetAsync(h->moves_dev, 0, (size_t)h->n_pad * 16, h->stream);
     hipError_t e4 = hipMemsetAsync(h->wave_counters, 0, (size_t)h->n_waves * POM_CNT_N * 8, h->stream);
+    if (e4 == hipSuccess) e4 = hipMemsetAsync(h->episode, 0, (size_t)h->n_pad * 4, h->stream);
     hipError_t e5 = hipStreamSynchronize(h->stream);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
         set_err("initial memset", e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4 != hipSuccess ? e4 : e5);
@@ -949,6 +1047,7 @@ int pom_batch_upload(PomBatch* h, const void* states, int64_t first, int64_t cou
             HIPCHK(hipMemcpyAsync(h->first_bad, &big, sizeof big, hipMemcpyHostToDevice, h->stream));
         }
     }
+    HIPCHK(hipMemsetAsync(h->episode + first, 0, (size_t)count * 4, h->stream)); /* an uploaded state is episode 0 of its env */
     if (h->agent_mem) { /* uploaded envs start new games: fresh agents */
         HIPCHK(hipMemsetAsync(h->agent_mem + first * 4, 0, (size_t)count * 16, h->stream));
         HIPCHK(hipMemsetAsync(h->agent_mem + 4 * h->n_pad + first * 4, 0, (size_t)count * 16, h->stream));
@@ -1038,6 +1137,9 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
     p.mode = h->mode;
     p.auto_reset = h->auto_reset;
     p.max_steps = h->max_steps;
+    p.episode = h->episode;
+    p.board_seed = h->board_seed;
+    p.fresh = h->fresh;
 #if defined(POM_DIAG)
     if (!h->diag) {
         HIPCHK(hipMalloc((void**)&h->diag, (size_t)h->n_waves * POM_PH_N * 8));
@@ -1056,10 +1158,11 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
         const dim3 grid((unsigned)(b1 - b0));
         const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
         if (prof) HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_n], st));
-        if (h->epw == 64) pom_step_kernel<64, 1><<<grid, dim3(64), 0, st>>>(p);
-        else if (h->epw == 32) pom_step_kernel<32, 1><<<grid, dim3(64), 0, st>>>(p);
-        else if (h->quad) pom_step_kernel<16, 4><<<grid, dim3(64), 0, st>>>(p);
-        else pom_step_kernel<16, 1><<<grid, dim3(64), 0, st>>>(p);
+        const bool fresh = h->fresh && h->mode == POM_MODE_ENV && h->auto_reset;
+        if (h->epw == 64) fresh ? pom_step_kernel<64, 1, true><<<grid, dim3(64), 0, st>>>(p) : pom_step_kernel<64, 1, false><<<grid, dim3(64), 0, st>>>(p);
+        else if (h->epw == 32) fresh ? pom_step_kernel<32, 1, true><<<grid, dim3(64), 0, st>>>(p) : pom_step_kernel<32, 1, false><<<grid, dim3(64), 0, st>>>(p);
+        else if (h->quad) fresh ? pom_step_kernel<16, 4, true><<<grid, dim3(64), 0, st>>>(p) : pom_step_kernel<16, 4, false><<<grid, dim3(64), 0, st>>>(p);
+        else fresh ? pom_step_kernel<16, 1, true><<<grid, dim3(64), 0, st>>>(p) : pom_step_kernel<16, 1, false><<<grid, dim3(64), 0, st>>>(p);
         HIPCHK(hipGetLastError());
         if (prof) {
             HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_n + 1], st));
@@ -1198,6 +1301,30 @@ int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_
     return POM_OK;
 }
 
+int pom_batch_generate(PomBatch* h, uint64_t board_seed)
+{
+    if (!h) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
+    h->board_seed = board_seed;
+    pom_generate_kernel<<<dim3((unsigned)((h->n + 15) / 16)), dim3(64), 0, h->stream>>>(h->state, h->snap, h->episode, h->n, h->n_pad,
+                                                                                         h->env_offset, board_seed);
+    HIPCHK(hipGetLastError());
+    if (h->agent_mem) HIPCHK(hipMemsetAsync(h->agent_mem, 0, (size_t)h->n_pad * 32, h->stream)); /* new games: fresh agents */
+    return POM_OK;
+}
+
+int pom_batch_episodes(PomBatch* h, int64_t first, int64_t count, uint32_t* out)
+{
+    int rc = check_range(h, first, count);
+    if (rc || !out) return rc ? rc : POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
+    HIPCHK(hipMemcpyAsync(out, h->episode + first, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return POM_OK;
+}
+
 int pom_batch_stream(PomBatch* h, void** stream)
 {
     if (!h || !stream) return POM_E_ARG;
@@ -1284,6 +1411,9 @@ static int launch_policy(PomBatch* h, uint64_t seed)
     p.tick = (uint32_t)h->tick;
     p.mode = h->mode;
     p.auto_reset = h->auto_reset;
+    p.episode = h->episode;
+    p.board_seed = h->board_seed;
+    p.fresh = h->fresh;
 #if defined(POM_DIAG)
     if (!h->diag_pol) {
         HIPCHK(hipMalloc((void**)&h->diag_pol, (size_t)(h->n_pad / 16) * POM_PP_N * 8));

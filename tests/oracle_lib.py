@@ -47,6 +47,12 @@ class Oracle:
             lib.pom_oracle_simple_policy.argtypes = [VP, VP, I, C.c_uint64, I, I, VP, VP]
             lib.pom_oracle_run_simple.argtypes = [VP, VP, VP, I, I, C.c_uint64, I, I, I]
             lib.pom_oracle_run_simple.restype = C.c_int64
+            lib.pom_oracle_boardgen.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, VP]
+            lib.pom_oracle_boardgen.restype = None
+            lib.pom_oracle_run_random_fresh.argtypes = [VP, VP, I, I, C.c_uint64, C.c_uint64, I, I, I, I]
+            lib.pom_oracle_run_random_fresh.restype = C.c_int64
+            lib.pom_oracle_run_simple_fresh.argtypes = [VP, VP, VP, I, I, C.c_uint64, C.c_uint64, I, I, I]
+            lib.pom_oracle_run_simple_fresh.restype = C.c_int64
             Oracle._lib = lib
         self.lib = Oracle._lib
 
@@ -99,3 +105,24 @@ class Oracle:
         assert mems.dtype == np.int32 and mems.shape == (states.size, 4, 16)
         return int(self.lib.pom_oracle_run_simple(states.ctypes.data, initial.ctypes.data, mems.ctypes.data, states.size, ticks, seed,
                                                   first_env, tick0, max_steps))
+
+    # ---- start boards (oracle/pom_boardgen_oracle.c) ----
+    def boardgen(self, seed: int, envs, episodes) -> np.ndarray:
+        """the start State of (seed, env, episode) for each pair of the two equally long sequences"""
+        envs, episodes = np.asarray(envs, dtype=np.int64), np.asarray(episodes, dtype=np.int64)
+        out = np.zeros(envs.size, dtype=STATE_DTYPE)
+        for i in range(envs.size):
+            self.lib.pom_oracle_boardgen(seed, int(envs[i]), int(episodes[i]), out.ctypes.data + i * 1004)
+        return out
+
+    def run_random_fresh(self, states: np.ndarray, episodes: np.ndarray, ticks: int, seed: int, board_seed: int, first_env: int,
+                         tick0: int, dist: int, max_steps: int) -> int:
+        assert states.flags["C_CONTIGUOUS"] and episodes.dtype == np.int32 and episodes.shape == (states.size,)
+        return int(self.lib.pom_oracle_run_random_fresh(states.ctypes.data, episodes.ctypes.data, states.size, ticks, seed,
+                                                        board_seed, first_env, tick0, dist, max_steps))
+
+    def run_simple_fresh(self, states: np.ndarray, episodes: np.ndarray, mems: np.ndarray, ticks: int, seed: int, board_seed: int,
+                         first_env: int, tick0: int, max_steps: int) -> int:
+        assert mems.dtype == np.int32 and mems.shape == (states.size, 4, 16) and episodes.dtype == np.int32
+        return int(self.lib.pom_oracle_run_simple_fresh(states.ctypes.data, episodes.ctypes.data, mems.ctypes.data, states.size,
+                                                        ticks, seed, board_seed, first_env, tick0, max_steps))
