@@ -102,11 +102,35 @@ def cpu_baseline(start: np.ndarray, seed: int, dist_id: int, max_steps: int, bud
         th.join()
     wall = time.perf_counter() - t0
     steps = int(sum(totals))
-    return {
+    port = {
         "value": steps / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
         "sample": f"oracle/pom_oracle.c ({flags}), {cores} threads x {per_thread} envs of the same boards and move stream, "
                   f"{steps} env-steps in {wall:.1f} s",
     }
+    # The reference itself, where its prebuilt library travelled with the repo (oracle/_ref/, built in the container that holds
+    # /root/reference): the unmodified bboard::Step, -O3, timed in a child process (it has UB on reachable states; a guard skips
+    # those ticks, and a crash only costs this leg).
+    ref_lib = os.path.join(ORACLE_DIR, "_ref", "libpomref_bench.so")
+    if os.path.exists(ref_lib):
+        import tempfile
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                f = os.path.join(td, "boards.npy")
+                np.save(f, start[:cores * per_thread])
+                out = subprocess.run([sys.executable, os.path.join(ORACLE_DIR, "ref_baseline_run.py"), f, str(seed), str(dist_id),
+                                      str(max_steps), str(budget_s)], capture_output=True, text=True, timeout=budget_s * 4 + 60)
+            r = json.loads(out.stdout.strip().splitlines()[-1])
+            return {
+                "value": r["value"], "unit": "env-steps/s", "cores": r["cores"], "kind": "reference",
+                "sample": f"unmodified reference bboard::Step (oracle/_ref/libpomref_bench.so, g++ -O3), {r['cores']} threads x "
+                          f"{r['per_thread']} envs of the same boards and move stream, {r['steps']} env-steps in "
+                          f"{r['timed_s_per_thread']:.1f} s of reference time per thread ({r['skipped_ub_ticks']} ticks with reference UB "
+                          f"stepped by the restatement, untimed)",
+                "port": port,
+            }
+        except Exception as exc:  # the figure below is still a measured baseline
+            port["reference_leg"] = f"failed: {type(exc).__name__}"
+    return port
 
 
 def main() -> None:
