@@ -227,7 +227,11 @@ inline bool IsOutOfBounds(const Position& p) { return IsOutOfBounds(p.x, p.y); }
 // (environment.cpp:139-146); a dead agent's entry is IDLE.
 class BatchEnvironment {
 public:
-    explicit BatchEnvironment(int64_t n, int device = 0, bool autoReset = false, int maxSteps = 0) : n_(n), states_(size_t(n))
+    // freshBoards: with autoReset, a finished game restarts on a newly drawn board (InitState's distribution, bboard.cpp:339-382,
+    // generated on the device; include/pom_boardgen.h) instead of replaying the one handed to MakeGame
+    explicit BatchEnvironment(int64_t n, int device = 0, bool autoReset = false, int maxSteps = 0, bool freshBoards = false,
+                              uint64_t boardSeed = 0)
+        : n_(n), states_(size_t(n))
     {
         PomBatchOptions o{};
         o.struct_size = sizeof o;
@@ -235,6 +239,8 @@ public:
         o.mode = POM_MODE_ENV;
         o.auto_reset = autoReset;
         o.max_steps = maxSteps;
+        o.fresh_boards = freshBoards;
+        o.board_seed = boardSeed;
         pom_check(pom_batch_create(&h_, n, &o));
     }
     ~BatchEnvironment() { pom_batch_destroy(h_); }
@@ -243,6 +249,10 @@ public:
 
     int64_t Size() const { return n_; }
     void MakeGame(const State* start) { pom_check(pom_batch_upload(h_, start, 0, n_)); }
+    // MakeGame without the host: InitState for every game, drawn on the device (bboard.cpp:339-344)
+    void MakeGame(uint64_t boardSeed) { pom_check(pom_batch_generate(h_, boardSeed)); }
+    // Environment::Step with four agents::SimpleAgent per game, policy and tick both on the device (include/agents.hpp:55-76)
+    void StepSimpleAgents(uint64_t seed, int ticks = 1) { pom_check(pom_batch_step_simple(h_, seed, ticks)); }
     void Step(const Move* moves /* [n][AGENT_COUNT] */) { pom_check(pom_batch_step(h_, reinterpret_cast<const int32_t*>(moves))); }
     // ask `agents` (shared by all games) for moves on the current states, then step: Environment::Step
     void Step(const std::array<Agent*, AGENT_COUNT>& agents)

@@ -94,6 +94,35 @@ int main()
         REQUIRE(blown_up > n);  // the watchers planted strength-1 bombs and stepped only one cell away
         std::printf("batch: %d of %d games finished, %d watchers caught by their own bombs\n", finished, n, blown_up);
     }
+    {
+        /* no host in the loop: boards drawn on the device, SimpleAgents and tick on the device, a fresh board per game */
+        const int n = 256;
+        bboard::BatchEnvironment env(n, 0, /*autoReset*/ true, /*maxSteps*/ 60, /*freshBoards*/ true, /*boardSeed*/ 5);
+        env.MakeGame(uint64_t(5));
+        const bboard::State* st = env.GetStates();
+        int woods = 0, rigid = 0;
+        for (int e = 0; e < n; e++) {
+            REQUIRE(st[e].board[0][0] == bboard::Item::AGENT0 && st[e].board[10][10] == bboard::Item::AGENT0 + 2);
+            REQUIRE(st[e].aliveAgents == 4 && st[e].timeStep == 0 && st[e].agents[2].x == 10 && st[e].agents[2].y == 10);
+            for (int y = 0; y < 11; y++)
+                for (int x = 0; x < 11; x++) {
+                    woods += bboard::IS_WOOD(st[e].board[y][x]);
+                    rigid += st[e].board[y][x] == bboard::Item::RIGID;
+                }
+        }
+        REQUIRE(woods > n * 121 / 9 && woods < n * 121 / 5 && rigid > n * 121 / 9 && rigid < n * 121 / 5);  // 1/7 each
+        env.StepSimpleAgents(/*seed*/ 3, /*ticks*/ 150);
+        st = env.GetStates();
+        uint32_t episodes[256];
+        REQUIRE(pom_batch_episodes(env.Handle(), 0, n, episodes) == POM_OK);
+        int restarted = 0;
+        for (int e = 0; e < n; e++) {
+            restarted += episodes[e] >= 2;
+            REQUIRE(st[e].timeStep <= 60);
+        }
+        REQUIRE(restarted == n);  // 150 ticks under a 60-tick cap: every game is at least in its third round
+        std::printf("generated boards: %d woods, %d rigid cells in %d games; all restarted on fresh boards\n", woods, rigid, n);
+    }
     std::printf("dropin ok\n");
     return 0;
 }
