@@ -73,6 +73,13 @@ enum { POM_PP_LOAD = 0, POM_PP_PREPARE, POM_PP_PREDICATES, POM_PP_TARGET, POM_PP
 #else
 #define POM_DUP(k, stmt, out) ((void)0)
 #endif
+/* POM_LEVEL_STATS (host analysis builds only, scripts/flood_levels.cpp): how many levels the two floods of an act() ran */
+#if defined(POM_LEVEL_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+extern "C" int pom_stat_fwd, pom_stat_bwd;
+#define POM_COUNT_LEVEL(v) ((v)++)
+#else
+#define POM_COUNT_LEVEL(v) ((void)0)
+#endif
 
 /* Shared preparation, executed by all four lanes of an env.  The 121-bit sets are four words and the env has four lanes:
  * member m builds word m of every set (cells 32m .. 32m+31) with plain stores, from whole board dwords (two cells each).  The
@@ -266,6 +273,7 @@ struct PomSimplePolicy {
         all = PomCells::zero();
         POM_NOUNROLL
         for (int level = 0; level < POM_CELLS; level++) {
+            POM_COUNT_LEVEL(pom_stat_fwd);
             const PomCells nb = front.neighbours().minus(all);
             const PomCells grown = nb & walk;
             all = all | grown | (nb & agents);
@@ -296,6 +304,7 @@ struct PomSimplePolicy {
             front.add(t);
             POM_NOUNROLL
             for (int level = 0; level < POM_CELLS; level++) {
+                POM_COUNT_LEVEL(pom_stat_bwd);
                 front = front.neighbours().minus(seen) & walk;
                 if (!front.any()) break;
                 seen = seen | front;
