@@ -147,6 +147,7 @@ def main() -> None:
     ap.add_argument("--policy", default="random", choices=["random", "simple"],
                     help="random: Move[4] from the counter stream (--dist); simple: the device SimpleAgent policy (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config3", action="store_true", help="skip the SimpleAgent segment (profiling runs: one kernel shape only)")
     ap.add_argument("--streams", type=int, default=0, help="sub-batches per step (0 = library default)")
     ap.add_argument("--fresh-boards", action="store_true",
                     help="boards drawn on the device (pom_batch_generate) and a new one per episode instead of the snapshot replay "
@@ -278,7 +279,7 @@ def main() -> None:
     # by the device SimpleAgent policy, act x4 + Step per env-step as Environment::Step does.  200 untimed ticks first: games
     # last ~190 ticks under this policy, so the batch is then a steady mix of openings, mid-games and restarts.
     config3 = None
-    if world == 1 and args.policy == "random" and tpl == 1:
+    if world == 1 and args.policy == "random" and tpl == 1 and not args.no_config3:
         env.make_game(start)
         env.set_tick(0)
         env.step_simple(args.seed, 200)

@@ -9,6 +9,7 @@
  *   HBM (SoA records, pom_packed.h) -> LDS tile + VGPRs -> tick(s) -> HBM,
  * the AoS<->SoA pack / unpack at the boundary, status extraction and counters.
  */
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <climits>
@@ -1156,18 +1157,21 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
         hipStream_t st = h->parts == 1 ? h->stream : h->sub[k];
         p.block0 = b0;
         const dim3 grid((unsigned)(b1 - b0));
+        /* per-launch timing (pom_batch_profile): start / stop events attached to the dispatch itself, i.e. the kernel's own
+         * duration as a profiler reports it, not the stream's period (events recorded around a launch also time the gap) */
         const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
-        if (prof) HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_n], st));
+        hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
         const bool fresh = h->fresh && h->mode == POM_MODE_ENV && h->auto_reset;
-        if (h->epw == 64) fresh ? pom_step_kernel<64, 1, true><<<grid, dim3(64), 0, st>>>(p) : pom_step_kernel<64, 1, false><<<grid, dim3(64), 0, st>>>(p);
-        else if (h->epw == 32) fresh ? pom_step_kernel<32, 1, true><<<grid, dim3(64), 0, st>>>(p) : pom_step_kernel<32, 1, false><<<grid, dim3(64), 0, st>>>(p);
-        else if (h->quad) fresh ? pom_step_kernel<16, 4, true><<<grid, dim3(64), 0, st>>>(p) : pom_step_kernel<16, 4, false><<<grid, dim3(64), 0, st>>>(p);
-        else fresh ? pom_step_kernel<16, 1, true><<<grid, dim3(64), 0, st>>>(p) : pom_step_kernel<16, 1, false><<<grid, dim3(64), 0, st>>>(p);
+#define POM_LAUNCH(E, G) \
+    (fresh ? hipExtLaunchKernelGGL((pom_step_kernel<E, G, true>), grid, dim3(64), 0, st, ev0, ev1, 0, p) \
+           : hipExtLaunchKernelGGL((pom_step_kernel<E, G, false>), grid, dim3(64), 0, st, ev0, ev1, 0, p))
+        if (h->epw == 64) POM_LAUNCH(64, 1);
+        else if (h->epw == 32) POM_LAUNCH(32, 1);
+        else if (h->quad) POM_LAUNCH(16, 4);
+        else POM_LAUNCH(16, 1);
+#undef POM_LAUNCH
         HIPCHK(hipGetLastError());
-        if (prof) {
-            HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_n + 1], st));
-            h->prof_n++;
-        }
+        if (prof) h->prof_n++;
     }
     return POM_OK;
 }
