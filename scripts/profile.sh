@@ -5,7 +5,7 @@ set -u
 TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 200 --warmup 20 --no-cpu-baseline --no-config3 ${TRACE_STREAMS:---streams 3} $*"
 # kernel durations: the bench as it runs by default (sub-batches on parallel streams).  Counters: ONE launch per step
