@@ -44,10 +44,22 @@ def shard_plan(rank: int, world: int, envs_per_gpu: int) -> dict:
     return {"first_env": rank * envs_per_gpu, "n_envs": envs_per_gpu, "global_envs": world * envs_per_gpu}
 
 
+def _all_reduce(t, op, dist_mod):
+    """all_reduce in place; a device tensor goes through the host when the process group is gloo (CPU tests, and the
+    POM_BENCH_REHEARSAL mode that runs several ranks on ONE GPU, which RCCL refuses)"""
+    if t.is_cuda and dist_mod.get_backend() == "gloo":
+        h = t.cpu()
+        dist_mod.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist_mod.all_reduce(t, op=op)
+    return t
+
+
 def reduce_counters(counters, dist_mod=None):
     """Sum the per-rank int64 counters over ranks (RCCL all-reduce on GPU, gloo in CPU tests)."""
     if dist_mod is not None and dist_mod.is_initialized() and dist_mod.get_world_size() > 1:
-        dist_mod.all_reduce(counters, op=dist_mod.ReduceOp.SUM)
+        _all_reduce(counters, dist_mod.ReduceOp.SUM, dist_mod)
     return counters
 
 
@@ -55,7 +67,7 @@ def reduce_max(value: float, device, dist_mod=None) -> float:
     import torch
     t = torch.tensor([value], dtype=torch.float64, device=device)
     if dist_mod is not None and dist_mod.is_initialized() and dist_mod.get_world_size() > 1:
-        dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+        _all_reduce(t, dist_mod.ReduceOp.MAX, dist_mod)
     return float(t.item())
 
 
@@ -169,13 +181,21 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the stepper has no CPU path")
+    # POM_BENCH_REHEARSAL=1: the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices, gloo instead of
+    # RCCL, which refuses two ranks on one device).  For rehearsing the launch / barrier / reduction logic, never for numbers.
+    rehearsal = os.environ.get("POM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         # create RCCL's communicator and streams now: they take hardware queues, which the stream tuning below must see
-        dist.all_reduce(torch.zeros(1, device=device))
+        _all_reduce(torch.zeros(1, device=device), dist.ReduceOp.SUM, dist)
         torch.cuda.synchronize()
     dist_id = {"harmless": 0, "random": 1, "stress": 2}[args.dist]
     plan = shard_plan(rank, world, args.envs)
@@ -242,7 +262,7 @@ def main() -> None:
         best = min(tuned, key=tuned.get)
         if world > 1:  # every rank must run the same shape: take the vote of the slowest rank's best
             votes = torch.tensor([tuned[1], tuned[2], tuned[3]], dtype=torch.float64, device=device)
-            dist.all_reduce(votes, op=dist.ReduceOp.MAX)
+            _all_reduce(votes, dist.ReduceOp.MAX, dist)
             best = int(torch.argmin(votes).item()) + 1
         env.set_streams(best)
     for _ in range(args.warmup):
@@ -311,7 +331,7 @@ def main() -> None:
             "metric": "env_steps_per_sec", "value": total_steps / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, not a measurement)" if rehearsal else ""),
             "config": {
                 "workload": f"{args.envs} concurrent 11x11 FFA envs per GPU, {args.kind} boards, "
                             + (f"uniform-{args.dist} Move[4] (RandomAgent distribution)" if args.policy == "random"
