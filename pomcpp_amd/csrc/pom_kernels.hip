@@ -510,7 +510,7 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
  * Observation export (row f4, pom_batch.h pom_batch_observe).  A wavefront takes a tile of 16 envs into LDS as the tick does,
  * then four envs at a time: zero a 4 x 1936-byte staging area, scatter one byte per cell / bomb (each cell sets exactly one
  * of the planes 0..11), and stream the area out — for uint8 global views a straight 16-byte copy, fully coalesced; other
- * element types and the per-agent plane order are a byte gather with conversion.  HBM-write-bound: 1936 B x elements per env.
+ * element types and the per-agent plane order take runs of 4 bytes through a byte funnel, convert and store 4 elements.  HBM-write-bound: 1936 B x elements per env.
  * ------------------------------------------------------------------------------------------- */
 enum { OBS_ENV_BYTES = POM_OBS_PLANES * POM_CELLS, OBS_PASS_ENVS = 4 };
 static_assert(OBS_ENV_BYTES % 16 == 0, "an env's planes are a whole number of 16-byte stores");
@@ -536,44 +536,69 @@ __device__ __forceinline__ int obs_plane_of(int code) /* which of the planes 0..
     return -1;
 }
 
+/* four staged bytes starting at byte offset `b` of the staging area (any alignment): two aligned dwords and a byte funnel */
+__device__ __forceinline__ uint32_t obs_bytes4(const uint32_t* stage_w, int b)
+{
+    const uint32_t lo = stage_w[b >> 2], hi = stage_w[(b >> 2) + 1];
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(b & 3));
+}
 template <class T>
-__device__ __forceinline__ T obs_convert(uint32_t v);
+__device__ __forceinline__ void obs_store4(T* dst, uint32_t bytes);
 template <>
-__device__ __forceinline__ uint8_t obs_convert<uint8_t>(uint32_t v) { return (uint8_t)v; }
+__device__ __forceinline__ void obs_store4<uint8_t>(uint8_t* dst, uint32_t bytes) { *reinterpret_cast<uint32_t*>(dst) = bytes; }
 template <>
-__device__ __forceinline__ _Float16 obs_convert<_Float16>(uint32_t v) { return (_Float16)(float)v; }
+__device__ __forceinline__ void obs_store4<_Float16>(_Float16* dst, uint32_t bytes)
+{
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<half4*>(dst) = half4{(_Float16)(float)(bytes & 0xFF), (_Float16)(float)((bytes >> 8) & 0xFF),
+                                           (_Float16)(float)((bytes >> 16) & 0xFF), (_Float16)(float)(bytes >> 24)};
+}
 template <>
-__device__ __forceinline__ float obs_convert<float>(uint32_t v) { return (float)v; }
+__device__ __forceinline__ void obs_store4<float>(float* dst, uint32_t bytes)
+{
+    *reinterpret_cast<float4*>(dst) = make_float4((float)(bytes & 0xFF), (float)((bytes >> 8) & 0xFF), (float)((bytes >> 16) & 0xFF),
+                                                  (float)(bytes >> 24));
+}
 
-/* the generic way out of the staging area: element type T, `views` plane orders per env */
+/* the generic way out of the staging area: element type T, `views` plane orders per env.  A lane takes 4 consecutive output
+ * elements per round (one aligned 4 / 8 / 16-byte store): their source bytes are consecutive in the staging area unless the
+ * group crosses a plane boundary (planes are 121 bytes, and the four agent planes are permuted per view), so it fetches the
+ * run starting at its first element and the run ending at its last one and splices them at the boundary.  Plane and offset
+ * advance incrementally (64 lanes x 4 elements = 2 planes + 14 per round): no division in the loop. */
 template <class T>
-__device__ __forceinline__ void obs_gather_out(const ObserveParams& p, const uint8_t* stage_b, int64_t e0, int lane)
+__device__ __forceinline__ void obs_gather_out(const ObserveParams& p, const uint32_t* stage_w, int64_t e0, int lane)
 {
     const int views = p.per_agent ? 4 : 1;
-    constexpr int GROUPS = OBS_ENV_BYTES / 4; /* 4 elements per lane and store */
     T* out = reinterpret_cast<T*>(p.planes);
-    POM_NOUNROLL
-    for (int g = lane; g < OBS_PASS_ENVS * views * GROUPS; g += 64) {
-        const int ev = g / GROUPS, gi = g - ev * GROUPS; /* (env, view) pair and group within it */
-        const int ei = p.per_agent ? ev >> 2 : ev, a = p.per_agent ? ev & 3 : 0;
-        if (e0 + ei >= p.n) continue;
-        T v[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int el = 4 * gi + k, pl = el / POM_CELLS, off = el - pl * POM_CELLS;
-            const int src = (pl >= 8 && pl < 12) ? 8 + ((pl - 8 + a) & 3) : pl;
-            v[k] = obs_convert<T>(stage_b[ei * OBS_ENV_BYTES + src * POM_CELLS + off]);
+    for (int ei = 0; ei < OBS_PASS_ENVS && e0 + ei < p.n; ei++) {
+        for (int a = 0; a < views; a++) {
+            T* dst = out + ((e0 + ei) * views + a) * (int64_t)OBS_ENV_BYTES;
+            int pl = (4 * lane) / POM_CELLS, off = 4 * lane - pl * POM_CELLS; /* of the group's first element */
+            POM_NOUNROLL
+            for (int el = 4 * lane; el < OBS_ENV_BYTES; el += 256) {
+                const int src0 = (pl >= 8 && pl < 12) ? 8 + ((pl - 8 + a) & 3) : pl;
+                const int pn = pl + 1, src1 = (pn >= 8 && pn < 12) ? 8 + ((pn - 8 + a) & 3) : pn;
+                const int room = POM_CELLS - off; /* elements left in this plane, >= 1 */
+                const uint32_t head = obs_bytes4(stage_w, ei * OBS_ENV_BYTES + src0 * POM_CELLS + off);
+                /* the next plane's first bytes, placed where they belong in the group (only read when the group crosses) */
+                const uint32_t tail = obs_bytes4(stage_w, ei * OBS_ENV_BYTES + (room < 4 ? src1 * POM_CELLS - room : src0 * POM_CELLS + off));
+                const uint32_t keep = room >= 4 ? 0xFFFFFFFFu : (1u << (8 * room)) - 1u;
+                obs_store4<T>(dst + el, (head & keep) | (tail & ~keep));
+                off += 256 - 2 * POM_CELLS; /* 256 = 2 x 121 + 14 */
+                pl += 2;
+                if (off >= POM_CELLS) {
+                    off -= POM_CELLS;
+                    pl++;
+                }
+            }
         }
-        T* dst = out + ((e0 + ei) * views + a) * (int64_t)OBS_ENV_BYTES + 4 * gi;
-        struct alignas(4 * sizeof(T)) Pack { T v[4]; };
-        *reinterpret_cast<Pack*>(dst) = Pack{{v[0], v[1], v[2], v[3]}};
     }
 }
 
 __global__ __launch_bounds__(64) void pom_observe_kernel(ObserveParams p)
 {
     __shared__ uint32_t tile[POM_REC_DWORDS * 16];
-    __shared__ uint4 stage[OBS_PASS_ENVS * OBS_ENV_BYTES / 16];
+    __shared__ uint4 stage[OBS_PASS_ENVS * OBS_ENV_BYTES / 16 + 1]; /* + 16 B: the byte funnel reads one dword past a run */
     const int lane = threadIdx.x;
     const int64_t np = p.n_pad;
     int64_t tile_local;
@@ -649,11 +674,11 @@ __global__ __launch_bounds__(64) void pom_observe_kernel(ObserveParams p)
                 if (idx < VECS && e0 + idx / (OBS_ENV_BYTES / 16) < p.n) out[idx] = stage[idx];
             }
         } else if (p.dtype == POM_OBS_U8) {
-            obs_gather_out<uint8_t>(p, stage_b, e0, lane);
+            obs_gather_out<uint8_t>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
         } else if (p.dtype == POM_OBS_F16) {
-            obs_gather_out<_Float16>(p, stage_b, e0, lane);
+            obs_gather_out<_Float16>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
         } else {
-            obs_gather_out<float>(p, stage_b, e0, lane);
+            obs_gather_out<float>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
         }
         __syncthreads();
     }
