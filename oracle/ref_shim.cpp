@@ -3,7 +3,7 @@
  * reference, compiled from the sources where they lie under /root/reference
  * (never copied into this repo) into oracle/_ref/libpomref.so by oracle/Makefile.
  * Used in this container only: to validate oracle/pom_oracle.c (fuzz_diff) and
- * to generate the golden vectors under tests/golden/ (scripts/gen_golden.py).
+ * to generate the golden vectors under tests/golden/ (tests/golden/gen_golden.py).
  * /root/reference does not exist on the GPU box; nothing there needs this file.
  */
 #include <cstring>

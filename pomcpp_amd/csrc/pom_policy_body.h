@@ -73,7 +73,7 @@ enum { POM_PP_LOAD = 0, POM_PP_PREPARE, POM_PP_PREDICATES, POM_PP_TARGET, POM_PP
 #else
 #define POM_DUP(k, stmt, out) ((void)0)
 #endif
-/* POM_LEVEL_STATS (host analysis builds only, scripts/flood_levels.cpp): how many levels the two floods of an act() ran */
+/* POM_LEVEL_STATS (host analysis builds only, tests/emul/flood_levels.cpp): how many levels the two floods of an act() ran */
 #if defined(POM_LEVEL_STATS) && !defined(__HIP_DEVICE_COMPILE__)
 extern "C" int pom_stat_fwd, pom_stat_bwd;
 #define POM_COUNT_LEVEL(v) ((v)++)

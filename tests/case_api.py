@@ -4,7 +4,7 @@ HostAPI  — boards are set up with the product's host helpers (pomcpp_amd.state
            State method the reference's tests call directly) with the oracle, and stepped by the
            stepper under test: the oracle on CPU, or the HIP path through the C-ABI (pom_step).
 RefAPI   — everything through the compiled, unmodified reference (oracle/_ref/libpomref.so);
-           only scripts/gen_golden.py uses it, in the build container.
+           only tests/golden/gen_golden.py uses it, in the build container.
 Both record the trace [(state before, Move[4], state after)] of every Step.
 """
 from __future__ import annotations

@@ -2,7 +2,7 @@
  * flood_levels.cpp — host analysis (not shipped, not a test): how many levels do the policy's two flood fills run, per agent
  * and per "wavefront" (16 envs = 64 agents in lock-step: the wavefront pays the maximum)?  Plays SimpleAgent games on
  * generated boards with the oracle tick; the act() is the device policy body built for the host with POM_LEVEL_STATS.
- * build: see scripts/flood_levels.sh
+ * build: see tests/emul/flood_levels.sh
  */
 #include <algorithm>
 #include <cstdio>

@@ -8,7 +8,7 @@ Each function below follows one TEST_CASE / SECTION of
     api.step(s, m) / api.several_steps(n, s, m)
     api.require(cond) / api.require_agent(s, agent, x, y)      REQUIRE / REQUIRE_AGENT (:11-17)
 
-The same script runs (a) against the compiled reference when scripts/gen_golden.py records the
+The same script runs (a) against the compiled reference when tests/golden/gen_golden.py records the
 golden trace, (b) against the oracle on CPU and (c) against the HIP path through the C-ABI — so the
 parity tests read like the reference's own.  `EXTRA_CASES` are directed vectors for the quirks of
 SURVEY.md §9 that the reference's suite does not reach.

@@ -1,4 +1,4 @@
-"""Golden vectors recorded from the compiled reference (scripts/gen_golden.py): every recorded Step
+"""Golden vectors recorded from the compiled reference (tests/golden/gen_golden.py): every recorded Step
 replayed in isolation, and whole random-play episodes replayed tick by tick against the per-tick
 state hashes, the checkpoints and the final state."""
 import hashlib
