@@ -1,0 +1,70 @@
+"""BASELINE's full size (65,536 envs, config 3) for the rows around the tick: SimpleAgent games with fresh boards and the
+observation export at full size, checked against the oracle on slices (envs are independent: a slice of the batch must equal
+the oracle's run of the same global env indices) and through size-independent properties."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 65536
+
+
+@pytest.mark.gpu
+def test_config3_full_size_policy_games_on_generated_boards(hip_lib, oracle):
+    from pomcpp_amd.batch import BatchEnvironment, MODE_ENV
+    seed, bseed, cap, ticks = 9, 2024, 50, 120
+    env = BatchEnvironment(N, mode=MODE_ENV, auto_reset=True, max_steps=cap, fresh_boards=True, board_seed=bseed)
+    env.generate(bseed)
+    env.step_simple(seed, ticks)
+    got = env.get_state()
+    eps = env.episodes()
+    cnt = env.counters()
+    assert cnt[0] == N * ticks and cnt[2] == eps.sum()          # every env stepped every tick; resets = games started
+    assert eps.min() >= 2                                        # 120 ticks under a 50-tick cap
+    assert np.all(got["timeStep"] <= cap) and np.all(got["timeStep"] >= 0)
+    # slices from the start, the middle (not wavefront-aligned) and the end of the batch, against the oracle
+    for first, m in ((0, 512), (30001, 700), (N - 300, 300)):
+        ref = oracle.boardgen(bseed, first + np.arange(m), np.zeros(m))
+        e = np.zeros(m, dtype=np.int32)
+        mems = np.zeros((m, 4, 16), dtype=np.int32)
+        oracle.run_simple_fresh(ref, e, mems, ticks, seed, bseed, first, 0, cap)
+        assert got[first:first + m].tobytes() == ref.tobytes(), first
+        assert np.array_equal(eps[first:first + m], e)
+        assert np.array_equal(env.policy_memory(first, m), mems)
+    # determinism: a second handle, different stream split, same result
+    env2 = BatchEnvironment(N, mode=MODE_ENV, auto_reset=True, max_steps=cap, fresh_boards=True, board_seed=bseed, streams=1)
+    env2.generate(bseed)
+    env2.step_simple(seed, ticks)
+    assert env2.get_state().tobytes() == got.tobytes()
+    env.close()
+    env2.close()
+
+
+@pytest.mark.gpu
+def test_observation_full_size_slices_and_plane_invariants(hip_lib):
+    spec = importlib.util.spec_from_file_location("pom_observe_oracle", os.path.join(ROOT, "oracle", "pom_observe_oracle.py"))
+    ob = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ob)
+    from pomcpp_amd.batch import BatchEnvironment, MODE_ENV
+    env = BatchEnvironment(N, mode=MODE_ENV, auto_reset=True, max_steps=800)
+    env.generate(5)
+    env.step_random(3, 1, ticks=40)
+    planes, attrs, eattrs = env.observe()
+    p = planes.cpu().numpy()
+    st = env.get_state()
+    for first, m in ((0, 300), (41111, 300), (N - 200, 200)):
+        want, want_attrs, _ = ob.observe(st[first:first + m])
+        assert np.array_equal(p[first:first + m], want) and np.array_equal(attrs.cpu().numpy()[first:first + m], want_attrs)
+    # every cell shows exactly one item plane (no fog on these boards); agent planes hold each live agent once
+    assert np.all(p[:, :12].sum(axis=1) == 1)
+    alive = attrs.cpu().numpy()[:, :, 2]
+    assert np.array_equal(p[:, 8:12].reshape(N, 4, -1).sum(axis=2), alive)
+    assert np.array_equal(eattrs.cpu().numpy()[:, 1], alive.sum(axis=1))
+    # the per-agent view is the global one with the agent planes rotated
+    v = env.observe(per_agent=True, attrs=False)[0].cpu().numpy()
+    for a in range(4):
+        order = list(range(8)) + [8 + ((a + j) & 3) for j in range(4)] + list(range(12, 16))
+        assert np.array_equal(v[:, a], p[:, order])
+    env.close()
