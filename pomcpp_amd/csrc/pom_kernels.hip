@@ -352,10 +352,11 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW 
 /* ---------------------------------------------------------------------------------------------
  * SimpleAgent policy (pom_policy_body.h): one lane per AGENT, the quad 4e..4e+3 = the four agents of env e,
  * 16 envs per wavefront.  The wavefront DMAs record rows 0..91 (board, meta, agents, bombs) of its 16 envs into a shared
- * tile; per env the four lanes together prepare a danger map ([121][16] dwords, LDS atomic min) and two cell sets.  The
- * reachability search runs on 121-bit cell sets in registers, so a wavefront needs only 14 KB of LDS.  Output: Move[4] per env
- * into the handle's move buffer, agent memory (2 dwords per agent) updated in place.  A finished env that the next step will
- * restart is read from its snapshot column and gets fresh (zero) agent memory, so policy and tick see the same game.
+ * tile; per env the four lanes together prepare a danger map ([128][16] dwords, LDS atomic min) and three cell sets.  The
+ * reachability questions are flood fills on 121-bit cell sets in registers, so a wavefront needs only 15 KB of LDS.  Output:
+ * Move[4] per env into the handle's move buffer, agent memory (2 dwords per agent) updated in place.  A finished env that the
+ * next step will restart is read from its snapshot column — or, with fresh boards, drawn here exactly as the tick will draw
+ * it — and gets fresh (zero) agent memory, so policy and tick see the same game.
  * ------------------------------------------------------------------------------------------- */
 enum { POL_ROWS = 92 };
 

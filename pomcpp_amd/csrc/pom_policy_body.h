@@ -23,9 +23,10 @@
  *                         m1 = recentPositions.index:2 | count:3 @2 | moveQueue.queue[0..3] 3 bits each @5 | moveQueue.count:3 @17
  * (moveQueue.index is always 0: the queue is never popped).  All-zero = a fresh agent.
  *
- * Per env and tick two things are prepared ONCE, by the four lanes of the env together (pom_policy_prepare), instead of being
+ * Per env and tick some things are prepared ONCE, by the four lanes of the env together (pom_policy_prepare_*), instead of being
  * recomputed per query: the danger map — IsInDanger(x, y) for every cell: each bomb's cross rasterised with an LDS atomic min
- * of its timer — and two 121-bit sets, "walkable" and "agent", which the BFS tests in registers instead of reading cells.
+ * of its timer — and three 121-bit cell sets, "walkable", "agent" and "safe", one 32-cell word per lane, which the floods and
+ * the safe-place scan work on in registers instead of reading cells.
  *
  * Store interface P:  int cell(int c)            16-bit board code (pom_packed.h), c = y*11+x
  *                     int bomb(int slot)         raw bomb word of physical slot
