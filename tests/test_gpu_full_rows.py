@@ -68,3 +68,52 @@ def test_observation_full_size_slices_and_plane_invariants(hip_lib):
         order = list(range(8)) + [8 + ((a + j) & 3) for j in range(4)] + list(range(12, 16))
         assert np.array_equal(v[:, a], p[:, order])
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fresh", [False, True])
+def test_long_horizon_random_play(hip_lib, oracle, fresh):
+    """3,000 ticks (the 800-tick cap is reached, every env plays dozens of games): rare paths get their turn"""
+    import pomcpp_amd as pa
+    from pomcpp_amd.batch import BatchEnvironment, MODE_ENV
+    n, seed, bseed, cap, offset = 2048, 17, 4, 800, 10_000
+    env = BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=cap, env_offset=offset, fresh_boards=fresh, board_seed=bseed)
+    if fresh:
+        env.generate(bseed)
+        ref = oracle.boardgen(bseed, offset + np.arange(n), np.zeros(n))
+    else:
+        start = pa.make_boards(n, seed=3)
+        env.make_game(start)
+        ref = start.copy()
+    eps = np.zeros(n, dtype=np.int32)
+    tick = 0
+    for chunk in (1000, 1000, 1000):
+        env.step_random(seed, 1, ticks=chunk)
+        if fresh:
+            oracle.run_random_fresh(ref, eps, chunk, seed, bseed, offset, tick, 1, cap)
+        else:
+            oracle.run_random(ref, start, chunk, seed, offset, tick, 1, cap)
+        tick += chunk
+        assert env.get_state().tobytes() == ref.tobytes(), (fresh, tick)
+    if fresh:
+        assert np.array_equal(env.episodes(), eps) and eps.min() > 20
+    env.close()
+
+
+@pytest.mark.gpu
+def test_long_horizon_simple_agents_with_fresh_boards(hip_lib, oracle):
+    from pomcpp_amd.batch import BatchEnvironment, MODE_ENV
+    n, seed, bseed, cap, offset = 1024, 23, 6, 800, 777
+    env = BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=cap, env_offset=offset, fresh_boards=True, board_seed=bseed)
+    env.generate(bseed)
+    ref = oracle.boardgen(bseed, offset + np.arange(n), np.zeros(n))
+    eps, mems = np.zeros(n, dtype=np.int32), np.zeros((n, 4, 16), dtype=np.int32)
+    tick = 0
+    for chunk in (400, 400, 400):
+        env.step_simple(seed, chunk)
+        oracle.run_simple_fresh(ref, eps, mems, chunk, seed, bseed, offset, tick, cap)
+        tick += chunk
+        assert env.get_state().tobytes() == ref.tobytes(), tick
+        assert np.array_equal(env.policy_memory(), mems), tick
+    assert np.array_equal(env.episodes(), eps) and eps.min() >= 1 and eps.mean() > 4  # 1,200 ticks: a game lasts ~190
+    env.close()
