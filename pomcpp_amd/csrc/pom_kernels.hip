@@ -186,6 +186,33 @@ __device__ __forceinline__ void store_tile(uint32_t* col, int64_t np, const uint
         g += stride;
     }
 }
+/* EPW = 16: the same movement in 16-byte pieces (gfx950's global_load_lds_dwordx4 / dwordx4 stores).  A tile row is 16 envs
+ * = 64 contiguous bytes in HBM and in LDS, so lane l takes envs 4(l%4)..+3 of row r0 + l/4 and one instruction covers 16 rows:
+ * 7 instead of 28 per direction.  All 16 columns come from the same buffer (`base` = &buf[tile's first env]). */
+template <int ROWS = POM_REC_DWORDS>
+__device__ __forceinline__ void load_tile16_x4(const uint32_t* base, int64_t np, uint32_t* tile, int lane)
+{
+    static_assert(ROWS % 16 == 0 && ROWS <= POM_REC_DWORDS, "whole instructions, inside the record");
+    const uint32_t* g = base + (int64_t)(lane >> 2) * np + 4 * (lane & 3);
+    const int64_t stride = 16 * np;
+#pragma unroll
+    for (int r0 = 0; r0 < ROWS; r0 += 16) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(tile + r0 * 16), 16, 0, 0);
+        g += stride;
+    }
+}
+__device__ __forceinline__ void store_tile16_x4(uint32_t* base, int64_t np, const uint32_t* tile, int lane)
+{
+    uint4* g = reinterpret_cast<uint4*>(base + (int64_t)(lane >> 2) * np + 4 * (lane & 3));
+    const int64_t stride = 4 * np; /* in uint4 */
+    const uint4* l = reinterpret_cast<const uint4*>(tile) + lane;
+#pragma unroll
+    for (int r0 = 0; r0 < POM_REC_DWORDS; r0 += 16) {
+        *g = l[r0 * 4];
+        g += stride;
+    }
+}
 /* the register-resident rows (timeStep, meta, agents) of one env, out of / into its tile column */
 __device__ __forceinline__ void lane_from_tile(PomLane& L, int& time_step, uint32_t& status, const uint32_t* t, int epw)
 {
@@ -208,7 +235,7 @@ template <int EPW, int G, bool FRESH>
 __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW == 32 ? 2 : 1)) void pom_step_kernel(StepParams p)
 {
     static_assert(G == 1 || (G == 4 && EPW == 16), "a quad per env needs 16 envs per wavefront");
-    __shared__ uint32_t tile[LDS_ROWS * EPW];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[LDS_ROWS * EPW];
     const int lane = threadIdx.x;
     /* XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own
      * L2).  With fewer than 64 envs per wavefront neighbouring tiles share 128-B lines of every record row, so they are
@@ -243,7 +270,17 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW 
 
     /* a finished env restarts from its snapshot: pick the source column per lane, one pass over the record */
     bool reload_d = e_d < p.n && env_mode && p.auto_reset && !FRESH && ((col_d[POM_REC_META2 * np] >> 8) & POM_ST_DONE);
-    load_tile<EPW>(reload_d ? scol_d : col_d, np, tile, sub);
+    if (EPW == 16) {
+        /* everything from the state buffer in 16-byte pieces; the (rarer) restarting envs' columns are then overwritten from
+         * the snapshot, lanes masked — both land in issue order, the wait in between is only for the second pass's sake */
+        load_tile16_x4(p.state + tile_id * EPW, np, tile, lane);
+        if (__any(reload_d)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (reload_d) load_tile<EPW>(scol_d, np, tile, sub);
+        }
+    } else {
+        load_tile<EPW>(reload_d ? scol_d : col_d, np, tile, sub);
+    }
     c_resets += __popcll(__ballot(reload_d && sub == 0));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the DMA rows have landed (one wavefront per workgroup: no barrier) */
     PomLane L;
@@ -332,7 +369,8 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW 
             t[(POM_REC_AGENTS + 2 * i + 1) * EPW] = (uint32_t)L.a1[i];
         }
     }
-    store_tile<EPW>(col_d, np, tile, sub, el);
+    if (EPW == 16) store_tile16_x4(p.state + tile_id * EPW, np, tile, lane);
+    else store_tile<EPW>(col_d, np, tile, sub, el);
 
 #if defined(POM_DIAG)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -358,7 +396,7 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW 
  * next step will restart is read from its snapshot column — or, with fresh boards, drawn here exactly as the tick will draw
  * it — and gets fresh (zero) agent memory, so policy and tick see the same game.
  * ------------------------------------------------------------------------------------------- */
-enum { POL_ROWS = 92 };
+enum { POL_ROWS = 92, POL_LOAD_ROWS = 96 }; /* the policy reads rows 0..91; they arrive 16 rows per instruction */
 
 struct PolicyStore {
     const uint32_t* t; /* &tile[env_in_wave], row stride 16 dwords */
@@ -395,7 +433,7 @@ struct PolicyParams {
 
 __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
 {
-    __shared__ uint32_t tile[POL_ROWS * 16];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[POL_LOAD_ROWS * 16];
     __shared__ int danger[128 * 16]; /* 121 cells; the safe-set pass reads whole 32-cell words */
     __shared__ uint32_t sets[12 * 16];
     const int lane = threadIdx.x;
@@ -414,12 +452,16 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
     const int el = lane & 15, sub = lane >> 4;
     const int64_t e_d = tile_id * 16 + el;
     const bool restart_d = e_d < p.n && env_mode && p.auto_reset && ((p.state[POM_REC_META2 * np + e_d] >> 8) & POM_ST_DONE);
-    {
-        const uint32_t* g = (restart_d && !p.fresh ? p.snap : p.state) + e_d + (int64_t)sub * np;
+    load_tile16_x4<POL_LOAD_ROWS>(p.state + tile_id * 16, np, tile, lane);
+    if (!p.fresh && __any(restart_d)) { /* restarting envs are judged on their snapshot: overwrite those columns, lanes masked */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (restart_d) {
+            const uint32_t* g = p.snap + e_d + (int64_t)sub * np;
 #pragma unroll 4
-        for (int r0 = 0; r0 < POL_ROWS; r0 += 4) {
-            dma_rows(g, tile + r0 * 16);
-            g += 4 * np;
+            for (int r0 = 0; r0 < POL_ROWS; r0 += 4) {
+                dma_rows(g, tile + r0 * 16);
+                g += 4 * np;
+            }
         }
     }
     /* the policy: lane -> (env lane/4, agent lane%4) */
@@ -598,7 +640,7 @@ __device__ __forceinline__ void obs_gather_out(const ObserveParams& p, const uin
 
 __global__ __launch_bounds__(64) void pom_observe_kernel(ObserveParams p)
 {
-    __shared__ uint32_t tile[POM_REC_DWORDS * 16];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[POM_REC_DWORDS * 16];
     __shared__ uint4 stage[OBS_PASS_ENVS * OBS_ENV_BYTES / 16 + 1]; /* + 16 B: the byte funnel reads one dword past a run */
     const int lane = threadIdx.x;
     const int64_t np = p.n_pad;
@@ -608,7 +650,7 @@ __global__ __launch_bounds__(64) void pom_observe_kernel(ObserveParams p)
         tile_local = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
     }
     const int64_t tile_id = p.block0 + tile_local;
-    load_tile<16>(p.state + tile_id * 16 + (lane & 15), np, tile, lane >> 4);
+    load_tile16_x4(p.state + tile_id * 16, np, tile, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint8_t* stage_b = reinterpret_cast<uint8_t*>(stage);
     const uint16_t* tile_h = reinterpret_cast<const uint16_t*>(tile);
@@ -706,18 +748,20 @@ __global__ __launch_bounds__(64) void pom_observe_kernel(ObserveParams p)
 __global__ __launch_bounds__(64) void pom_generate_kernel(uint32_t* state, uint32_t* snap, uint32_t* episode, int64_t n, int64_t np,
                                                           int64_t env_offset, uint64_t board_seed)
 {
-    __shared__ uint32_t tile[POM_REC_DWORDS * 16];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[POM_REC_DWORDS * 16];
     const int lane = threadIdx.x;
     const int64_t tile_id = blockIdx.x;
+    if (tile_id * 16 + 16 > n) { /* the last, partial tile: its unused columns leave as blank records */
+        for (int k = lane; k < POM_REC_DWORDS * 4; k += 64) reinterpret_cast<uint4*>(tile)[k] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
     for (int ec = 0; ec < 16 && tile_id * 16 + ec < n; ec++)
         pom_boardgen_wave<16, POM_REC_DWORDS>(tile + ec, pom_board_key(board_seed, (uint32_t)(env_offset + tile_id * 16 + ec), 0u), lane);
     if (tile_id * 16 + lane < n && lane < 16) episode[tile_id * 16 + lane] = 0u;
     __syncthreads();
-    const int el = lane & 15, sub = lane >> 4;
-    if (tile_id * 16 + el < n) {
-        store_tile<16>(state + tile_id * 16 + el, np, tile, sub, el);
-        store_tile<16>(snap + tile_id * 16 + el, np, tile, sub, el);
-    }
+    /* whole tiles: the buffers hold n_pad columns; columns past n are blank records here, as after creation */
+    store_tile16_x4(state + tile_id * 16, np, tile, lane);
+    store_tile16_x4(snap + tile_id * 16, np, tile, lane);
 }
 
 /* ---- boundary kernels ----------------------------------------------------------------------- */
