@@ -378,12 +378,14 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW 
     if (lane == 0 && p.diag) /* one slot per wavefront: no contended atomics that would distort the timing */
         for (int k = 0; k < POM_PH_N; k++) p.diag[tile_id * POM_PH_N + k] += L.t_acc[k];
 #endif
-    if (lane == 0) { /* each wavefront owns its slot: no atomics on the tick path */
-        int64_t* wc = p.wave_counters + tile_id * POM_CNT_N;
-        wc[POM_CNT_STEPS] += c_steps;
-        wc[POM_CNT_EPISODES] += c_episodes;
-        wc[POM_CNT_RESETS] += c_resets;
-        wc[POM_CNT_UB_TICKS] += c_ub;
+    if (lane == 0) {
+        /* each wavefront owns its slot, so nothing contends; the adds are returnless atomics only because those are
+         * fire-and-forget — a load / add / store would keep the finished wavefront alive for a global round trip */
+        unsigned long long* wc = reinterpret_cast<unsigned long long*>(p.wave_counters + tile_id * POM_CNT_N);
+        __hip_atomic_fetch_add(&wc[POM_CNT_STEPS], (unsigned long long)c_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c_episodes) __hip_atomic_fetch_add(&wc[POM_CNT_EPISODES], (unsigned long long)c_episodes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c_resets) __hip_atomic_fetch_add(&wc[POM_CNT_RESETS], (unsigned long long)c_resets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c_ub) __hip_atomic_fetch_add(&wc[POM_CNT_UB_TICKS], (unsigned long long)c_ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
