@@ -111,6 +111,7 @@ struct StepParams {
     uint32_t tick0;
     int32_t dist, ticks, mode, auto_reset, max_steps;
     int64_t block0; /* this launch covers tiles block0 .. block0 + gridDim.x - 1 (sub-batch of a split step) */
+    uint32_t* agent_mem; /* POLICY instantiation: SimpleAgent memory, [2][4 * n_pad] */
     uint32_t* episode;   /* games started so far per env (fresh boards: keys the next board) */
     uint64_t board_seed;
     int32_t fresh;       /* a restarting env gets the next board of pom_boardgen.h instead of its snapshot */
@@ -225,17 +226,45 @@ __device__ __forceinline__ void lane_from_tile(PomLane& L, int& time_step, uint3
     status = (m2 >> 8) & 0xFF;
 }
 
+/* the four lanes of an env as the SimpleAgent policy sees them (pom_policy_body.h): lane = agent, 16 envs per wavefront */
+struct PolicyStore {
+    const uint32_t* t; /* &tile[env_in_wave], row stride 16 dwords */
+    uint8_t* dcol;     /* &danger[env_in_wave], a byte per cell, row stride 16 */
+    uint32_t* scol;    /* &sets[env_in_wave], row stride 16 */
+    int who;           /* lane % 4 */
+    __device__ int member() const { return who; }
+    __device__ int danger(int c) const { return dcol[c * 16]; }
+    __device__ void danger_init(int c) { dcol[c * 16] = (uint8_t)POM_DANGER_NONE; }
+    __device__ void danger_put(int c, int tm) { dcol[c * 16] = (uint8_t)tm; }
+    __device__ uint32_t setw(int k) const { return scol[k * 16]; }
+    __device__ void set_put(int k, uint32_t bits) { scol[k * 16] = bits; }
+    __device__ uint32_t board_word(int k) const { return t[k * 16]; }
+    __device__ int cell(int c) const { return reinterpret_cast<const uint16_t*>(t)[(c >> 1) * 32 + (c & 1)]; }
+    __device__ int bomb(int s) const { return (int)t[(POM_REC_BOMBS + s) * 16]; }
+};
+
 /* occupancy target of the quad kernel.  It needs 107 VGPRs since its tile mirrors the whole record (no per-row global
  * addresses live across the tick), so 4 wavefronts per SIMD fit anyway; the target only forbids the compiler to squeeze
  * further (an earlier 157-VGPR version capped at 128 spilled 60 B/lane and ran 12 % slower, profiles/r01_quad.txt) */
 #ifndef POM_QUAD_WAVES
 #define POM_QUAD_WAVES 3
 #endif
-template <int EPW, int G, bool FRESH>
-__global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW == 32 ? 2 : 1)) void pom_step_kernel(StepParams p)
+/* POLICY: the moves are not read but decided here — lane m of an env's quad is agent m and runs SimpleAgent::act
+ * (pom_policy_body.h) on the tile the tick is about to work on: Environment::Step with four SimpleAgents in ONE kernel, one
+ * record load per tick instead of two and no Move[4] round trip (pom_batch_step_simple). */
+template <int EPW, int G, bool FRESH, bool POLICY = false>
+__global__ __launch_bounds__(64, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW == 32 ? 2 : 1)) void pom_step_kernel(StepParams p)
 {
     static_assert(G == 1 || (G == 4 && EPW == 16), "a quad per env needs 16 envs per wavefront");
-    __shared__ __attribute__((aligned(16))) uint32_t tile[LDS_ROWS * EPW];
+    static_assert(!POLICY || G == 4, "the policy runs one agent per lane of the quad");
+    /* POLICY: the danger map (32 rows of bytes) and the cell sets (12 rows) live where the tick keeps its bomb destinations
+     * and explosion frames (26 rows) — the policy of a tick is over before its tick begins.  156 rows = 9,984 B: 16
+     * wavefronts per CU, i.e. all of 65,536 envs resident at once. */
+    constexpr int ROWS = POLICY ? POM_REC_DWORDS + 44 : LDS_ROWS;
+    static_assert(ROWS >= LDS_ROWS, "the tick's scratch rows fit under the overlay");
+    __shared__ __attribute__((aligned(16))) uint32_t tile[ROWS * EPW];
+    uint8_t* const danger = reinterpret_cast<uint8_t*>(tile + POM_REC_DWORDS * EPW);
+    uint32_t* const sets = tile + (POM_REC_DWORDS + 32) * EPW;
     const int lane = threadIdx.x;
     /* XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own
      * L2).  With fewer than 64 envs per wavefront neighbouring tiles share 128-B lines of every record row, so they are
@@ -282,6 +311,12 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW 
         load_tile<EPW>(reload_d ? scol_d : col_d, np, tile, sub);
     }
     c_resets += __popcll(__ballot(reload_d && sub == 0));
+    uint32_t m0 = 0, m1 = 0; /* POLICY: this lane's agent's memory */
+    if (POLICY) {
+        m0 = p.agent_mem[tile_id * 64 + lane];
+        m1 = p.agent_mem[4 * np + tile_id * 64 + lane];
+    }
+    bool restarted = POLICY && !FRESH && __shfl((int)reload_d, ec) != 0; /* lane ec moved env ec's rows */
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the DMA rows have landed (one wavefront per workgroup: no barrier) */
     PomLane L;
     int time_step = 0;
@@ -318,6 +353,7 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW 
             }
             asm volatile("" ::: "memory"); /* other lanes wrote this lane's column: no read of it may be scheduled earlier */
             if (reload) lane_from_tile(L, time_step, status, t, EPW); /* the register-resident rows, from the new record */
+            restarted = reload;
             c_resets += __popcll(__ballot(reload && owner));
         } else if (tk > 0) {
             /* the lanes that move env el's rows need the verdict of the lane that owns env el */
@@ -329,13 +365,44 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (reload) lane_from_tile(L, time_step, status, t, EPW);
             }
+            restarted = reload;
             c_resets += __popcll(__ballot(reload && owner));
         }
         const bool active = valid && !(env_mode && (status & POM_ST_DONE));
         bool newly_done = false, new_ub = false;
+        int mv_own = POM_MOVE_IDLE;
+        if (POLICY) {
+            if (tk > 0) { /* the memory does not stay in registers through the tick */
+                m0 = p.agent_mem[tile_id * 64 + lane];
+                m1 = p.agent_mem[4 * np + tile_id * 64 + lane];
+            }
+            if (restarted) m0 = m1 = 0; /* a new game gets fresh agents */
+            restarted = false;
+            PolicyStore st{t, danger + ec, sets + ec, member};
+            if (active) { /* all four lanes of the env, dead agents' lanes included */
+                pom_policy_prepare_clear(st);
+                pom_policy_prepare_fill(st, PomPolicyEnv{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {L.a1[0], L.a1[1], L.a1[2], L.a1[3]}, L.bIdx, L.bCnt});
+                pom_policy_prepare_safe(st);
+            }
+            if (active && !ag_dead(sel4(member, L.a0))) { /* act() is only asked of live agents, environment.cpp:139-146 */
+                const PomPolicyEnv E{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {L.a1[0], L.a1[1], L.a1[2], L.a1[3]}, L.bIdx, L.bCnt};
+                PomSimplePolicy<PolicyStore> pol(st, E, member, m0, m1);
+                const uint64_t r = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick0 + (uint32_t)tk);
+                mv_own = pol.act((int)((((uint32_t)(r >> (16 * member)) & 0xFFFFu) * 5u) >> 16));
+                m0 = pol.m0;
+                m1 = pol.m1;
+            }
+            p.agent_mem[tile_id * 64 + lane] = m0;
+            p.agent_mem[4 * np + tile_id * 64 + lane] = m1;
+        }
         if (active) {
             int mv[4];
-            if (p.moves) {
+            if (POLICY) {
+                mv[0] = acc.template gbcast<0>(mv_own);
+                mv[1] = acc.template gbcast<1>(mv_own);
+                mv[2] = acc.template gbcast<2>(mv_own);
+                mv[3] = acc.template gbcast<3>(mv_own);
+            } else if (p.moves) {
                 const int4 m = reinterpret_cast<const int4*>(p.moves)[e];
                 mv[0] = m.x; mv[1] = m.y; mv[2] = m.z; mv[3] = m.w;
             } else {
@@ -343,7 +410,17 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW 
             }
             const uint32_t ub_before = L.ub;
             L.ub = 0;
-            stepper.step(mv);
+            if (POLICY) {
+                /* a fresh view of the tile for the tick: keeps the compiler from computing the tick's addresses before the
+                 * policy and carrying them through it (the fused kernel otherwise wants 170 VGPRs) */
+                uint32_t* t2 = t;
+                asm volatile("" : "+v"(t2));
+                LdsEnv<EPW, G> acc2{t2, member};
+                PomStepper<LdsEnv<EPW, G>> stepper2(acc2, L);
+                stepper2.step(mv);
+            } else {
+                stepper.step(mv);
+            }
             new_ub = L.ub != 0;
             L.ub |= ub_before;
             if (env_mode) {
@@ -392,29 +469,14 @@ __global__ __launch_bounds__(64, (G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW 
 /* ---------------------------------------------------------------------------------------------
  * SimpleAgent policy (pom_policy_body.h): one lane per AGENT, the quad 4e..4e+3 = the four agents of env e,
  * 16 envs per wavefront.  The wavefront DMAs record rows 0..91 (board, meta, agents, bombs) of its 16 envs into a shared
- * tile; per env the four lanes together prepare a danger map ([128][16] dwords, LDS atomic min) and three cell sets.  The
- * reachability questions are flood fills on 121-bit cell sets in registers, so a wavefront needs only 15 KB of LDS.  Output:
+ * tile; per env the four lanes together prepare a danger map ([128][16] bytes) and three cell sets.  The reachability
+ * questions are flood fills on 121-bit cell sets in registers, so a wavefront needs only 9 KB of LDS (17 wavefronts per CU).  Output:
  * Move[4] per env into the handle's move buffer, agent memory (2 dwords per agent) updated in place.  A finished env that the
  * next step will restart is read from its snapshot column — or, with fresh boards, drawn here exactly as the tick will draw
  * it — and gets fresh (zero) agent memory, so policy and tick see the same game.
  * ------------------------------------------------------------------------------------------- */
 enum { POL_ROWS = 92, POL_LOAD_ROWS = 96 }; /* the policy reads rows 0..91; they arrive 16 rows per instruction */
 
-struct PolicyStore {
-    const uint32_t* t; /* &tile[env_in_wave], row stride 16 dwords */
-    int* dcol;         /* &danger[env_in_wave], row stride 16 */
-    uint32_t* scol;    /* &sets[env_in_wave], row stride 16 */
-    int who;           /* lane % 4 */
-    __device__ int member() const { return who; }
-    __device__ int danger(int c) const { return dcol[c * 16]; }
-    __device__ void danger_init(int c) { dcol[c * 16] = POM_DANGER_NONE; }
-    __device__ void danger_min(int c, int tm) { atomicMin(&dcol[c * 16], tm); } /* the env's lanes rasterise different bombs */
-    __device__ uint32_t setw(int k) const { return scol[k * 16]; }
-    __device__ void set_put(int k, uint32_t bits) { scol[k * 16] = bits; }
-    __device__ uint32_t board_word(int k) const { return t[k * 16]; }
-    __device__ int cell(int c) const { return reinterpret_cast<const uint16_t*>(t)[(c >> 1) * 32 + (c & 1)]; }
-    __device__ int bomb(int s) const { return (int)t[(POM_REC_BOMBS + s) * 16]; }
-};
 
 struct PolicyParams {
     const uint32_t* state;
@@ -436,7 +498,7 @@ struct PolicyParams {
 __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tile[POL_LOAD_ROWS * 16];
-    __shared__ int danger[128 * 16]; /* 121 cells; the safe-set pass reads whole 32-cell words */
+    __shared__ uint8_t danger[128 * 16]; /* 121 cells; the safe-set pass reads whole 32-cell words */
     __shared__ uint32_t sets[12 * 16];
     const int lane = threadIdx.x;
     const int64_t np = p.n_pad;
@@ -889,6 +951,7 @@ struct PomBatch {
     hipStream_t sub[MAX_PARTS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS] = {};
     bool forked = false;
+    bool fuse_policy = true; /* pom_batch_step_simple: policy and tick in one kernel (quad shape); POM_FUSE=0 keeps them apart */
     /* optional per-launch timing (pom_batch_profile) */
     bool profiling = false;
     hipEvent_t prof_ev[2 * PROF_RING] = {};
@@ -1023,6 +1086,10 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
         delete h;
         return POM_E_ARG;
     }
+    /* measured (MI355X, profiles/r01_fuse.txt): the fused kernel is 4-9 % faster up to 131,072 envs and 3 % slower at 262,144
+     * (it is capped at 128 VGPRs to keep 4 wavefronts per SIMD and parks ~25 long-lived values in scratch) */
+    h->fuse_policy = h->n_pad < 262144;
+    if (const char* ev = getenv("POM_FUSE")) h->fuse_policy = atoi(ev) != 0;
     if (const char* ev = getenv("POM_STREAMS")) {
         const int v = atoi(ev);
         if (v >= 1 && v <= PomBatch::MAX_PARTS) h->parts = v;
@@ -1193,9 +1260,20 @@ static int join_parts(PomBatch* h)
     return POM_OK;
 }
 
-static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int dist, int ticks)
+static int ensure_agent_mem(PomBatch* h)
+{
+    if (!h->agent_mem) {
+        if (int jr = join_parts(h)) return jr; /* the next launch forks the sub-streams again, after this memset */
+        HIPCHK(hipMalloc((void**)&h->agent_mem, (size_t)h->n_pad * 32));
+        HIPCHK(hipMemsetAsync(h->agent_mem, 0, (size_t)h->n_pad * 32, h->stream));
+    }
+    return POM_OK;
+}
+
+static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int dist, int ticks, bool policy = false)
 {
     StepParams p;
+    p.agent_mem = h->agent_mem;
     p.state = h->state;
     p.snap = h->snap;
     p.moves = moves_dev;
@@ -1237,7 +1315,10 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
 #define POM_LAUNCH(E, G) \
     (fresh ? hipExtLaunchKernelGGL((pom_step_kernel<E, G, true>), grid, dim3(64), 0, st, ev0, ev1, 0, p) \
            : hipExtLaunchKernelGGL((pom_step_kernel<E, G, false>), grid, dim3(64), 0, st, ev0, ev1, 0, p))
-        if (h->epw == 64) POM_LAUNCH(64, 1);
+        if (policy) { /* the caller checked h->quad */
+            fresh ? hipExtLaunchKernelGGL((pom_step_kernel<16, 4, true, true>), grid, dim3(64), 0, st, ev0, ev1, 0, p)
+                  : hipExtLaunchKernelGGL((pom_step_kernel<16, 4, false, true>), grid, dim3(64), 0, st, ev0, ev1, 0, p);
+        } else if (h->epw == 64) POM_LAUNCH(64, 1);
         else if (h->epw == 32) POM_LAUNCH(32, 1);
         else if (h->quad) POM_LAUNCH(16, 4);
         else POM_LAUNCH(16, 1);
@@ -1471,10 +1552,7 @@ int pom_batch_set_streams(PomBatch* h, int32_t streams)
 
 static int launch_policy(PomBatch* h, uint64_t seed)
 {
-    if (!h->agent_mem) {
-        HIPCHK(hipMalloc((void**)&h->agent_mem, (size_t)h->n_pad * 32));
-        HIPCHK(hipMemsetAsync(h->agent_mem, 0, (size_t)h->n_pad * 32, h->stream));
-    }
+    if (int rc = ensure_agent_mem(h)) return rc;
     PolicyParams p;
     p.state = h->state;
     p.snap = h->snap;
@@ -1544,6 +1622,14 @@ int pom_batch_step_simple(PomBatch* h, uint64_t seed, int32_t ticks)
 {
     if (!h || ticks < 0) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    if (h->quad && h->fuse_policy) { /* the fused kernel: policy and tick on one load of the record */
+        if (int rc = ensure_agent_mem(h)) return rc;
+        for (int32_t t = 0; t < ticks; t++) {
+            if (int rc = launch_step(h, nullptr, seed, 0, 1, true)) return rc;
+            h->tick += 1;
+        }
+        return POM_OK;
+    }
     for (int32_t t = 0; t < ticks; t++) {
         int rc = launch_policy(h, seed);
         if (!rc) rc = launch_step(h, h->moves_dev, 0, 0, 1);

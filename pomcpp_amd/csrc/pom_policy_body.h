@@ -24,15 +24,15 @@
  * (moveQueue.index is always 0: the queue is never popped).  All-zero = a fresh agent.
  *
  * Per env and tick some things are prepared ONCE, by the four lanes of the env together (pom_policy_prepare_*), instead of being
- * recomputed per query: the danger map — IsInDanger(x, y) for every cell: each bomb's cross rasterised with an LDS atomic min
- * of its timer — and three 121-bit cell sets, "walkable", "agent" and "safe", one 32-cell word per lane, which the floods and
+ * recomputed per query: the danger map — IsInDanger(x, y) for every cell: the minimum timer over the bombs whose cross covers
+ * it, a byte per cell — and three 121-bit cell sets, "walkable", "agent" and "safe", one 32-cell word per lane, which the floods and
  * the safe-place scan work on in registers instead of reading cells.
  *
  * Store interface P:  int cell(int c)            16-bit board code (pom_packed.h), c = y*11+x
  *                     int bomb(int slot)         raw bomb word of physical slot
  *                     uint32_t board_word(int k) board dword k = cells 2k (low half) and 2k+1; k up to 63 must be readable
- *                     int danger(int c) / void danger_init(int c) / void danger_min(int c, int t)     per-env danger map, 128
- *                                                entries (c up to 127 must be readable)
+ *                     int danger(int c) / void danger_init(int c) / void danger_put(int c, int t)     per-env danger map, 128
+ *                                                entries of at least 8 bits (c up to 127 must be readable)
  *                     uint32_t setw(int k) / void set_put(int k, uint32_t bits)   per-env cell sets, words
  *                                                k = 0..3 walkable, 4..7 agents, 8..11 "safe" (_safe_condition(IsInDanger))
  *                     int member()               which of the env's 4 lanes this is
@@ -115,17 +115,21 @@ POM_HD void pom_policy_prepare_fill(P& p, const PomPolicyEnv& E)
     p.set_put(m, w & keep);
     p.set_put(4 + m, g & keep);
     /* IsInDanger for every cell at once: min BMB_TIME over the bombs whose cross (IsInBombRange, strategy.hpp:163-169: the
-     * +-strength row and column segments through the bomb, walls ignored) covers the cell */
+     * +-strength row and column segments through the bomb, walls ignored) covers the cell.  Every lane walks every bomb and
+     * takes one ARM of its cross (member 0: centre and +x, 1: -x, 2: +y, 3: -y): within a bomb the four lanes touch
+     * different cells and the bombs come one after the other, so the minimum needs no atomic and the map can be bytes. */
+    const int dx = (m == 0) - (m == 1), dy = (m == 2) - (m == 3);
     POM_NOUNROLL
-    for (int i = m; i < E.bCnt; i += 4) {
+    for (int i = 0; i < E.bCnt; i++) {
         const int b = p.bomb(wrap20(E.bIdx + i));
         const int bx = pb_x(b), by = pb_y(b), s = pb_strength(b), t = pb_time(b);
         if (bx >= POM_N || by >= POM_N) continue; /* upload validates live bombs; a stale word cannot index the map */
         POM_NOUNROLL
-        for (int k = -s; k <= s; k++) {
-            const int x = bx + k, y = by + k;
-            if (x >= 0 && x < POM_N) p.danger_min(by * POM_N + x, t);
-            if (y >= 0 && y < POM_N) p.danger_min(y * POM_N + bx, t);
+        for (int k = m == 0 ? 0 : 1; k <= s; k++) {
+            const int x = bx + k * dx, y = by + k * dy;
+            if (x < 0 || x >= POM_N || y < 0 || y >= POM_N) break;
+            const int c = y * POM_N + x;
+            if (t < p.danger(c)) p.danger_put(c, t);
         }
     }
 }

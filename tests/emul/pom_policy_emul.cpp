@@ -16,7 +16,7 @@ struct PolicyArrays {
     int member() const { return who; }
     int danger(int c) const { return dmap[c]; }
     void danger_init(int c) { dmap[c] = POM_DANGER_NONE; }
-    void danger_min(int c, int t) { dmap[c] = t < dmap[c] ? t : dmap[c]; }
+    void danger_put(int c, int t) { dmap[c] = t; }
     uint32_t setw(int k) const { return sets[k]; }
     void set_put(int k, uint32_t bits) { sets[k] = bits; }
     int cell(int c) const { return cells[c]; }
