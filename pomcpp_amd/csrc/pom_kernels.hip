@@ -615,11 +615,14 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
 
 /* ------------------------------------------------------------------------------------------------
  * Observation export (row f4, pom_batch.h pom_batch_observe).  A wavefront takes a tile of 16 envs into LDS as the tick does,
- * then four envs at a time: zero a 4 x 1936-byte staging area, scatter one byte per cell / bomb (each cell sets exactly one
+ * then env by env: zero a 1936-byte staging area, scatter one byte per cell / bomb (each cell sets exactly one
  * of the planes 0..11), and stream the area out — for uint8 global views a straight 16-byte copy, fully coalesced; other
  * element types and the per-agent plane order take runs of 4 bytes through a byte funnel, convert and store 4 elements.  HBM-write-bound: 1936 B x elements per env.
  * ------------------------------------------------------------------------------------------- */
-enum { OBS_ENV_BYTES = POM_OBS_PLANES * POM_CELLS, OBS_PASS_ENVS = 4 };
+#ifndef POM_OBS_PASS_ENVS
+#define POM_OBS_PASS_ENVS 1 /* envs staged at a time: 1 keeps the wavefront at 9 KB of LDS (17 per CU); 4 needed 15 KB and ran 25 % slower */
+#endif
+enum { OBS_ENV_BYTES = POM_OBS_PLANES * POM_CELLS, OBS_PASS_ENVS = POM_OBS_PASS_ENVS };
 static_assert(OBS_ENV_BYTES % 16 == 0, "an env's planes are a whole number of 16-byte stores");
 
 struct ObserveParams {
