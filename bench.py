@@ -315,6 +315,28 @@ def main() -> None:
         config3 = {"workload": f"{args.envs} envs, 4x SimpleAgent policy on the device + Step, games from the start, "
                                "200 warm-up ticks", "value": plan["n_envs"] / (ms_c * 1e-3),
                    "unit": "env-steps/s", "ms_per_step": ms_c, "steps": n_c}
+    # BASELINE's other single-GPU configs, briefly (untimed region, default run only): config 2 (4,096 envs, random moves) and
+    # config 5 (65,536 envs, kick / chain-explosion stress boards and move mix) — parity-test cases first, numbers for context
+    other = None
+    default_run = (args.envs == 65536 and args.kind == "ffa" and args.dist == "random" and not args.fresh_boards)
+    if world == 1 and args.policy == "random" and tpl == 1 and not args.no_config3 and default_run:
+        other = {}
+        for name, n_o, kind_o, dist_o in (("config2_4096_envs_random", 4096, "ffa", 1), ("config5_65536_envs_stress", 65536, "stress", 2)):
+            e2 = BatchEnvironment(n_o, device=local_rank, mode=MODE_ENV, auto_reset=True, max_steps=args.max_steps,
+                                  stream=stream.cuda_stream)
+            e2.make_game(pa.make_boards(n_o, seed=args.seed * 1000003, kind=kind_o))
+            e2.step_random(args.seed, dist_o, ticks=60)
+            e2.sync()
+            ev4, ev5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n_o_steps = 200
+            ev4.record(stream)
+            e2.step_random(args.seed, dist_o, ticks=n_o_steps)
+            e2.flush()
+            ev5.record(stream)
+            e2.sync()
+            ms_o = ev4.elapsed_time(ev5) / n_o_steps
+            other[name] = {"value": n_o / (ms_o * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_o, "steps": n_o_steps}
+            e2.close()
     total_steps = int(counters[CNT_STEPS].item())
     expect = plan["global_envs"] * args.steps * tpl
     if total_steps != expect:
@@ -356,6 +378,8 @@ def main() -> None:
         }
         if config3:
             line["config3_simple_agent"] = config3
+        if other:
+            line["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(start, args.seed, dist_id, args.max_steps)
         print(json.dumps(line), flush=True)
