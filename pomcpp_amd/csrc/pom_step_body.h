@@ -142,6 +142,8 @@ template <class A>
 struct PomStepper {
     A& a;
     PomLane& L;
+    uint32_t oldp_ = 0; /* the agents' positions before the tick, a byte each (x | y << 4) */
+    int irregular_ = 0; /* a bounce put an agent somewhere else than where he stood before the tick */
     POM_HD PomStepper(A& a_, PomLane& l_) : a(a_), L(l_) {}
 
     POM_HD int bomb_at(int i) const { return a.bomb(wrap20(L.bIdx + i)); }
@@ -455,6 +457,7 @@ struct PomStepper {
                 }
             }
             put4(id, L.a0, ag_setpos(av, ox, oy));
+            irregular_ |= (ox | (oy << 4)) != (int)((oldp_ >> (8 * id)) & 0xFF);
             a.set_cell(oy * POM_N + ox, POM_C_AGENT | id);
             if (origin_agent != -1) {
                 id = origin_agent;
@@ -524,6 +527,32 @@ struct PomStepper {
     }
 
     /* ------------------------------------------------------------------ */
+    /* one bomb of loop A, step.cpp:197-226 */
+    POM_HD void loop_a_bomb(int mvp, int oldp, int k)
+    {
+        const int b = bomb_at(k);
+        const int bx = pb_x(b), by = pb_y(b), d = pb_dir(b);
+        const int tx = bx + mv_dx(d), ty = by + mv_dy(d);
+        int blocked = oob(tx, ty);
+        if (!blocked) {
+            const int e = a.cell(ty * POM_N + tx);
+            blocked = pc_is_static_block(e) || pc_is_agent(e);
+        }
+        if (blocked) {
+            set_bomb_at(k, pb_set(b, 0xF00000u, 0));
+            const int ag = get_agent(bx, by);
+            if (ag > -1) {
+                const int m = (mvp >> (4 * ag)) & 0xF;
+                const int av = sel4(ag, L.a0);
+                const int was = (oldp >> (8 * ag)) & 0xFF;
+                if (m != POM_MOVE_IDLE && m != POM_MOVE_BOMB && (ag_x(av) | (ag_y(av) << 4)) != was) {
+                    chain_reversion(mvp, ag);
+                    if (get_agent(bx, by) == -1) a.set_cell(by * POM_N + bx, POM_C_BOMB);
+                }
+            }
+        }
+    }
+
     POM_HD void step(const int mv_in[4])
     {
         tick_flames(); /* step.cpp:15 */
@@ -548,6 +577,7 @@ struct PomStepper {
             dx[i] = px[i] + mv_dx(mv[i]);
             dy[i] = py[i] + mv_dy(mv[i]);
             oldp |= (uint32_t)(px[i] | (py[i] << 4)) << (8 * i);
+            oldp_ = oldp;
         }
         /* Does any agent's destination touch another agent's cell (dead agents included: SURVEY Q9)?  If not — the usual
          * case, the agents are far apart — FixSwitchMove changes nothing and ResolveDependencies makes everyone a root in
@@ -809,7 +839,8 @@ struct PomStepper {
             /* ResetBombFlags + FillBombDestPos, step_utility.cpp:331-337,146-152.  The same pass notes whether any
              * bomb of this env is moving and whether two bombs share a cell (121-bit occupancy in 4 registers):
              * if neither, loop B below cannot see a collision and collapses to one cell test per bomb. */
-            int moving = 0, shared = 0, bounce = 0;
+            int moving = 0, shared = 0;
+            uint32_t cand = 0; /* queue offsets of the resting bombs under an agent that walked onto them this tick */
             uint32_t occ[4] = {0, 0, 0, 0};
             POM_NOUNROLL
             for (int k = a.sub(); k < L.bCnt; k += A::G) { /* split: each lane its own slots, combined below */
@@ -835,12 +866,12 @@ struct PomStepper {
                         if (ag > -1) {
                             const int m2 = (mvp >> (4 * ag)) & 0xF;
                             const int was = (oldp >> (8 * ag)) & 0xFF;
-                            bounce |= m2 != POM_MOVE_IDLE && m2 != POM_MOVE_BOMB && pb_pos(b) != was;
+                            if (m2 != POM_MOVE_IDLE && m2 != POM_MOVE_BOMB && pb_pos(b) != was) cand |= 1u << k;
                         }
                     }
                 }
             }
-            bounce = a.gor(bounce);
+            cand = (uint32_t)a.gor((int)cand);
             if (A::G > 1) { /* two lanes' bombs share a cell iff the lanes' cell sets overlap: |union| < sum of |set| */
                 int mine = 0, all = 0;
 #pragma unroll
@@ -852,34 +883,27 @@ struct PomStepper {
                 moving = a.gor(moving);
             }
             /* bomb loop A, step.cpp:195-227.  A resting bomb's "target" is its own cell: it is blocked iff an agent item (or,
-             * never in practice, a static item) shows there; setting an idle bomb idle changes nothing, so the loop only
-             * matters when some agent that moved this tick has to be bounced back.  Split: look first. */
-            const int loop_a = moving | bounce;
-            if (loop_a)
-            POM_NOUNROLL
-            for (int k = 0; k < L.bCnt; k++) {
-                const int b = bomb_at(k);
-                const int bx = pb_x(b), by = pb_y(b), d = pb_dir(b);
-                const int tx = bx + mv_dx(d), ty = by + mv_dy(d);
-                int blocked = oob(tx, ty);
-                if (!blocked) {
-                    const int e = a.cell(ty * POM_N + tx);
-                    blocked = pc_is_static_block(e) || pc_is_agent(e);
+             * never in practice, a static item) shows there; setting an idle bomb idle changes nothing, so while no bomb moves
+             * the loop only matters for the bombs noted above, whose agent has to be bounced back — and only those are
+             * visited, in queue order.  (A bounce only ever puts agents back where they stood before the tick: an agent it
+             * brings onto another resting bomb has position == old position there and is not bounced, so no bomb outside the
+             * noted set can come to matter during the loop.)  With a moving bomb in the queue the whole loop runs. */
+            int next = 0; /* loop A is done for the offsets below `next` */
+            if (!moving) {
+                irregular_ = 0;
+                POM_NOUNROLL
+                while (cand && !irregular_) {
+                    const int k = __builtin_ctz(cand);
+                    cand &= cand - 1u;
+                    loop_a_bomb(mvp, oldp, k);
+                    next = k + 1;
                 }
-                if (blocked) {
-                    set_bomb_at(k, pb_set(b, 0xF00000u, 0));
-                    const int ag = get_agent(bx, by);
-                    if (ag > -1) {
-                        const int m = (mvp >> (4 * ag)) & 0xF;
-                        const int av = sel4(ag, L.a0);
-                        const int was = (oldp >> (8 * ag)) & 0xFF;
-                        if (m != POM_MOVE_IDLE && m != POM_MOVE_BOMB && (ag_x(av) | (ag_y(av) << 4)) != was) {
-                            chain_reversion(mvp, ag);
-                            if (get_agent(bx, by) == -1) a.set_cell(by * POM_N + bx, POM_C_BOMB);
-                        }
-                    }
-                }
+                /* the argument above holds as long as every bounce was a plain step back; after any other (two agents on one
+                 * cell: states past a lost-agent tick) the rest of the queue is walked bomb by bomb */
+                if (!irregular_) next = L.bCnt;
             }
+            POM_NOUNROLL
+            for (int k = next; k < L.bCnt; k++) loop_a_bomb(mvp, oldp, k);
             POM_STAMP(L, POM_PH_BOMB_A);
             /* bomb loop B, step.cpp:230-278 */
             if (!moving && !shared) {
