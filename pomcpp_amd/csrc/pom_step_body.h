@@ -67,8 +67,8 @@
 #else
 #define POM_STAMP(L, k) ((void)0)
 #endif
-enum { POM_PH_LOAD = 0, POM_PH_FLAMES, POM_PH_AGENT_PREP, POM_PH_AGENT_LOOP, POM_PH_BOMB_A, POM_PH_BOMB_B, POM_PH_TICK_BOMBS,
-       POM_PH_EPILOGUE, POM_PH_STORE, POM_PH_N };
+enum { POM_PH_LOAD = 0, POM_PH_FLAMES, POM_PH_AGENT_PREP, POM_PH_AGENT_LOOP, POM_PH_BOMB_PASS, POM_PH_BOMB_A, POM_PH_BOMB_B,
+       POM_PH_TICK_BOMBS, POM_PH_EPILOGUE, POM_PH_STORE, POM_PH_N };
 
 struct PomLane { /* the register-resident part of one env */
     int a0[4];   /* x:8 | y:8 | bombCount:8 | canKick@24 | dead@25 — only ever indexed statically */
@@ -448,14 +448,16 @@ struct PomStepper {
             if (oob(ox, oy)) return;
             const int origin_agent = get_agent(ox, oy);
             const int okey = (ox + 1) | ((oy + 1) << 4);
-            int bd = -1;
+            int bd = 99; /* the first bomb heading for the origin cell; split: lane `sub` looks at offsets sub, sub+G, ... */
             POM_NOUNROLL
-            for (int i = 0; i < L.bCnt; i++) {
+            for (int i = a.sub(); i < L.bCnt; i += A::G) {
                 if (a.bdest(i) == okey) {
                     bd = i;
                     break;
                 }
             }
+            bd = a.gmin(bd);
+            if (bd == 99) bd = -1;
             put4(id, L.a0, ag_setpos(av, ox, oy));
             irregular_ |= (ox | (oy << 4)) != (int)((oldp_ >> (8 * id)) & 0xFF);
             a.set_cell(oy * POM_N + ox, POM_C_AGENT | id);
@@ -888,6 +890,7 @@ struct PomStepper {
              * visited, in queue order.  (A bounce only ever puts agents back where they stood before the tick: an agent it
              * brings onto another resting bomb has position == old position there and is not bounced, so no bomb outside the
              * noted set can come to matter during the loop.)  With a moving bomb in the queue the whole loop runs. */
+            POM_STAMP(L, POM_PH_BOMB_PASS);
             int next = 0; /* loop A is done for the offsets below `next` */
             if (!moving) {
                 irregular_ = 0;
