@@ -106,6 +106,10 @@ int pom_batch_step_random(PomBatch* h, uint64_t seed, int32_t dist, int32_t tick
 int pom_batch_policy_simple(PomBatch* h, uint64_t seed, int32_t* moves_out_host);
 int pom_batch_step_policy(PomBatch* h);
 int pom_batch_step_simple(PomBatch* h, uint64_t seed, int32_t ticks);
+/* the handle's move buffer in device memory, int32[n_envs][4]: what pom_batch_policy_simple fills and pom_batch_step_policy
+ * consumes.  A device-side consumer may overwrite entries in between (on the handle's stream, see pom_batch_stream) — e.g. a
+ * learned policy for agent 0 playing against three SimpleAgents — without a host round trip. */
+int pom_batch_moves_device(PomBatch* h, int32_t** moves_dev);
 /* agent memory of envs [first, first+count): 16 int32 per agent, 4 agents per env: recentPositions {x,y}x4, index, count,
  * moveQueue x4, index, count (the members of SimpleAgent that survive between act() calls) */
 int pom_batch_policy_memory(PomBatch* h, int64_t first, int64_t count, int32_t* out16);

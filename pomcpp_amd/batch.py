@@ -79,6 +79,7 @@ def load_library() -> C.CDLL:
     lib.pom_batch_size.restype = I64
     lib.pom_batch_observe.argtypes = [P, VP, I32, I32, VP, VP]
     lib.pom_batch_stream.argtypes = [P, C.POINTER(C.c_void_p)]
+    lib.pom_batch_moves_device.argtypes = [P, C.POINTER(C.POINTER(C.c_int32))]
     lib.pom_batch_generate.argtypes = [P, U64]
     lib.pom_batch_episodes.argtypes = [P, I64, I64, VP]
     lib.pom_batch_upload.argtypes = [P, VP, I64, I64]
@@ -267,6 +268,19 @@ class BatchEnvironment:
         if mine.cuda_stream != theirs.cuda_stream:
             theirs.wait_stream(mine)
         return out, a_attrs, e_attrs
+
+    def moves_tensor(self):
+        """The handle's device move buffer as a torch int32 tensor [n, 4] (zero-copy): what policy_simple() fills and
+        step_policy() consumes; overwrite entries on the handle's stream to mix in another policy."""
+        import torch
+        ptr = C.POINTER(C.c_int32)()
+        _check(self._lib, self._lib.pom_batch_moves_device(self._h, C.byref(ptr)))
+        addr = C.cast(ptr, C.c_void_p).value
+
+        class _Raw:  # the CUDA array interface is how torch adopts foreign device memory
+            __cuda_array_interface__ = {"shape": (self.n, 4), "typestr": "<i4", "data": (addr, False), "version": 2}
+
+        return torch.as_tensor(_Raw(), device=torch.device("cuda", self.device))
 
     def stream_handle(self) -> int:
         """the hipStream_t (as an integer) this handle's work is ordered on"""

@@ -1485,6 +1485,15 @@ int pom_batch_episodes(PomBatch* h, int64_t first, int64_t count, uint32_t* out)
     return POM_OK;
 }
 
+int pom_batch_moves_device(PomBatch* h, int32_t** moves_dev)
+{
+    if (!h || !moves_dev) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr; /* what the caller queues on the handle's stream next sees the policy's moves */
+    *moves_dev = h->moves_dev;
+    return POM_OK;
+}
+
 int pom_batch_stream(PomBatch* h, void** stream)
 {
     if (!h || !stream) return POM_E_ARG;

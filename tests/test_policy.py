@@ -97,3 +97,34 @@ def test_gpu_step_simple_with_autoreset_matches_oracle(hip_lib, oracle, n, strea
         # uploading envs again gives them fresh agents
         env.make_game(start[:10], first=0)
         assert not env.policy_memory(0, 10).any() and env.policy_memory(10, 5).any()
+
+
+@pytest.mark.gpu
+def test_mixed_play_through_the_device_move_buffer(hip_lib, oracle):
+    """agent 0 follows an outside policy (here: always IDLE unless dead) written into the device move buffer, agents 1..3 are
+    SimpleAgents: policy_simple -> overwrite column 0 on the handle's stream -> step_policy, against the oracle"""
+    import torch
+    from pomcpp_amd.batch import BatchEnvironment, MODE_ENV
+    n, seed = 600, 4
+    start = pa.make_boards(n, seed=8)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        env = BatchEnvironment(n, mode=MODE_ENV, auto_reset=False, stream=stream.cuda_stream)
+        env.make_game(start)
+        ref = start.copy()
+        mems = np.zeros((n, 4, 16), dtype=np.int32)
+        for t in range(40):
+            env.policy_simple(seed)
+            mv = env.moves_tensor()
+            mv[:, 0] = int(Move.IDLE)
+            env.step_policy()
+            done = (ref["aliveAgents"] <= 1).astype(np.int32)
+            want = oracle.simple_policy(ref, mems, seed, 0, t, done)
+            want[:, 0] = int(Move.IDLE)
+            for e in range(n):
+                if not done[e]:
+                    oracle.step(ref[e:e + 1], want[e])
+                    ref["timeStep"][e] += 1
+        assert env.get_state().tobytes() == ref.tobytes()
+        assert np.array_equal(env.policy_memory(), mems)
+        env.close()
