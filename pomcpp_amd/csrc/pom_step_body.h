@@ -433,7 +433,9 @@ struct PomStepper {
     }
 
     /* AgentBombChainReversion, step_utility.cpp:62-128; mvp = moves, one nibble per agent */
-    POM_HD void chain_reversion(uint32_t mvp, int id)
+    /* `bombs_move` = 0: the caller knows that no queued bomb has a direction.  A resting bomb on the origin cell changes
+     * nothing about the bounce (the agent item is put there either way and the chain ends), so the queue is not searched. */
+    POM_HD void chain_reversion(uint32_t mvp, int id, int bombs_move = 1)
     {
         POM_NOUNROLL
         for (int hop = 0;; hop++) {
@@ -448,16 +450,19 @@ struct PomStepper {
             if (oob(ox, oy)) return;
             const int origin_agent = get_agent(ox, oy);
             const int okey = (ox + 1) | ((oy + 1) << 4);
-            int bd = 99; /* the first bomb heading for the origin cell; split: lane `sub` looks at offsets sub, sub+G, ... */
-            POM_NOUNROLL
-            for (int i = a.sub(); i < L.bCnt; i += A::G) {
-                if (a.bdest(i) == okey) {
-                    bd = i;
-                    break;
+            int bd = -1; /* the first bomb heading for the origin cell; split: lane `sub` looks at offsets sub, sub+G, ... */
+            if (bombs_move) {
+                bd = 99;
+                POM_NOUNROLL
+                for (int i = a.sub(); i < L.bCnt; i += A::G) {
+                    if (a.bdest(i) == okey) {
+                        bd = i;
+                        break;
+                    }
                 }
+                bd = a.gmin(bd);
+                if (bd == 99) bd = -1;
             }
-            bd = a.gmin(bd);
-            if (bd == 99) bd = -1;
             put4(id, L.a0, ag_setpos(av, ox, oy));
             irregular_ |= (ox | (oy << 4)) != (int)((oldp_ >> (8 * id)) & 0xFF);
             a.set_cell(oy * POM_N + ox, POM_C_AGENT | id);
@@ -530,7 +535,7 @@ struct PomStepper {
 
     /* ------------------------------------------------------------------ */
     /* one bomb of loop A, step.cpp:197-226 */
-    POM_HD void loop_a_bomb(int mvp, int oldp, int k)
+    POM_HD void loop_a_bomb(int mvp, int oldp, int k, int bombs_move)
     {
         const int b = bomb_at(k);
         const int bx = pb_x(b), by = pb_y(b), d = pb_dir(b);
@@ -548,7 +553,7 @@ struct PomStepper {
                 const int av = sel4(ag, L.a0);
                 const int was = (oldp >> (8 * ag)) & 0xFF;
                 if (m != POM_MOVE_IDLE && m != POM_MOVE_BOMB && (ag_x(av) | (ag_y(av) << 4)) != was) {
-                    chain_reversion(mvp, ag);
+                    chain_reversion(mvp, ag, bombs_move);
                     if (get_agent(bx, by) == -1) a.set_cell(by * POM_N + bx, POM_C_BOMB);
                 }
             }
@@ -898,7 +903,7 @@ struct PomStepper {
                 while (cand && !irregular_) {
                     const int k = __builtin_ctz(cand);
                     cand &= cand - 1u;
-                    loop_a_bomb(mvp, oldp, k);
+                    loop_a_bomb(mvp, oldp, k, 0);
                     next = k + 1;
                 }
                 /* the argument above holds as long as every bounce was a plain step back; after any other (two agents on one
@@ -906,7 +911,7 @@ struct PomStepper {
                 if (!irregular_) next = L.bCnt;
             }
             POM_NOUNROLL
-            for (int k = next; k < L.bCnt; k++) loop_a_bomb(mvp, oldp, k);
+            for (int k = next; k < L.bCnt; k++) loop_a_bomb(mvp, oldp, k, moving);
             POM_STAMP(L, POM_PH_BOMB_A);
             /* bomb loop B, step.cpp:230-278 */
             if (!moving && !shared) {
