@@ -389,20 +389,24 @@ struct PomStepper {
     POM_HD void tick_flames() /* step_utility.cpp:208-222 + PopFlame bboard.cpp:148-180 */
     {
         if (L.fCnt <= 0) return;
+        int top = 0; /* the head of the queue after the decrement, as the lane that owns offset 0 wrote it */
         {   /* timeLeft-- of every queued flame; split over the lanes (offsets i and i+20 fall to the same lane) */
             int p = L.fIdx + a.sub();
             p = wrap20(p);
             POM_NOUNROLL
             for (int i = a.sub(); i < L.fCnt; i += A::G) {
                 const int f = a.flame(p);
-                a.put_flame(p, (f & ~0xFF0000) | ((f - 0x10000) & 0xFF0000));
+                const int nf = (f & ~0xFF0000) | ((f - 0x10000) & 0xFF0000);
+                a.put_flame(p, nf);
+                if (i == 0) top = nf;
                 p = wrap20(p + A::G);
             }
+            top = a.template gbcast<0>(top);
         }
         const int n = L.fCnt;
         POM_NOUNROLL
         for (int k = 0; k < n; k++) {
-            const int f = a.flame(L.fIdx);
+            const int f = k == 0 ? top : a.flame(L.fIdx); /* the first look needs no trip to the queue */
             if (((f >> 16) & 0xFF) != 0) break; /* nothing pops, so flames[0] stays what it is for the remaining rounds */
             /* PopFlame: every flame cell on the +-strength cross that carries this origin's id gives way to the item
              * under it.  The cells are independent: the four arms are split over the lanes, the centre is the owner's */
@@ -979,13 +983,18 @@ struct PomStepper {
             }
             POM_STAMP(L, POM_PH_BOMB_B);
             /* TickBombs, step_utility.cpp:224-245 */
+            int top = 0; /* the head of the queue after the decrement, as the lane that owns offset 0 wrote it */
             POM_NOUNROLL
-            for (int k = a.sub(); k < L.bCnt; k += A::G) /* split */
-                put_bomb_at(k, (int)((uint32_t)bomb_at(k) - (1u << 16)));
+            for (int k = a.sub(); k < L.bCnt; k += A::G) { /* split */
+                const int nb = (int)((uint32_t)bomb_at(k) - (1u << 16));
+                put_bomb_at(k, nb);
+                if (k == 0) top = nb;
+            }
+            top = a.template gbcast<0>(top);
             const int n = L.bCnt;
             POM_NOUNROLL
             for (int k = 0; k < n && L.bCnt > 0; k++) {
-                const int c = bomb_at(0);
+                const int c = k == 0 ? top : bomb_at(0); /* the first look needs no trip to the queue */
                 if (pb_time(c) != 0) break;
                 explode(pb_x(c), pb_y(c), pb_strength(c), REM_TOP);
             }

@@ -77,8 +77,10 @@ def test_gpu_policy_moves_memory_and_states_match_oracle(hip_lib, oracle, kind, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,streams", [(4096 + 5, 1), (4096 + 5, 3)])
-def test_gpu_step_simple_with_autoreset_matches_oracle(hip_lib, oracle, n, streams):
+@pytest.mark.parametrize("n,streams,shape", [(4096 + 5, 1, {}), (4096 + 5, 3, {}),
+                                             # one lane per env: the policy kernel and the tick stay two launches
+                                             (2048 + 3, 2, dict(lanes_per_env=1, envs_per_wave=16)), (1000, 1, dict(envs_per_wave=64))])
+def test_gpu_step_simple_with_autoreset_matches_oracle(hip_lib, oracle, n, streams, shape):
     from pomcpp_amd.batch import BatchEnvironment, MODE_ENV, CNT_STEPS, CNT_RESETS
     ticks, seed = 150, 5
     start = pa.make_boards(n, seed=4)
@@ -86,7 +88,7 @@ def test_gpu_step_simple_with_autoreset_matches_oracle(hip_lib, oracle, n, strea
     mem = np.zeros((n, 4, 16), dtype=np.int32)
     steps = oracle.run_simple(want, start, mem, ticks, seed, 0, 0, 800)
     want["agents"]["pad"] = 0
-    with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800, streams=streams) as env:
+    with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800, streams=streams, **shape) as env:
         env.make_game(start)
         env.step_simple(seed, ticks)
         got = env.get_state()
