@@ -168,9 +168,18 @@ struct PomStepper {
     /* the same scan done by ONE lane alone, for split code in which the lanes of a group look at different cells */
     POM_HD int bomb_index_alone(int pos) const
     {
+        /* four slots per round, their reads in flight together (one LDS round trip per four bombs instead of one per bomb);
+         * offsets past the count read stale slots of the ring, which the count test discards */
         POM_NOUNROLL
-        for (int i = 0; i < L.bCnt; i++)
-            if (pb_pos(bomb_at(i)) == pos) return i;
+        for (int i = 0; i < L.bCnt; i += 4) {
+            const int b0 = bomb_at(i), b1 = bomb_at(i + 1), b2 = bomb_at(i + 2), b3 = bomb_at(i + 3);
+            int r = -1;
+            r = (i + 3 < L.bCnt && pb_pos(b3) == pos) ? i + 3 : r;
+            r = (i + 2 < L.bCnt && pb_pos(b2) == pos) ? i + 2 : r;
+            r = (i + 1 < L.bCnt && pb_pos(b1) == pos) ? i + 1 : r;
+            r = pb_pos(b0) == pos ? i : r;
+            if (r >= 0) return r;
+        }
         return -1;
     }
 
