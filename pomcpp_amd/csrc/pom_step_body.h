@@ -248,17 +248,17 @@ struct PomStepper {
     }
 
     /* SpawnFlame prologue, bboard.cpp:200-218 */
-    POM_HD void flame_prologue(int x, int y, int strength)
+    POM_HD void flame_prologue(int x, int y, int strength, int e /* the origin cell, as it shows now */)
     {
         int slot = L.fIdx + L.fCnt; /* NextPos(): (index + count) % 20, count may exceed 20 (see tick_flames) */
         slot = slot >= 2 * POM_Q ? slot % POM_Q : wrap20(slot);
         a.set_flame(slot, x | (y << 8) | (POM_FLAME_LIFETIME << 16) | ((strength & 0xFF) << 24));
         L.fCnt++;
         const int c = y * POM_N + x;
-        const int e = a.cell(c);
         if (pc_is_agent(e)) kill(e & 0x3FFF);
         a.set_cell(c, POM_C_FLAME | (c << 3));
     }
+    POM_HD void flame_prologue(int x, int y, int strength) { flame_prologue(x, y, strength, a.cell(y * POM_N + x)); }
 
     /* bookkeeping after a frame's four rays: ExplodeTopBomb's PopBomb / ExplodeBombAt's RemoveAt */
     POM_HD void explode_epilogue(int rem)
@@ -281,7 +281,8 @@ struct PomStepper {
         return room < s ? room : s;
     }
 
-    POM_HD void explode(int x, int y, int strength, int rem)
+    /* `top_word`: for rem == REM_TOP the caller may pass the head of the queue it has just looked at (-1: not known) */
+    POM_HD void explode(int x, int y, int strength, int rem, int top_word = -1)
     {
         int s = strength < 0 ? 0 : strength > POM_N ? POM_N : strength;
         /* Split fast path.  Read-only scan of the four rays (lane `sub` takes rays sub, sub+G, ...): how far does
@@ -291,8 +292,10 @@ struct PomStepper {
          * sequential engine below runs (replicated). */
         {
             const int c0 = y * POM_N + x;
+            const int e0 = a.cell(c0); /* the origin, read together with the rays' first cells: nothing is written before the vote */
             int chains = 0, victims = 0;
             uint32_t lens = 0; /* reach of ray r in nibble r */
+            uint32_t ends = 0; /* power-up flag of the wood a ray ends on, 2 bits per ray (only a ray's last cell can be wood) */
             POM_NOUNROLL
             for (int r = a.sub(); r < 4; r += A::G) {
                 const int lim = ray_room(x, y, s, r);
@@ -312,27 +315,36 @@ struct PomStepper {
                     }
                     if (e == POM_C_RIGID) break;
                     len = i;
-                    if (pc_is_wood(e)) break;
+                    if (pc_is_wood(e)) {
+                        ends |= (uint32_t)(e & 3) << (2 * r);
+                        break;
+                    }
                 }
                 lens |= (uint32_t)len << (4 * r);
             }
             if (!a.gor(chains)) {
-                flame_prologue(x, y, strength);
+                flame_prologue(x, y, strength, e0);
                 victims = a.gor(victims);
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if ((victims >> j) & 1) kill(j);
+                for (int j = 0; j < 4; j++) { /* Kill, bboard.hpp:474-481, for every agent a ray met */
+                    const int hit = (victims >> j) & 1 & !ag_dead(L.a0[j]);
+                    L.a0[j] |= hit << 25;
+                    L.alive -= hit;
+                }
                 POM_NOUNROLL
-                for (int r = a.sub(); r < 4; r += A::G) {
+                for (int r = a.sub(); r < 4; r += A::G) { /* no reads: the scan has seen every cell it writes */
                     const int len = (lens >> (4 * r)) & 0xF;
                     POM_NOUNROLL
-                    for (int i = 1; i <= len; i++) {
-                        const int c = ray_cell(c0, r, i);
-                        const int e = a.cell(c);
-                        a.put_cell(c, POM_C_FLAME | ((c0 << 3) + (pc_is_wood(e) ? (e & 3) : 0)));
-                    }
+                    for (int i = 1; i <= len; i++)
+                        a.put_cell(ray_cell(c0, r, i), POM_C_FLAME | ((c0 << 3) + (i == len ? (int)((ends >> (2 * r)) & 3u) : 0)));
                 }
-                explode_epilogue(rem);
+                if (rem == REM_TOP && top_word != -1) { /* nothing touched the queue: the head is still the word the caller saw */
+                    owner_bombcount_dec(top_word);
+                    L.bIdx = wrap20(L.bIdx + 1);
+                    L.bCnt--;
+                } else {
+                    explode_epilogue(rem);
+                }
                 return;
             }
         }
@@ -1005,7 +1017,7 @@ struct PomStepper {
             for (int k = 0; k < n && L.bCnt > 0; k++) {
                 const int c = k == 0 ? top : bomb_at(0); /* the first look needs no trip to the queue */
                 if (pb_time(c) != 0) break;
-                explode(pb_x(c), pb_y(c), pb_strength(c), REM_TOP);
+                explode(pb_x(c), pb_y(c), pb_strength(c), REM_TOP, c);
             }
         }
         POM_STAMP(L, POM_PH_TICK_BOMBS);
