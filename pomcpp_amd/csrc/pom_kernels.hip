@@ -243,11 +243,13 @@ struct PolicyStore {
     __device__ int bomb(int s) const { return (int)t[(POM_REC_BOMBS + s) * 16]; }
 };
 
-/* occupancy target of the quad kernel.  It needs 107 VGPRs since its tile mirrors the whole record (no per-row global
- * addresses live across the tick), so 4 wavefronts per SIMD fit anyway; the target only forbids the compiler to squeeze
- * further (an earlier 157-VGPR version capped at 128 spilled 60 B/lane and ran 12 % slower, profiles/r01_quad.txt) */
+/* occupancy target of the quad kernel: 4 wavefronts per SIMD = 16 per CU = every one of 65,536 envs' wavefronts resident at
+ * once.  The kernel needs 120-128 VGPRs; the target keeps the compiler from drifting past 128 (which would drop a whole
+ * round's worth of wavefronts to a second round) — at the price of a spill or two if it ever has to.  History: an early
+ * 157-VGPR version capped at 128 spilled 60 B/lane and ran 12 % slower than uncapped (profiles/r01_quad.txt); since the tile
+ * mirrors the whole record the kernel fits. */
 #ifndef POM_QUAD_WAVES
-#define POM_QUAD_WAVES 3
+#define POM_QUAD_WAVES 4
 #endif
 /* POLICY: the moves are not read but decided here — lane m of an env's quad is agent m and runs SimpleAgent::act
  * (pom_policy_body.h) on the tile the tick is about to work on: Environment::Step with four SimpleAgents in ONE kernel, one
