@@ -956,6 +956,9 @@ struct PomBatch {
     hipStream_t sub[MAX_PARTS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS] = {};
     bool forked = false;
+    int main_part = 1; /* part 0 of a split step runs on the caller's stream itself, parts 1.. on sub-streams: one stream
+                          fewer for the same overlap (3 parts: 21.2 -> 20.6 us per step at 65,536 envs); POM_MAIN_PART=0: all
+                          parts on sub-streams */
     bool fuse_policy = true; /* pom_batch_step_simple: policy and tick in one kernel (quad shape); POM_FUSE=0 keeps them apart */
     /* optional per-launch timing (pom_batch_profile) */
     bool profiling = false;
@@ -1095,6 +1098,7 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
      * (it is capped at 128 VGPRs to keep 4 wavefronts per SIMD and parks ~25 long-lived values in scratch) */
     h->fuse_policy = h->n_pad < 262144;
     if (const char* ev = getenv("POM_FUSE")) h->fuse_policy = atoi(ev) != 0;
+    if (const char* ev = getenv("POM_MAIN_PART")) h->main_part = atoi(ev) != 0;
     if (const char* ev = getenv("POM_STREAMS")) {
         const int v = atoi(ev);
         if (v >= 1 && v <= PomBatch::MAX_PARTS) h->parts = v;
@@ -1249,7 +1253,7 @@ static int fork_parts(PomBatch* h)
 {
     if (h->parts == 1 || h->forked) return POM_OK;
     HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-    for (int k = 0; k < h->parts; k++) HIPCHK(hipStreamWaitEvent(h->sub[k], h->ev_fork, 0));
+    for (int k = h->main_part; k < h->parts; k++) HIPCHK(hipStreamWaitEvent(h->sub[k], h->ev_fork, 0));
     h->forked = true;
     return POM_OK;
 }
@@ -1257,7 +1261,7 @@ static int fork_parts(PomBatch* h)
 static int join_parts(PomBatch* h)
 {
     if (h->parts == 1 || !h->forked) return POM_OK;
-    for (int k = 0; k < h->parts; k++) {
+    for (int k = h->main_part; k < h->parts; k++) {
         HIPCHK(hipEventRecord(h->ev_join[k], h->sub[k]));
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join[k], 0));
     }
@@ -1309,7 +1313,7 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
     for (int k = 0; k < h->parts; k++) {
         const int64_t b0 = tiles * k / h->parts, b1 = tiles * (k + 1) / h->parts;
         if (b1 <= b0) continue;
-        hipStream_t st = h->parts == 1 ? h->stream : h->sub[k];
+        hipStream_t st = (h->parts == 1 || k < h->main_part) ? h->stream : h->sub[k];
         p.block0 = b0;
         const dim3 grid((unsigned)(b1 - b0));
         /* per-launch timing (pom_batch_profile): start / stop events attached to the dispatch itself, i.e. the kernel's own
@@ -1601,7 +1605,7 @@ static int launch_policy(PomBatch* h, uint64_t seed)
         if (b1 <= b0) continue;
         (void)tiles;
         p.block0 = b0;
-        hipStream_t st = h->parts == 1 ? h->stream : h->sub[k];
+        hipStream_t st = (h->parts == 1 || k < h->main_part) ? h->stream : h->sub[k];
         pom_policy_kernel<<<dim3((unsigned)(b1 - b0)), dim3(64), 0, st>>>(p);
         HIPCHK(hipGetLastError());
     }
