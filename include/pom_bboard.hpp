@@ -279,9 +279,25 @@ public:
         draw.resize(size_t(n_));
         pom_check(pom_batch_status(h_, 0, n_, done.data(), winner.data(), draw.data(), nullptr, nullptr, nullptr));
     }
+    // Environment's per-game queries (bboard.hpp:597-636, environment.cpp:176-208) for game e; each call downloads what it
+    // needs — game loops that look at every game should use GetStates() / Status() once per tick instead
+    const State& GetState(int64_t e)
+    {
+        pom_check(pom_batch_download(h_, &states_[size_t(e)], e, 1));
+        return states_[size_t(e)];
+    }
+    bool IsDone(int64_t e) { return Query(e, 0) != 0; }
+    bool IsDraw(int64_t e) { return Query(e, 2) != 0; }
+    int GetWinner(int64_t e) { return Query(e, 1); }
     PomBatch* Handle() { return h_; }
 
 private:
+    int32_t Query(int64_t e, int which)
+    {
+        int32_t v[3] = {0, -1, 0};
+        pom_check(pom_batch_status(h_, e, 1, &v[0], &v[1], &v[2], nullptr, nullptr, nullptr));
+        return v[which];
+    }
     PomBatch* h_ = nullptr;
     int64_t n_;
     std::vector<State> states_;

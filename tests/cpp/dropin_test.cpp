@@ -91,6 +91,10 @@ int main()
             REQUIRE(done[e] == (st[e].aliveAgents <= 1));
             if (done[e] && !draw[e]) REQUIRE(!st[e].agents[winner[e]].dead);
         }
+        for (int e = 0; e < 4; e++) { /* the per-game queries agree with the batch ones */
+            REQUIRE(env.IsDone(e) == (done[e] != 0) && env.IsDraw(e) == (draw[e] != 0) && env.GetWinner(e) == winner[e]);
+            REQUIRE(env.GetState(e).timeStep == st[e].timeStep && env.GetState(e).aliveAgents == st[e].aliveAgents);
+        }
         REQUIRE(blown_up > n);  // the watchers planted strength-1 bombs and stepped only one cell away
         std::printf("batch: %d of %d games finished, %d watchers caught by their own bombs\n", finished, n, blown_up);
     }
