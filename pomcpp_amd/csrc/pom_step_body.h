@@ -407,24 +407,29 @@ struct PomStepper {
     }
 
     /* ------------------------------------------------------------------ */
-    POM_HD void tick_flames() /* step_utility.cpp:208-222 + PopFlame bboard.cpp:148-180 */
+    /* TickFlames, step_utility.cpp:208-222, first half: timeLeft-- of every queued flame.  Returns the head of the queue as
+     * it stands afterwards (0 if the queue is empty) and the number of rounds the pop loop may take. */
+    POM_HD void flames_dec(int& top, int& n)
     {
+        top = 0;
+        n = L.fCnt;
         if (L.fCnt <= 0) return;
-        int top = 0; /* the head of the queue after the decrement, as the lane that owns offset 0 wrote it */
-        {   /* timeLeft-- of every queued flame; split over the lanes (offsets i and i+20 fall to the same lane) */
-            int p = L.fIdx + a.sub();
-            p = wrap20(p);
-            POM_NOUNROLL
-            for (int i = a.sub(); i < L.fCnt; i += A::G) {
-                const int f = a.flame(p);
-                const int nf = (f & ~0xFF0000) | ((f - 0x10000) & 0xFF0000);
-                a.put_flame(p, nf);
-                if (i == 0) top = nf;
-                p = wrap20(p + A::G);
-            }
-            top = a.template gbcast<0>(top);
+        /* split over the lanes (offsets i and i+20 fall to the same lane) */
+        int p = L.fIdx + a.sub();
+        p = wrap20(p);
+        POM_NOUNROLL
+        for (int i = a.sub(); i < L.fCnt; i += A::G) {
+            const int f = a.flame(p);
+            const int nf = (f & ~0xFF0000) | ((f - 0x10000) & 0xFF0000);
+            a.put_flame(p, nf);
+            if (i == 0) top = nf;
+            p = wrap20(p + A::G);
         }
-        const int n = L.fCnt;
+        top = a.template gbcast<0>(top);
+    }
+    /* second half: PopFlame (bboard.cpp:148-180) while the head has run out, by the env's own lanes */
+    POM_HD void flame_pops(int top, int n)
+    {
         POM_NOUNROLL
         for (int k = 0; k < n; k++) {
             const int f = k == 0 ? top : a.flame(L.fIdx); /* the first look needs no trip to the queue */
@@ -585,10 +590,35 @@ struct PomStepper {
         }
     }
 
+    /* bboard::Step, step.cpp:9-284, in four pieces so that a kernel can put its own version of the two event loops
+     * (flame pops, top-bomb explosions) between them; step() is the plain sequence. */
     POM_HD void step(const int mv_in[4])
     {
-        tick_flames(); /* step.cpp:15 */
+        int ftop, fn, btop, bn;
+        flames_dec(ftop, fn); /* step.cpp:15 */
+        flame_pops(ftop, fn);
         POM_STAMP(L, POM_PH_FLAMES);
+        step_middle(mv_in, btop, bn);
+        top_explosions(btop, bn);
+        POM_STAMP(L, POM_PH_TICK_BOMBS);
+    }
+    /* TickBombs' second half, step_utility.cpp:233-244: explode the head of the queue while its timer has run out; `n` = 0
+     * if the tick had no bombs */
+    POM_HD void top_explosions(int top, int n)
+    {
+        POM_NOUNROLL
+        for (int k = 0; k < n && L.bCnt > 0; k++) {
+            const int c = k == 0 ? top : bomb_at(0); /* the first look needs no trip to the queue */
+            if (pb_time(c) != 0) break;
+            explode(pb_x(c), pb_y(c), pb_strength(c), REM_TOP, c);
+        }
+    }
+    /* everything between the flame pops and the top-bomb explosions; returns the head of the bomb queue after the timer
+     * decrement and the number of rounds the explosion loop may take */
+    POM_HD void step_middle(const int mv_in[4], int& top, int& n)
+    {
+        top = 0;
+        n = 0;
 
         /* moves: anything outside 0..5 acts as "no displacement, not IDLE, not BOMB" -> code 6 */
         int mv[4];
@@ -1003,8 +1033,8 @@ struct PomStepper {
                 }
             }
             POM_STAMP(L, POM_PH_BOMB_B);
-            /* TickBombs, step_utility.cpp:224-245 */
-            int top = 0; /* the head of the queue after the decrement, as the lane that owns offset 0 wrote it */
+            /* TickBombs, step_utility.cpp:224-245, first half: the timers; the head after the decrement comes from the lane
+             * that wrote it */
             POM_NOUNROLL
             for (int k = a.sub(); k < L.bCnt; k += A::G) { /* split */
                 const int nb = (int)((uint32_t)bomb_at(k) - (1u << 16));
@@ -1012,15 +1042,8 @@ struct PomStepper {
                 if (k == 0) top = nb;
             }
             top = a.template gbcast<0>(top);
-            const int n = L.bCnt;
-            POM_NOUNROLL
-            for (int k = 0; k < n && L.bCnt > 0; k++) {
-                const int c = k == 0 ? top : bomb_at(0); /* the first look needs no trip to the queue */
-                if (pb_time(c) != 0) break;
-                explode(pb_x(c), pb_y(c), pb_strength(c), REM_TOP, c);
-            }
+            n = L.bCnt;
         }
-        POM_STAMP(L, POM_PH_TICK_BOMBS);
     }
 };
 
