@@ -1082,12 +1082,11 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
         }
     }
     if (const char* ev = getenv("POM_QUAD")) h->quad = atoi(ev) != 0 && h->epw == 16;
-    /* sub-batches per step.  Measured on MI355X (scripts/streams_test.py, profiles/r01_streams.txt): 2 parts give
-     * 40.8 -> 36.4 us at 64k envs and 120 -> 93 us at 262k, 4 parts only 35.1 — but ROCm multiplexes all streams of
-     * the process onto 4 hardware queues, kernels that share a queue serialize, and each part has a ~30 us latency
-     * floor, so more sub-streams than free queues (e.g. next to torch's own streams) DOUBLES the step time.
-     * Two parts stay inside that budget. */
-    h->parts = h->n_pad >= 8192 ? 2 : 1;
+    /* sub-batches per step: part 0 on the caller's stream, the others on internal streams.  Measured on MI355X at 65,536
+     * envs: one launch 26.4 us, two parts 22.3, three 20.4; FOUR concurrent streams of one process serialize on this stack
+     * (36 us; profiles/r01_streams.txt), and other streams of the process (RCCL) count against that budget, so the default
+     * stays at three only for batches where it matters and a caller can measure (pom_batch_set_streams, as bench.py does). */
+    h->parts = h->n_pad >= 49152 ? 3 : h->n_pad >= 8192 ? 2 : 1;
     if (o.streams >= 1 && o.streams <= PomBatch::MAX_PARTS) h->parts = o.streams;
     else if (o.streams != 0) {
         snprintf(g_err, sizeof g_err, "pom_batch_create: streams must be 0..%d", (int)PomBatch::MAX_PARTS);
