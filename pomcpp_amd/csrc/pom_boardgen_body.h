@@ -3,9 +3,10 @@
  * of, each a pure function so that the identical source also runs on the host in tests/emul.  SURVEY.md §8 row f3.
  *
  * On gfx950 (pom_boardgen_wave in pom_kernels.hip) a whole wavefront draws one env's board: lane l takes cells l and l+64
- * (pom_board_cell_kind), two ballots of "is wood" ARE the 121-bit wood set, and the flag pass (pom_board_flags: selection
- * sampling, sequential by nature, ~17 woods) then works on wave-uniform values only, i.e. on the scalar unit; lanes 0..50
- * write the other 51 dwords of the fresh record (pom_fresh_row).
+ * (pom_board_cell_kind), two ballots of "is wood" ARE the 121-bit wood set; every lane also computes its cells' selection
+ * thresholds and flags (pom_board_threshold / pom_board_flag_code, two hashes each), so that the sequential part of the flag
+ * pass — selection sampling over ~17 woods — is a countdown over ready-made numbers; lanes 0..50 write the other 51 dwords of
+ * the fresh record (pom_fresh_row).  The host emulation does the same countdown with pom_board_flags.
  */
 #ifndef POM_BOARDGEN_BODY_H_
 #define POM_BOARDGEN_BODY_H_
@@ -18,8 +19,18 @@
 POM_HD uint32_t pom_board_cell_kind(uint32_t key, int c) { return pom_mulhi32(pom_board_draw(key, (uint32_t)c), 7u); }
 POM_HD int pom_board_cell_code(uint32_t kind) { return kind == 1u ? POM_RIGID : kind == 2u ? POM_WOOD : POM_PASSAGE; }
 
-/* step 2: which woods carry a flag.  w0 = wood cells 0..63, w1 = wood cells 64..120 (bit c - 64); put(c, code) rewrites a
- * chosen cell.  Selection sampling in ascending cell order: exactly ceil(woods / 2) calls of put (bboard.cpp:367-381). */
+/* step 2: which woods carry a flag.  Selection sampling in ascending cell order (exactly ceil(woods / 2) woods are chosen,
+ * bboard.cpp:367-381): wood cell c, with `left` woods not yet visited (this one included), is chosen iff
+ * pom_board_threshold(key, c, left) < need, where `need` counts down from ceil(woods / 2) with every choice.  The threshold
+ * and the flag are pure functions of the cell — a wavefront computes them for all cells at once, only the countdown is
+ * sequential. */
+POM_HD uint32_t pom_board_threshold(uint32_t key, int c, int left)
+{
+    return pom_mulhi32(pom_board_draw(key, (uint32_t)(POM_BOARD_DRAW_SELECT + c)), (uint32_t)left);
+}
+POM_HD int pom_board_flag_code(uint32_t key, int c) { return POM_WOOD + 1 + (int)(pom_board_draw(key, (uint32_t)(POM_BOARD_DRAW_FLAG + c)) >> 30); }
+/* the countdown done by one thread alone: w0 = wood cells 0..63, w1 = wood cells 64..120 (bit c - 64); put(c, code) rewrites a
+ * chosen cell */
 template <class Put>
 POM_HD void pom_board_flags(uint32_t key, uint64_t w0, uint64_t w1, Put put)
 {
@@ -32,8 +43,8 @@ POM_HD void pom_board_flags(uint32_t key, uint64_t w0, uint64_t w1, Put put)
         while (w != 0 && need > 0) { /* need <= left always: once they are equal every remaining wood is chosen */
             const int c = 64 * half + __builtin_ctzll(w);
             w &= w - 1;
-            if ((int)pom_mulhi32(pom_board_draw(key, (uint32_t)(POM_BOARD_DRAW_SELECT + c)), (uint32_t)left) < need) {
-                put(c, POM_WOOD + 1 + (int)(pom_board_draw(key, (uint32_t)(POM_BOARD_DRAW_FLAG + c)) >> 30));
+            if ((int)pom_board_threshold(key, c, left) < need) {
+                put(c, pom_board_flag_code(key, c));
                 need--;
             }
             left--;

@@ -140,9 +140,39 @@ __device__ __forceinline__ void pom_boardgen_wave(uint32_t* col, uint32_t key, i
     const uint64_t w0 = __ballot(k0 == 2u), w1 = __ballot(k1 == 2u);
     const int r = POM_REC_TIMESTEP + lane;
     if (r < ROWS) col[r * EPW] = pom_fresh_row(r);
-    pom_board_flags(key, w0, w1, [&](int c, int code) {
-        if (lane == 0) cells[(c >> 1) * (2 * EPW) + (c & 1)] = (uint16_t)code;
-    });
+    /* the flags (pom_boardgen_body.h, step 2).  Per lane, in parallel: how many woods are still to come at each of my cells
+     * (prefix counts of the ballots) and the selection threshold that follows from it.  Then the countdown, wave-uniform:
+     * one readlane and a compare per wood.  The chosen cells come back as two masks and are rewritten by their lanes. */
+    const int woods = __popcll(w0) + __popcll(w1);
+    const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane)); /* the lanes before mine */
+    const int t0 = (int)pom_board_threshold(key, lane, woods - __popcll(w0 & below));
+    const int t1 = (int)pom_board_threshold(key, c1 < POM_CELLS ? c1 : 0, woods - __popcll(w0) - __popcll(w1 & below));
+    uint64_t ch0 = 0, ch1 = 0;
+    {
+        int need = (woods + 1) >> 1;
+        uint64_t w = w0;
+        POM_NOUNROLL
+        while (w != 0 && need > 0) {
+            const int l = __builtin_ctzll(w);
+            w &= w - 1;
+            if (__builtin_amdgcn_readlane(t0, l) < need) {
+                ch0 |= 1ull << l;
+                need--;
+            }
+        }
+        w = w1;
+        POM_NOUNROLL
+        while (w != 0 && need > 0) {
+            const int l = __builtin_ctzll(w);
+            w &= w - 1;
+            if (__builtin_amdgcn_readlane(t1, l) < need) {
+                ch1 |= 1ull << l;
+                need--;
+            }
+        }
+    }
+    if ((ch0 >> lane) & 1) cells[(lane >> 1) * (2 * EPW) + (lane & 1)] = (uint16_t)pom_board_flag_code(key, lane);
+    if ((ch1 >> lane) & 1) cells[(c1 >> 1) * (2 * EPW) + (c1 & 1)] = (uint16_t)pom_board_flag_code(key, c1);
     if (lane < POM_AGENT_COUNT) {
         const int c = pom_corner_cell(lane);
         cells[(c >> 1) * (2 * EPW) + (c & 1)] = (uint16_t)(POM_C_AGENT | lane);
