@@ -902,6 +902,7 @@ struct PomStepper {
              * bomb of this env is moving and whether two bombs share a cell (121-bit occupancy in 4 registers):
              * if neither, loop B below cannot see a collision and collapses to one cell test per bomb. */
             int moving = 0, shared = 0;
+            int ripe = 0; /* some bomb's own cell shows a walkable item or a flame: the only cells loop B's resting case acts on */
             uint32_t cand = 0; /* queue offsets of the resting bombs under an agent that walked onto them this tick */
             uint32_t occ[4] = {0, 0, 0, 0};
             POM_NOUNROLL
@@ -923,6 +924,7 @@ struct PomStepper {
                  * agent that walked onto it this tick means a bounce-back */
                 if (idx < POM_CELLS) {
                     const int e = a.cell(idx);
+                    ripe |= pc_is_walkable(e) | pc_is_flame(e);
                     if (pc_is_static_block(e) || pc_is_agent(e)) {
                         const int ag = get_agent(pb_x(b), pb_y(b));
                         if (ag > -1) {
@@ -934,6 +936,7 @@ struct PomStepper {
                 }
             }
             cand = (uint32_t)a.gor((int)cand);
+            ripe = a.gor(ripe);
             if (A::G > 1) { /* two lanes' bombs share a cell iff the lanes' cell sets overlap: |union| < sum of |set| */
                 int mine = 0, all = 0;
 #pragma unroll
@@ -969,7 +972,10 @@ struct PomStepper {
             for (int k = next; k < L.bCnt; k++) loop_a_bomb(mvp, oldp, k, moving);
             POM_STAMP(L, POM_PH_BOMB_A);
             /* bomb loop B, step.cpp:230-278 */
-            if (!moving && !shared) {
+            if (!moving && !shared && !ripe) {
+                /* Every bomb rests on a cell of its own that showed neither a walkable item nor a flame when the pass above
+                 * looked, and loop A in between only ever writes agent and BOMB items: loop B finds nothing to do. */
+            } else if (!moving && !shared) {
                 /* every bomb rests on a cell of its own: HasBombCollision is false for all of them, each "moves"
                  * onto its own cell (step.cpp:243-272): a walkable cell there becomes BOMB, a flame detonates it.
                  * Split: first only look (does any bomb sit in a flame?); without a detonation the writes are
