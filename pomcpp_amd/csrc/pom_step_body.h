@@ -695,12 +695,14 @@ struct PomStepper {
 
         /* HasBomb(x, y) is only ever asked about the moving agent's own cell (step.cpp:89,127,152,172) and bombs
          * do not move during the agent loop: one pass over the queue answers it for all four agents */
-        int on_bomb = 0;
+        int on_bomb = 0; /* bit 4: some queued bomb has a direction (before this tick's kicks) */
         POM_NOUNROLL
         for (int k = a.sub(); k < L.bCnt; k += A::G) { /* split over the lanes, OR-combined */
-            const int bp = pb_pos(bomb_at(k));
+            const int bw = bomb_at(k);
+            const int bp = pb_pos(bw);
 #pragma unroll
             for (int j = 0; j < 4; j++) on_bomb |= (bp == (px[j] | (py[j] << 4))) << j;
+            on_bomb |= (pb_dir(bw) != 0) << 4;
         }
         on_bomb = a.gor(on_bomb);
         POM_STAMP(L, POM_PH_AGENT_PREP);
@@ -730,9 +732,11 @@ struct PomStepper {
                 const int slot_off = __builtin_popcount(w_all & ((1 << m) - 1));
                 const int fits = wants && L.bCnt + slot_off < POM_Q;
                 int ubm = (wants && !fits) ? POM_UB_QUEUE_OVERFLOW : 0;
+                int planted_moving = 0; /* PlantBomb leaves the slot's old direction nibble in place: the new bomb may move */
                 if (fits) {
                     const int slot = wrap20(L.bIdx + L.bCnt + slot_off);
                     int b = a.bomb(slot); /* stale bits of the slot survive: SURVEY Q1 */
+                    planted_moving = pb_dir(b) != 0;
                     b = pb_set(b, 0xF00u, (uint32_t)m << 8);
                     b = pb_set(b, 0xFFu, (uint32_t)ag_x(av) + ((uint32_t)ag_y(av) << 4));
                     b = pb_set(b, 0xF000u, (uint32_t)((a1v >> 16) & 0xFFFF) << 12);
@@ -741,34 +745,50 @@ struct PomStepper {
                     av = ag_bombcount_add(av, 1);
                 }
                 int died = 0;
-                if (live && mvm != POM_MOVE_IDLE && mvm != POM_MOVE_BOMB) {
-                    const int x = ag_x(av), y = ag_y(av);
-                    const int dkey = (dstp >> (8 * m)) & 0xFF;
-                    const int ddx = (dkey & 0xF) - 1, ddy = (dkey >> 4) - 1;
-                    if (!oob(ddx, ddy)) {
-                        const int dc = ddy * POM_N + ddx, oc = y * POM_N + x;
-                        int item = a.cell(dc);
-                        const int vacated = ((on_bomb >> m) & 1) ? POM_C_BOMB : POM_C_PASSAGE;
-                        int collide = 0;
+                /* where the agent wants to go and what is there, for all four at once (nothing has been written yet) */
+                const int walks = live && mvm != POM_MOVE_IDLE && mvm != POM_MOVE_BOMB;
+                const int x = ag_x(av), y = ag_y(av);
+                const int dkey = (dstp >> (8 * m)) & 0xFF;
+                const int ddx = (dkey & 0xF) - 1, ddy = (dkey >> 4) - 1;
+                const int goes = walks && !oob(ddx, ddy);
+                const int dc = ddy * POM_N + ddx, oc = y * POM_N + x;
+                int item = 0, collide = 0;
+                if (goes) {
+                    item = a.cell(dc);
 #pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            collide |= (j != m) & !((deadmask >> j) & 1) & (((dstp >> (8 * j)) & 0xFF) == (uint32_t)dkey);
-                        if (pc_is_flame(item)) { /* step.cpp:84-99 */
-                            died = 1;
-                            av |= 1 << 25;
+                    for (int j = 0; j < 4; j++)
+                        collide |= (j != m) & !((deadmask >> j) & 1) & (((dstp >> (8 * j)) & 0xFF) == (uint32_t)dkey);
+                }
+                /* Will any bomb move this tick?  One has a direction already, somebody is about to kick one, or a bomb
+                 * planted just now inherited one. */
+                const int kicks = goes && !pc_is_flame(item) && !collide && item == POM_C_BOMB && ag_kick(av);
+                const int bombs_move = ((on_bomb >> 4) & 1) | a.gor(kicks | planted_moving);
+                if (goes) {
+                    const int vacated = ((on_bomb >> m) & 1) ? POM_C_BOMB : POM_C_PASSAGE;
+                    if (pc_is_flame(item)) { /* step.cpp:84-99 */
+                        died = 1;
+                        av |= 1 << 25;
+                        if (a.cell(oc) == (POM_C_AGENT | m)) a.put_cell(oc, vacated);
+                    } else if (!collide) {
+                        if (pc_is_powerup(item)) { /* ConsumePowerup, step_utility.cpp:247-262 */
+                            if (item == POM_EXTRABOMB) a1v = (a1v & ~0xFFFF) | ((a1v + 1) & 0xFFFF);
+                            else if (item == POM_INCRRANGE) a1v += 1 << 16;
+                            else av |= 1 << 24;
+                            item = POM_C_PASSAGE;
+                        }
+                        if (item == POM_C_PASSAGE) { /* step.cpp:120-140 */
                             if (a.cell(oc) == (POM_C_AGENT | m)) a.put_cell(oc, vacated);
-                        } else if (!collide) {
-                            if (pc_is_powerup(item)) { /* ConsumePowerup, step_utility.cpp:247-262 */
-                                if (item == POM_EXTRABOMB) a1v = (a1v & ~0xFFFF) | ((a1v + 1) & 0xFFFF);
-                                else if (item == POM_INCRRANGE) a1v += 1 << 16;
-                                else av |= 1 << 24;
-                                item = POM_C_PASSAGE;
-                            }
-                            if (item == POM_C_PASSAGE) { /* step.cpp:120-140 */
-                                if (a.cell(oc) == (POM_C_AGENT | m)) a.put_cell(oc, vacated);
-                                a.put_cell(dc, POM_C_AGENT | m);
-                                av = ag_setpos(av, ddx, ddy);
-                            } else if (item == POM_C_BOMB) { /* step.cpp:147-184 */
+                            a.put_cell(dc, POM_C_AGENT | m);
+                            av = ag_setpos(av, ddx, ddy);
+                        } else if (item == POM_C_BOMB) { /* step.cpp:147-184 */
+                            /* Stepping onto a resting bomb without kicking it while no bomb moves at all: the agent loop
+                             * would put him there, bomb loop A (step.cpp:195-227) would find the bomb blocked by him and
+                             * bounce him straight back (nobody can have entered the cell he left: no dependency edge; no
+                             * bomb can be heading for it: none moves), restoring both cells and his position.  The pair
+                             * is skipped — provided a queued bomb really sits there (a BOMB item without one bounces nobody)
+                             * and his own cell shows him, so that "restoring" it changes nothing. */
+                            if (!bombs_move && a.cell(oc) == (POM_C_AGENT | m) && bomb_index_alone(ddx | (ddy << 4)) >= 0) {
+                            } else {
                                 a.put_cell(oc, vacated);
                                 a.put_cell(dc, POM_C_AGENT | m);
                                 av = ag_setpos(av, ddx, ddy);
