@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long GPU soak (not collected by pytest; run by hand on the GPU box): 65,536 envs for tens of thousands of ticks, slices
-compared bit for bit with the oracle.  usage: python tests/soak_gpu.py [--ticks 20000] [--policy-ticks 3000]"""
+compared bit for bit with the oracle every few ticks (a difference must not get the chance to be wiped out by a restart).  usage: python tests/soak_gpu.py [--ticks 20000] [--policy-ticks 3000]"""
 import argparse
 import os
 import sys
@@ -17,6 +17,8 @@ from tests.oracle_lib import Oracle
 ap = argparse.ArgumentParser()
 ap.add_argument("--ticks", type=int, default=20000)
 ap.add_argument("--policy-ticks", type=int, default=3000)
+ap.add_argument("--chunk", type=int, default=16, help="ticks between comparisons (random-move configurations)")
+ap.add_argument("--policy-chunk", type=int, default=20)
 a = ap.parse_args()
 ora = Oracle()
 N, cap = 65536, 800
@@ -31,43 +33,56 @@ for name, fresh, kind, dist in (("replay, ffa, random moves", False, "ffa", 1), 
     else:
         start = pa.make_boards(N, seed=5, kind=kind)
         env.make_game(start)
-    t0 = time.time()
-    env.step_random(seed, dist, ticks=a.ticks)
-    got = env.get_state()
-    eps = env.episodes()
-    ub = env.status()["ubflags"]
-    gpu_s = time.time() - t0
+    # compare every `chunk` ticks — shorter than a game, so that a difference cannot be wiped out by the restart that follows it
+    chunk, t0, gpu_s = a.chunk, time.time(), 0.0
+    refs = []
     for first, m in slices:
         if fresh:
-            ref = ora.boardgen(bseed, first + np.arange(m), np.zeros(m))
-            e = np.zeros(m, dtype=np.int32)
-            ora.run_random_fresh(ref, e, a.ticks, seed, bseed, first, 0, dist, cap)
-            assert np.array_equal(eps[first:first + m], e), (name, first)
+            refs.append([ora.boardgen(bseed, first + np.arange(m), np.zeros(m)), np.zeros(m, dtype=np.int32), None])
         else:
             init = np.ascontiguousarray(start[first:first + m])
-            ref = init.copy()
-            ora.run_random(ref, init, a.ticks, seed, first, 0, dist, cap)
-        assert got[first:first + m].tobytes() == ref.tobytes(), (name, first)
+            refs.append([init.copy(), None, init])
+    for tick in range(0, a.ticks, chunk):
+        t1 = time.time()
+        env.step_random(seed, dist, ticks=chunk)
+        got = [env.get_state(first, m) for first, m in slices]
+        gpu_s += time.time() - t1
+        for (first, m), r, g in zip(slices, refs, got):
+            if fresh:
+                ora.run_random_fresh(r[0], r[1], chunk, seed, bseed, first, tick, dist, cap)
+            else:
+                ora.run_random(r[0], r[2], chunk, seed, first, tick, dist, cap)
+            assert g.tobytes() == r[0].tobytes(), (name, first, tick)
+    eps = env.episodes()
+    ub = env.status()["ubflags"]
+    if fresh:
+        for (first, m), r in zip(slices, refs):
+            assert np.array_equal(eps[first:first + m], r[1]), (name, first)
     cnt = env.counters()
     assert cnt[0] == N * a.ticks
     print(f"{name}: {N} envs x {a.ticks} ticks in {gpu_s:.1f} s, {int(cnt[1])} episodes, {int(cnt[3])} ticks with UB flags "
-          f"({int((ub != 0).sum())} envs flagged now); 4 slices of 384 envs = oracle", flush=True)
+          f"({int((ub != 0).sum())} envs flagged now); 4 slices of 384 envs = oracle every {a.chunk} ticks", flush=True)
     env.close()
 # SimpleAgent games with fresh boards
 seed, bseed = 7, 9
 env = BatchEnvironment(N, mode=MODE_ENV, auto_reset=True, max_steps=cap, fresh_boards=True, board_seed=bseed)
 env.generate(bseed)
-t0 = time.time()
-env.step_simple(seed, a.policy_ticks)
-got, eps = env.get_state(), env.episodes()
-gpu_s = time.time() - t0
-for first, m in [(0, 192), (30000, 192), (N - 192, 192)]:
-    ref = ora.boardgen(bseed, first + np.arange(m), np.zeros(m))
-    e, mems = np.zeros(m, dtype=np.int32), np.zeros((m, 4, 16), dtype=np.int32)
-    ora.run_simple_fresh(ref, e, mems, a.policy_ticks, seed, bseed, first, 0, cap)
-    assert got[first:first + m].tobytes() == ref.tobytes() and np.array_equal(eps[first:first + m], e), first
-    assert np.array_equal(env.policy_memory(first, m), mems), first
+pslices = [(0, 192), (30000, 192), (N - 192, 192)]
+prefs = [[ora.boardgen(bseed, first + np.arange(m), np.zeros(m)), np.zeros(m, dtype=np.int32), np.zeros((m, 4, 16), dtype=np.int32)]
+         for first, m in pslices]
+gpu_s, chunk = 0.0, a.policy_chunk
+for tick in range(0, a.policy_ticks, chunk):
+    t1 = time.time()
+    env.step_simple(seed, chunk)
+    got = [(env.get_state(first, m), env.policy_memory(first, m)) for first, m in pslices]
+    gpu_s += time.time() - t1
+    for (first, m), r, (g, gm) in zip(pslices, prefs, got):
+        ora.run_simple_fresh(r[0], r[1], r[2], chunk, seed, bseed, first, tick, cap)
+        assert g.tobytes() == r[0].tobytes() and np.array_equal(gm, r[2]), (first, tick)
+eps = env.episodes()
+for (first, m), r in zip(pslices, prefs):
+    assert np.array_equal(eps[first:first + m], r[1]), first
 print(f"SimpleAgent x4, fresh boards: {N} envs x {a.policy_ticks} ticks in {gpu_s:.1f} s, {int(env.counters()[1])} episodes; "
-      f"3 slices of 192 envs (states, episode counts, agent memory) = oracle", flush=True)
+      f"3 slices of 192 envs (states, agent memory every {a.policy_chunk} ticks, episode counts) = oracle", flush=True)
 env.close()
 print(f"soak ok in {time.time() - t_all:.0f} s")
