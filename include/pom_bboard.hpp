@@ -5,23 +5,39 @@
 // What is mirrored (file:line in /root/reference/include/bboard.hpp): the constants :15-27, Move :35-43,
 // Direction :45-52, Item and its predicates :54-109, FixedQueue :115-188, Position :192-201, AgentInfo :228-245,
 // the bit-packed Bomb and its accessors :261-335, Flame :342-347, State :356-511 (identical 1004-byte layout,
-// checked below), Agent :517-533 and `Step` :668; from step_utility.hpp the two helpers agents call,
-// DesiredPosition :16 and IsOutOfBounds :155-166.  State methods that only place things are host inlines; the
-// ones that simulate (SpawnFlame, PopFlame, Explode*) live on the device path inside Step and are not offered
-// as host calls.  `BatchEnvironment` is the n-game counterpart of bboard::Environment :541-644.
+// checked below), Agent :517-533, Environment :541-644 (src/bboard/environment.cpp:48-213), the free functions
+// InitBoardItems / InitState / Step / StartGame / PrintState / PrintItem :646-689 and std::hash<Position> :693-704;
+// from step_utility.hpp the helpers agents call, DesiredPosition :16, OriginPosition and IsOutOfBounds :155-166.
+// The standard headers bboard.hpp pulls in (:4-10) are included here too: the reference's agents rely on them
+// transitively (std::cout in simple_agent.cpp:135, strategy.cpp:263).  State methods that only place things are
+// host inlines; the ones that simulate (SpawnFlame, PopFlame, Explode*) live on the device path inside Step and are
+// not offered as host calls.  `BatchEnvironment` is the n-game counterpart of Environment.
+//
+// tests/test_cpp_dropin.py compiles the reference's UNMODIFIED src/agents/*.cpp, src/bboard/strategy.cpp and
+// src/main.cpp against this header (tests/cpp/shim/bboard.hpp and step_utility.hpp only include it).
 //
 // Not a port: there is no simulation code in this header.  Step() hands the State to libpom_batch.so.
 #ifndef POM_BBOARD_HPP_
 #define POM_BBOARD_HPP_
 
+#include <algorithm>
 #include <array>
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
+#include <functional>
+#include <iostream>
+#include <memory>
+#include <random>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pom_batch.h"
+#include "pom_boardgen.h"
+
+#include <sys/types.h>  // `uint`, which the reference's sources use unqualified (strategy.hpp:21, bboard.hpp:614)
 
 namespace bboard {
 
@@ -77,6 +93,7 @@ struct Position {
     int x, y;
 };
 inline bool operator==(const Position& a, const Position& b) { return a.x == b.x && a.y == b.y; }
+inline std::ostream& operator<<(std::ostream& os, const Position& p) { return os << "(" << p.x << ", " << p.y << ")"; }
 
 struct AgentInfo {
     int x, y;
@@ -218,9 +235,182 @@ inline Position DesiredPosition(int x, int y, Move m)
     return {x + (m == Move::RIGHT) - (m == Move::LEFT), y + (m == Move::DOWN) - (m == Move::UP)};
 }
 inline Position DesiredPosition(const Bomb b) { return DesiredPosition(BMB_POS_X(b), BMB_POS_Y(b), Move(BMB_DIR(b))); }
+inline Position OriginPosition(int x, int y, Move m)  // one step against the move
+{
+    return {x - (m == Move::RIGHT) + (m == Move::LEFT), y - (m == Move::DOWN) + (m == Move::UP)};
+}
 inline bool IsOutOfBounds(int x, int y) { return x < 0 || y < 0 || x >= BOARD_SIZE || y >= BOARD_SIZE; }
 inline bool IsOutOfBounds(const Position& p) { return IsOutOfBounds(p.x, p.y); }
 }  // namespace util
+
+// ---- start boards (bboard.hpp:646-661).  The reference draws them from std::mt19937_64 through libstdc++'s distributions
+// and reads an unwritten queue slot doing so (bboard.cpp:346-382), so its stream is not reproducible; its DISTRIBUTION is
+// specified in pom_boardgen.h as a pure function of (seed, env, episode), which the device generator implements
+// (pom_batch_generate).  These host inlines place the board of (seed, env 0, episode 0) the same way.
+inline void InitBoardItems(State& state, int seed = 0x1337)
+{
+    const uint32_t key = pom_board_key(uint64_t(uint32_t(seed)), 0u, 0u);
+    int* const cells = &state.board[0][0];  // cell c = y * BOARD_SIZE + x
+    int woods = 0;
+    for (int c = 0; c < BOARD_SIZE * BOARD_SIZE; ++c) {
+        const uint32_t kind = pom_mulhi32(pom_board_draw(key, uint32_t(c)), 7u);
+        cells[c] = kind == 1u ? RIGID : kind == 2u ? WOOD : PASSAGE;
+        woods += kind == 2u;
+    }
+    int left = woods, need = (woods + 1) / 2;  // selection sampling: exactly ceil(woods / 2) woods carry a flag
+    for (int c = 0; c < BOARD_SIZE * BOARD_SIZE && need > 0; ++c) {
+        if (cells[c] != WOOD) continue;
+        if (int(pom_mulhi32(pom_board_draw(key, uint32_t(POM_BOARD_DRAW_SELECT + c)), uint32_t(left))) < need) {
+            cells[c] = WOOD + 1 + int(pom_board_draw(key, uint32_t(POM_BOARD_DRAW_FLAG + c)) >> 30);
+            --need;
+        }
+        --left;
+    }
+}
+inline void InitState(State* state, int a0, int a1, int a2, int a3)
+{
+    InitBoardItems(*state);
+    state->PutAgentsInCorners(a0, a1, a2, a3);
+}
+
+// ---- plain-text rendering (bboard.hpp:678-689).  Rendering is outside this repo's scope; these exist so that
+// game loops written against the reference link.  Three characters per cell, no colours.
+inline std::string PrintItem(int item)
+{
+    if (item == PASSAGE) return " . ";
+    if (item == RIGID) return "[X]";
+    if (IS_WOOD(item)) return "[ ]";
+    if (item == BOMB) return " o ";
+    if (IS_FLAME(item)) return " * ";
+    if (item == EXTRABOMB) return " +b";
+    if (item == INCRRANGE) return " +r";
+    if (item == KICK) return " +k";
+    if (IS_AGENT(item)) return " " + std::to_string(item - AGENT0) + " ";
+    return " ? ";
+}
+inline void PrintState(State* state, bool clearConsole = false)
+{
+    if (clearConsole) std::cout << "\033c";
+    for (int y = 0; y < BOARD_SIZE; ++y) {
+        for (int x = 0; x < BOARD_SIZE; ++x) std::cout << PrintItem(state->board[y][x]);
+        if (y < AGENT_COUNT) {
+            const AgentInfo& a = state->agents[y];
+            std::cout << "    agent " << y << (a.dead ? " dead" : "     ") << " bombs " << a.bombCount << "/" << a.maxBombCount
+                      << " range " << a.bombStrength << (a.canKick ? " kick" : "");
+        }
+        std::cout << "\n";
+    }
+    std::cout << "tick " << state->timeStep << ", " << state->bombs.count << " bombs, " << state->flames.count << " flames" << std::endl;
+}
+
+// bboard.hpp:663-676: the bare loop over a caller-owned State (every agent is asked, dead or not, bboard.cpp:396-412)
+inline void StartGame(State* state, Agent* agents[AGENT_COUNT], int timeSteps)
+{
+    Move moves[AGENT_COUNT];
+    for (int t = 0; t < timeSteps; ++t) {
+        for (int j = 0; j < AGENT_COUNT; ++j) moves[j] = agents[j]->act(state);
+        Step(state, moves);
+        PrintState(state, true);
+        std::this_thread::sleep_for(std::chrono::milliseconds(80));
+    }
+}
+
+// One game with the reference's own surface (bboard.hpp:541-644, environment.cpp:48-213) over ONE slot of a device batch:
+// the tick and Environment::Step's bookkeeping (timeStep++, finished / winner / draw) run on the GPU in POM_MODE_ENV.
+// GetState() is the host mirror callers may edit between steps, as main.cpp:18-21 does, so every Step hands it to the device
+// and takes the result back (2 kB each way; a loop over many games wants BatchEnvironment).  Differences, all at points where
+// the reference is undefined: a dead agent's Move entry is IDLE (the reference leaves it uninitialised, environment.cpp:130,
+// SURVEY Q9); MakeGame's board comes from InitBoardItems above.
+class Environment {
+public:
+    Environment() : state(std::make_unique<State>()) { agents.fill(nullptr); std::fill(lastMoves, lastMoves + AGENT_COUNT, Move::IDLE); }
+    ~Environment() { if (h_) pom_batch_destroy(h_); }
+    Environment(const Environment&) = delete;
+    Environment& operator=(const Environment&) = delete;
+
+    void MakeGame(std::array<Agent*, AGENT_COUNT> a, bool randomizePositions = false)
+    {
+        InitBoardItems(*state);
+        std::array<int, 4> f = {0, 1, 2, 3};
+        if (randomizePositions) std::shuffle(f.begin(), f.end(), std::mt19937(std::random_device{}()));
+        state->PutAgentsInCorners(f[0], f[1], f[2], f[3]);
+        SetAgents(a);
+        hasStarted = true;
+    }
+    void StartGame(int timeSteps, bool render = true, bool stepByStep = false)
+    {
+        state->timeStep = 0;
+        while (!IsDone() && state->timeStep < timeSteps) {
+            if (render) {
+                Print();
+                if (listener) listener(*this);
+                if (stepByStep) std::cin.get();
+            }
+            Step(true);
+        }
+        Print();
+        std::cout << std::endl;
+        if (!IsDone()) std::cout << "Draw! Max timesteps reached " << std::endl;
+        else if (IsDraw()) std::cout << "Draw! All agents are dead" << std::endl;
+        else std::cout << "Finished! The winner is Agent " << GetWinner() << std::endl;
+    }
+    // competitiveTimeLimit: the live agents think concurrently and the environment waits 100 ms (environment.cpp:95-116)
+    void Step(bool competitiveTimeLimit = false)
+    {
+        if (!hasStarted || finished) return;
+        Move m[AGENT_COUNT] = {Move::IDLE, Move::IDLE, Move::IDLE, Move::IDLE};
+        if (competitiveTimeLimit) {
+            std::thread th[AGENT_COUNT];
+            for (int i = 0; i < AGENT_COUNT; ++i)
+                if (!state->agents[i].dead) th[i] = std::thread([&m, this, i] { m[i] = agents[i]->act(state.get()); });
+            std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            for (int i = 0; i < AGENT_COUNT; ++i)
+                if (th[i].joinable()) th[i].join();
+        } else {
+            for (int i = 0; i < AGENT_COUNT; ++i)
+                if (!state->agents[i].dead) {  // act() is only asked of live agents, environment.cpp:139-146
+                    m[i] = agents[i]->act(state.get());
+                    lastMoves[i] = m[i];
+                }
+        }
+        if (!h_) {
+            PomBatchOptions o{};
+            o.struct_size = sizeof o;
+            o.mode = POM_MODE_ENV;
+            pom_check(pom_batch_create(&h_, 1, &o));
+        }
+        pom_check(pom_batch_upload(h_, state.get(), 0, 1));
+        pom_check(pom_batch_step(h_, reinterpret_cast<const int32_t*>(m)));
+        pom_check(pom_batch_download(h_, state.get(), 0, 1));
+        int32_t done = 0, winner = -1, draw = 0;
+        pom_check(pom_batch_status(h_, 0, 1, &done, &winner, &draw, nullptr, nullptr, nullptr));
+        finished = done != 0;
+        isDraw = draw != 0;
+        if (winner >= 0) agentWon = winner;
+    }
+    void Print(bool clear = true) { (void)clear; PrintState(state.get(), true); }
+    State& GetState() const { return *state; }
+    void SetAgents(std::array<Agent*, AGENT_COUNT> a)
+    {
+        for (int i = 0; i < AGENT_COUNT; ++i) a[size_t(i)]->id = i;
+        agents = a;
+    }
+    Agent* GetAgent(uint agentID) const { return agents[agentID]; }
+    void SetStepListener(const std::function<void(const Environment&)>& f) { listener = f; }
+    bool IsDone() { return finished; }
+    bool IsDraw() { return isDraw; }
+    int GetWinner() { return agentWon; }
+    Move GetLastMove(int agentID) { return lastMoves[agentID]; }
+
+private:
+    std::unique_ptr<State> state;
+    std::array<Agent*, AGENT_COUNT> agents;
+    std::function<void(const Environment&)> listener;
+    bool finished = false, hasStarted = false, isDraw = false;
+    int agentWon = -1;
+    Move lastMoves[AGENT_COUNT];
+    PomBatch* h_ = nullptr;
+};
 
 // n concurrent games on one device: MakeGame / Step / IsDone / IsDraw / GetWinner / GetState of Environment,
 // with moves for all n games handed over at once.  Agents are asked for a move only while alive
@@ -304,5 +494,12 @@ private:
 };
 
 }  // namespace bboard
+
+namespace std {
+template <>
+struct hash<bboard::Position> {  // bboard.hpp:693-704: positions as keys of unordered containers (strategy.cpp:270)
+    size_t operator()(const bboard::Position& p) const { return hash<int>()(p.x + p.y * bboard::BOARD_SIZE); }
+};
+}  // namespace std
 
 #endif  // POM_BBOARD_HPP_

@@ -130,3 +130,56 @@ void ref_simple_set_memory(void* p, const int* in16)
 }
 
 }
+
+/* ---- Environment::Step (src/bboard/environment.cpp:123-169) behind a C window: the unmodified Environment
+ * with four agents that play back a move handed in before each step and note that they were asked.  Pins the restatement's
+ * bookkeeping (pom_oracle_env_step): timeStep++, finished / winner / draw, finished games not stepped, act() only asked of
+ * live agents.  The reference leaves the Move entry of a dead agent uninitialised (environment.cpp:130) and passes a 4-entry
+ * array to Step, which reads moves[-1] on lost-agent ticks (Q-UB1): the caller (fuzz_env.c, gen_golden.py) never steps it on
+ * a tick where either could matter. */
+namespace {
+struct ScriptedAgent : Agent {
+    Move next = Move::IDLE;
+    bool asked = false;
+    Move act(const State*) override
+    {
+        asked = true;
+        return next;
+    }
+};
+struct RefEnvGame {
+    Environment env;
+    ScriptedAgent a[4];
+};
+}  // namespace
+
+extern "C" {
+
+void* ref_env_new(const void* start_state)
+{
+    RefEnvGame* g = new RefEnvGame();
+    g->env.MakeGame({&g->a[0], &g->a[1], &g->a[2], &g->a[3]}, false); /* sets hasStarted; its board is replaced right away */
+    std::memcpy(&g->env.GetState(), start_state, sizeof(State));
+    return g;
+}
+void ref_env_delete(void* p) { delete static_cast<RefEnvGame*>(p); }
+/* one Environment::Step(false); returns the bit mask of the agents whose act() was called */
+int ref_env_step(void* p, const int* moves, void* state_out, int* done, int* winner, int* draw)
+{
+    RefEnvGame* g = static_cast<RefEnvGame*>(p);
+    for (int i = 0; i < 4; i++) {
+        g->a[i].next = Move(moves[i]);
+        g->a[i].asked = false;
+    }
+    g->env.Step(false);
+    std::memcpy(state_out, &g->env.GetState(), sizeof(State));
+    *done = g->env.IsDone();
+    *winner = g->env.GetWinner();
+    *draw = g->env.IsDraw();
+    int mask = 0;
+    for (int i = 0; i < 4; i++) mask |= int(g->a[i].asked) << i;
+    return mask;
+}
+int ref_env_last_move(void* p, int agent) { return int(static_cast<RefEnvGame*>(p)->env.GetLastMove(agent)); }
+
+}

@@ -135,7 +135,8 @@ __device__ __forceinline__ void pom_boardgen_wave(uint32_t* col, uint32_t key, i
     uint32_t k1 = 0u;
     if (c1 < POM_CELLS) {
         k1 = pom_board_cell_kind(key, c1);
-        cells[(c1 >> 1) * (2 * EPW) + (c1 & 1)] = (uint16_t)pom_board_cell_code(k1);
+        if (c1 == POM_CELLS - 1) col[(c1 >> 1) * EPW] = (uint32_t)pom_board_cell_code(k1); /* the last dword's unused half: 0, as pom_pack_state writes it */
+        else cells[(c1 >> 1) * (2 * EPW) + (c1 & 1)] = (uint16_t)pom_board_cell_code(k1);
     }
     const uint64_t w0 = __ballot(k0 == 2u), w1 = __ballot(k1 == 2u);
     const int r = POM_REC_TIMESTEP + lane;

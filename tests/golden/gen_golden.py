@@ -11,6 +11,10 @@ never reference source.
                     per-tick blake2b-64 of the reference's state, full state every 32 ticks + final.
                     The reference is never stepped on a tick for which the oracle predicts one of
                     its crashing UBs (SURVEY §8c guard); such an episode ends there.
+  env_traces.npz    games played by the reference's Environment::Step (environment.cpp:123-169, row a12) with
+                    play-back agents: start state, per-tick moves, per-tick done / winner / draw, which agents
+                    were asked, per-tick state hash, final state.  A game ends before a tick on which the
+                    reference's uninitialised Move entries (dead agents; moves[-1]) could matter.
 """
 from __future__ import annotations
 
@@ -102,9 +106,79 @@ def gen_trajectories():
     print(f"trajectories.npz: {E} episodes, {offsets[-1]} reference steps, {len(ck_state)} checkpoints")
 
 
+def gen_env_traces():
+    import ctypes as C
+    import itertools
+    ref = RefAPI().lib
+    ref.ref_env_new.restype = C.c_void_p
+    ref.ref_env_new.argtypes = [C.c_void_p]
+    ref.ref_env_delete.argtypes = [C.c_void_p]
+    ref.ref_env_step.argtypes = [C.c_void_p] * 3 + [C.POINTER(C.c_int)] * 3
+    oracle = Oracle()
+    rng = np.random.default_rng(20261004)
+    plan = [("ffa", 6, 40, 200), ("ffa", 5, 8, 300), ("stress", "stress", 32, 100)]
+    starts, finals, moves_all, hashes_all, status_all, offsets = [], [], [], [], [], [0]
+    for kind, dist, games, max_ticks in plan:
+        boards = pa.make_boards(games, seed=int(rng.integers(1 << 30)), kind=kind)
+        for e in range(games):
+            s = boards[e:e + 1].copy()
+            starts.append(s.tobytes())
+            g = ref.ref_env_new(s.ctypes.data)
+            n = 0
+            for t in range(max_ticks):
+                if dist == "stress":
+                    mv = rng.choice(6, size=4, p=[.10, .15, .15, .15, .15, .30]).astype(np.int32)
+                else:
+                    mv = rng.integers(0, dist, size=4, dtype=np.int32)
+                dead = [i for i in range(4) if s["agents"]["dead"][0, i]]
+                mv[dead] = 0  # what the restatement and the device define for agents that are not asked
+                probe = s.copy()
+                if oracle.step(probe, mv):
+                    break  # any UB flag: the reference's moves[-1] / null deref would be in play
+                sensitive = False
+                for combo in itertools.product(range(5), repeat=len(dead)):
+                    m2 = mv.copy()
+                    m2[dead] = combo
+                    p2 = s.copy()
+                    oracle.step(p2, m2)
+                    if p2.tobytes() != probe.tobytes():
+                        sensitive = True
+                        break
+                if sensitive:
+                    break
+                d, w, dr = C.c_int(), C.c_int(), C.c_int()
+                asked = ref.ref_env_step(g, mv.ctypes.data, s.ctypes.data, C.byref(d), C.byref(w), C.byref(dr))
+                s["agents"]["pad"] = 0
+                moves_all.append(mv)
+                hashes_all.append(state_hash(s.tobytes()))
+                status_all.append((d.value, w.value, dr.value, asked))
+                n += 1
+                if d.value:
+                    break
+            ref.ref_env_delete(g)
+            finals.append(s.tobytes())
+            offsets.append(offsets[-1] + n)
+    E = len(starts)
+    st = np.array(status_all, dtype=np.int32).reshape(-1, 4)
+    np.savez_compressed(
+        os.path.join(OUT, "env_traces.npz"),
+        start=np.frombuffer(b"".join(starts), dtype=np.uint8).reshape(E, 1004),
+        final=np.frombuffer(b"".join(finals), dtype=np.uint8).reshape(E, 1004),
+        moves=np.array(moves_all, dtype=np.int32).reshape(-1, 4),
+        hashes=np.array(hashes_all, dtype=np.uint64),
+        status=st, offsets=np.array(offsets, dtype=np.int64),
+    )
+    print(f"env_traces.npz: {E} games, {offsets[-1]} Environment::Step calls, {int(st[:, 0].sum())} finished "
+          f"({int(st[:, 2].sum())} draws)")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_cases()
-    gen_trajectories()
+    if len(sys.argv) > 1 and sys.argv[1] == "env":  # only the new fixture; the others are byte-stable and stay as committed
+        gen_env_traces()
+    else:
+        gen_cases()
+        gen_trajectories()
+        gen_env_traces()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")

@@ -1,29 +1,167 @@
 """Code written against pomcpp's C++ API compiled against include/pom_bboard.hpp (the drop-in surface) —
-compile+link everywhere, run on the GPU."""
+compile+link everywhere, run on the GPU.
+
+Three layers:
+  * tests/cpp/dropin_test.cpp — reference-style test code and home-made Agent subclasses;
+  * the reference's UNMODIFIED src/agents/simple_agent.cpp, src/agents/basic_agents.cpp, src/bboard/strategy.cpp and
+    src/main.cpp compiled where they lie against the header (tests/cpp/shim/bboard.hpp / step_utility.hpp only include
+    it; agents.hpp / strategy.hpp / colors.hpp are reached through symlinks in the git-ignored build dir) — only where
+    /root/reference exists, i.e. in the build container;
+  * tests/cpp/env_game.cpp — games through bboard::Environment (the reference's game-loop surface, bboard.hpp:541-644)
+    on the GPU, replayed through the oracle's restatement of Environment::Step (environment.cpp:123-169), with scripted
+    agents and — where the build container left the binary under oracle/_ref/ — with the reference's own SimpleAgent.
+"""
 import os
+import struct
 import subprocess
 
+import numpy as np
 import pytest
 
+from pomcpp_amd.state import STATE_DTYPE
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(ROOT, "build", "dropin_test")
+BUILD = os.path.join(ROOT, "build")
+EXE = os.path.join(BUILD, "dropin_test")
+REF = "/root/reference"
+REF_SOURCES = ["src/agents/simple_agent.cpp", "src/agents/basic_agents.cpp", "src/bboard/strategy.cpp", "src/main.cpp"]
+REF_OUT = os.path.join(ROOT, "oracle", "_ref")  # binaries built from reference sources live only here (git-ignored)
+LINK = ["-L" + os.path.join(ROOT, "pomcpp_amd"), "-lpom_batch", "-Wl,-rpath," + os.path.join(ROOT, "pomcpp_amd"),
+        "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-pthread"]
+INC = ["-I" + os.path.join(ROOT, "tests", "cpp", "shim"), "-I" + os.path.join(ROOT, "include")]
+
+have_reference = os.path.isdir(os.path.join(REF, "src", "bboard"))
 
 
 @pytest.fixture(scope="module")
 def dropin_exe(hip_lib):
-    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    os.makedirs(BUILD, exist_ok=True)
     subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "tests", "cpp", "dropin_test.cpp"), "-o", EXE,
-                    "-L" + os.path.join(ROOT, "pomcpp_amd"), "-lpom_batch", "-Wl,-rpath," + os.path.join(ROOT, "pomcpp_amd"),
-                    "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"], check=True)
+                    os.path.join(ROOT, "tests", "cpp", "dropin_test.cpp"), "-o", EXE] + LINK, check=True)
     return EXE
+
+
+@pytest.fixture(scope="module")
+def env_game_exe(hip_lib):
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "env_game")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror"] + INC +
+                   [os.path.join(ROOT, "tests", "cpp", "env_game.cpp"), "-o", exe] + LINK, check=True)
+    return exe
+
+
+@pytest.fixture(scope="module")
+def reference_objects(hip_lib):
+    """the reference's unmodified agent / game-loop sources compiled against pom_bboard.hpp"""
+    inc = os.path.join(BUILD, "dropin_inc")
+    os.makedirs(inc, exist_ok=True)
+    os.makedirs(REF_OUT, exist_ok=True)
+    for h in ("agents.hpp", "strategy.hpp", "colors.hpp"):  # headers of the agents themselves; bboard.hpp / step_utility.hpp are ours
+        link = os.path.join(inc, h)
+        if os.path.islink(link) or os.path.exists(link):
+            os.remove(link)
+        os.symlink(os.path.join(REF, "include", h), link)
+    objs = {}
+    for src in REF_SOURCES:
+        obj = os.path.join(REF_OUT, "dropin_" + os.path.basename(src).replace(".cpp", ".o"))
+        subprocess.run(["g++", "-std=c++17", "-O1", "-c"] + INC + ["-I" + inc, os.path.join(REF, src), "-o", obj], check=True)
+        objs[os.path.basename(src)] = obj
+    return objs, inc
 
 
 def test_reference_style_code_compiles_against_the_drop_in_header(dropin_exe):
     assert os.path.exists(dropin_exe)
 
 
+@pytest.mark.skipif(not have_reference, reason="the reference tree only exists in the build container")
+def test_unmodified_reference_agents_and_main_compile_and_link_against_the_drop_in_header(reference_objects):
+    objs, inc = reference_objects
+    # src/main.cpp: SimpleAgents + bboard::Environment::MakeGame / GetState / StartGame
+    exe = os.path.join(REF_OUT, "dropin_main")
+    subprocess.run(["g++", "-o", exe, objs["main.cpp"], objs["simple_agent.cpp"], objs["basic_agents.cpp"], objs["strategy.cpp"]] + LINK,
+                   check=True)
+    assert os.path.exists(exe)
+    # the trace program with the reference's own SimpleAgent as the four players; runs on the GPU box (test below)
+    exe2 = os.path.join(REF_OUT, "env_game_ref")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-DPOM_WITH_REFERENCE_AGENTS"] + INC + ["-I" + inc,
+                    os.path.join(ROOT, "tests", "cpp", "env_game.cpp"), objs["simple_agent.cpp"], objs["basic_agents.cpp"],
+                    objs["strategy.cpp"], "-o", exe2] + LINK, check=True)
+    assert os.path.exists(exe2)
+
+
+def test_host_init_board_items_is_the_boardgen_specification(env_game_exe, oracle, tmp_path):
+    """InitState of the header = the board (seed, env 0, episode 0) of include/pom_boardgen.h, as the device generator draws it"""
+    for seed in (0x1337, 5, 123456789):
+        out = tmp_path / f"b{seed}.bin"
+        subprocess.run([env_game_exe, "--board", str(out), str(seed)], check=True, timeout=60)
+        got = np.fromfile(out, dtype=STATE_DTYPE)
+        want = oracle.boardgen(seed, [0], [0])
+        got["agents"]["pad"] = 0
+        assert got.tobytes() == want.tobytes()
+
+
+def _replay(trace_path, oracle):
+    """every step of every recorded game must be what the oracle's Environment::Step makes of the same state and moves"""
+    buf = open(trace_path, "rb").read()
+    pos, games, steps, finished = 0, 0, 0, 0
+    while pos < len(buf):
+        magic, _g = struct.unpack_from("<ii", buf, pos)
+        assert magic == 0x504F4D45
+        pos += 8
+        ref = np.frombuffer(buf, dtype=STATE_DTYPE, count=1, offset=pos).copy()
+        pos += 1004
+        assert ref["timeStep"][0] == 0
+        status = dict(done=0, winner=-1, draw=0)
+        n = 0
+        while True:
+            rec = struct.unpack_from("<8i", buf, pos)
+            pos += 32
+            if rec[0] == 2:
+                assert rec[1] == n and (rec[5], rec[6], rec[7]) == (status["done"], status["winner"], status["draw"])
+                break
+            assert rec[0] == 1
+            got = np.frombuffer(buf, dtype=STATE_DTYPE, count=1, offset=pos).copy()
+            pos += 1004
+            dead_before = ref["agents"]["dead"][0].copy()
+            moves = list(rec[1:5])
+            assert all(m == 0 for m, d in zip(moves, dead_before) if d), "a dead agent was asked for a move"
+            ub = oracle.env_step(ref, moves, status)
+            assert ub & ~1 == 0, "only the lost-agent case (POM_UB_LOST_AGENT, defined fallback) may occur in these games"
+            want = ref.copy()
+            want["agents"]["pad"] = 0
+            got["agents"]["pad"] = 0
+            assert got.tobytes() == want.tobytes(), f"game {games} step {n}"
+            assert (rec[5], rec[6], rec[7]) == (status["done"], status["winner"], status["draw"])
+            n += 1
+        games += 1
+        steps += n
+        finished += status["done"]
+    return games, steps, finished
+
+
 @pytest.mark.gpu
 def test_reference_style_code_runs_on_the_gpu(dropin_exe):
     out = subprocess.run([dropin_exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "dropin ok" in out.stdout, f"rc={out.returncode}\n{out.stdout}\n{out.stderr}"
+
+
+@pytest.mark.gpu
+def test_games_through_bboard_environment_equal_the_oracles_environment_step(env_game_exe, oracle, tmp_path):
+    trace = tmp_path / "trace.bin"
+    out = subprocess.run([env_game_exe, str(trace), "12", "200"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "env games ok" in out.stdout, f"rc={out.returncode}\n{out.stdout}\n{out.stderr}"
+    games, steps, finished = _replay(trace, oracle)
+    assert games == 12 and steps > 300 and finished >= 1
+
+
+@pytest.mark.gpu
+def test_reference_simple_agents_play_through_bboard_environment(hip_lib, oracle, tmp_path):
+    """the reference's own agents::SimpleAgent (unmodified sources, linked in the build container) as the four players"""
+    exe = os.path.join(REF_OUT, "env_game_ref")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/env_game_ref is built only where /root/reference exists")
+    trace = tmp_path / "trace_ref.bin"
+    out = subprocess.run([exe, str(trace), "6", "300"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "env games ok" in out.stdout, f"rc={out.returncode}\n{out.stdout}\n{out.stderr}"
+    games, steps, _ = _replay(trace, oracle)
+    assert games == 6 and steps > 200

@@ -235,7 +235,6 @@ def test_split_steps_over_streams_give_identical_results(hip_lib, oracle, stream
             mv = rng.integers(0, 6, size=(n, 4), dtype=np.int32)
             env.step(mv)
             mv[:] = 0                  # the host buffer may be reused immediately
-            oracle.step_batch(ref, rng_moves := None) if False else None
         # recompute the same moves for the oracle
         rng = np.random.default_rng(streams)
         for t in range(20):
