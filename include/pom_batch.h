@@ -167,7 +167,11 @@ enum { POM_OBS_PLANES = 16, POM_OBS_AGENT_ATTRS = 8, POM_OBS_ENV_ATTRS = 4 };
 int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_agent, int32_t* agent_attrs_dev,
                       int32_t* env_attrs_dev);
 
-/* bboard::Step for a single host State on the GPU (a batch of one, device 0): the literal drop-in */
+/* bboard::Step for a single host State on the GPU (a batch of one, device 0): the literal drop-in.  Compatibility path, not
+ * a fast one: every call uploads the State, steps and downloads it, and ALL callers of the process share one internal
+ * one-env handle behind a mutex — calls from several threads are safe but run one after the other, whereas the reference's
+ * Step is re-entrant over distinct States (performance_test.cpp:71-94 steps one env per std::thread).  Code that steps
+ * many States should hand them to one PomBatch (pom_batch_upload / pom_batch_step) instead. */
 int pom_step(void* state_1004, const int32_t moves[4]);
 
 #ifdef __cplusplus

@@ -63,3 +63,42 @@ int64_t ref_run_random_timed(void* states, const void* initial, int n, int ticks
     free(skip);
     return steps;
 }
+
+/*
+ * BASELINE config 1: ONE env, i.i.d. uniform {IDLE, UP, DOWN, LEFT, RIGHT} moves per agent per tick (HarmlessAgent's
+ * distribution, src/agents/basic_agents.cpp:28-38), one thread, `reps` x `ticks` ticks from the same start board — the
+ * shape of unit_test/bboard/performance_test.cpp:55-59.  The move script is laid out first and played once by the
+ * restatement (untimed) so that the reference is never timed into a tick with one of its crashing UBs: the script is cut
+ * there (harmless play plants no bombs, so in practice only lost-agent ticks occur, which the padded move array defines).
+ * Returns the reference's env-steps; *seconds accumulates the time of the whole replay loops (no per-tick timer calls).
+ */
+int64_t ref_run_single_timed(const void* start, int ticks, uint64_t seed, int dist, int reps, double* seconds)
+{
+    int32_t* mv = (int32_t*)malloc((size_t)ticks * 4 * sizeof(int32_t));
+    PomState probe = *(const PomState*)start;
+    int usable = 0;
+    for (int t = 0; t < ticks; t++) {
+        pom_rng_moves(seed, 0u, (uint32_t)t, dist, &mv[4 * t]);
+        if (pom_oracle_step(&probe, &mv[4 * t]) & ~(uint32_t)POM_UB_LOST_AGENT) break;
+        probe.timeStep++;
+        usable++;
+        if (probe.aliveAgents <= 1) break;
+    }
+    int64_t steps = 0;
+    for (int r = 0; r < reps; r++) {
+        PomState s = *(const PomState*)start;
+        const double t0 = now_s();
+        for (int t = 0; t < usable; t++) {
+            ref_step(&s, &mv[4 * t]);
+            s.timeStep++;
+        }
+        *seconds += now_s() - t0;
+        steps += usable;
+        if (memcmp(s.board, probe.board, sizeof s.board) != 0) { /* the replay must end where the restatement ended */
+            steps = -1;
+            break;
+        }
+    }
+    free(mv);
+    return steps;
+}

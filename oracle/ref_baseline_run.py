@@ -2,7 +2,8 @@
 """TEST INFRASTRUCTURE — child process of bench.py's cpu_baseline leg: times the compiled, unmodified reference
 (oracle/_ref/libpomref_bench.so, see oracle/ref_baseline.c) on the host cores and prints one JSON line.  A separate process
 because the reference has undefined behaviour on reachable states; should it crash despite the guard, bench.py falls back to
-the restatement's figure.  usage: ref_baseline_run.py boards.npy seed dist_id max_steps budget_s"""
+the restatement's figure.  usage: ref_baseline_run.py boards.npy seed dist_id max_steps budget_s
+       ref_baseline_run.py boards.npy seed config1      (BASELINE config 1: one env, harmless moves, one thread, 10 x 1000 ticks)"""
 import ctypes as C
 import json
 import os
@@ -14,8 +15,20 @@ import numpy as np
 
 here = os.path.dirname(os.path.abspath(__file__))
 start = np.load(sys.argv[1])
-seed, dist_id, max_steps, budget = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])
 lib = C.CDLL(os.path.join(here, "_ref", "libpomref_bench.so"))
+if len(sys.argv) > 3 and sys.argv[3] == "config1":
+    lib.ref_run_single_timed.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    lib.ref_run_single_timed.restype = C.c_int64
+    one = np.ascontiguousarray(start[:1])
+    secs = C.c_double(0)
+    ticks, reps = 1000, 10
+    lib.ref_run_single_timed(one.ctypes.data, ticks, int(sys.argv[2]), 0, 2, C.byref(secs))  # warm the caches
+    secs = C.c_double(0)
+    n = lib.ref_run_single_timed(one.ctypes.data, ticks, int(sys.argv[2]), 0, reps, C.byref(secs))
+    print(json.dumps({"value": n / secs.value if n > 0 and secs.value > 0 else None, "cores": 1, "steps": int(n), "timed_s": secs.value,
+                      "ticks": ticks, "reps": reps}))
+    sys.exit(0 if n > 0 else 1)
+seed, dist_id, max_steps, budget = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])
 lib.ref_run_random_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.POINTER(C.c_double), C.POINTER(C.c_int64)]
 lib.ref_run_random_timed.restype = C.c_int64

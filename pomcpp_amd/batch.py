@@ -17,6 +17,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import sys
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -131,6 +132,7 @@ class BatchEnvironment:
                  streams: int = 0, lanes_per_env: int = 0, fresh_boards: bool = False, board_seed: int = 0):
         self._lib = load_library()
         self._h = C.c_void_p()
+        self._views = []  # weak references to tensors that alias the handle's device memory (moves_tensor)
         self.n = int(n_envs)
         self.device = int(device)
         o = _Options(C.sizeof(_Options), device, stream, mode, int(auto_reset), max_steps, env_offset, envs_per_wave, streams,
@@ -138,6 +140,9 @@ class BatchEnvironment:
         _check(self._lib, self._lib.pom_batch_create(C.byref(self._h), self.n, C.byref(o)))
 
     def close(self) -> None:
+        if any(r() is not None for r in getattr(self, "_views", ())):
+            raise RuntimeError("close(): a tensor returned by moves_tensor() still views this handle's device memory; "
+                               "delete it first")
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.pom_batch_destroy(self._h)
             self._h = C.c_void_p()
@@ -280,7 +285,12 @@ class BatchEnvironment:
         class _Raw:  # the CUDA array interface is how torch adopts foreign device memory
             __cuda_array_interface__ = {"shape": (self.n, 4), "typestr": "<i4", "data": (addr, False), "version": 2}
 
-        return torch.as_tensor(_Raw(), device=torch.device("cuda", self.device))
+        t = torch.as_tensor(_Raw(), device=torch.device("cuda", self.device))
+        # the memory belongs to the handle: the view keeps its BatchEnvironment alive (no __del__ while a view exists), and an
+        # explicit close() with views outstanding is refused
+        t._pom_owner = self
+        self._views.append(weakref.ref(t))
+        return t
 
     def stream_handle(self) -> int:
         """the hipStream_t (as an integer) this handle's work is ordered on"""

@@ -54,3 +54,49 @@ def test_single_process_helpers_are_identity():
     assert bench.reduce_counters(c, None).tolist() == [5, 1, 0, 0]
     assert bench.reduce_max(3.5, torch.device("cpu"), None) == 3.5
     assert bench.shard_plan(0, 1, 65536) == {"first_env": 0, "n_envs": 65536, "global_envs": 65536}
+
+
+# ---- the launcher behind `bench.py --gpus N` (--gpus was parsed and never read) ---------------------------
+def _launch(argv, n):
+    """bench.launch_ranks in a child interpreter (it relays rank 0's stdout to its own), with the CPU stand-in as the worker"""
+    import subprocess
+    code = ("import sys, bench; sys.exit(bench.launch_ranks(%d, %r, worker_cmd=[sys.executable, %r], timeout_s=100))"
+            % (n, argv, os.path.join(ROOT, "tests", "stub_rank.py")))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None)
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=150, env=env, cwd=ROOT)
+
+
+@pytest.mark.timeout(200)
+def test_launcher_starts_n_ranks_and_relays_rank0_line():
+    import json
+    out = _launch(["--gpus", "2", "--envs", "32768", "--steps", "10"], 2)
+    assert out.returncode == 0, out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0's line only
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["global_envs"] == 65536
+    assert r["steps_total"] == 2 * 32768 * 10 and r["slowest"] == 2.0 and r["first_env"] == 0
+
+
+@pytest.mark.timeout(200)
+def test_launcher_fails_when_a_rank_fails():
+    out = _launch(["--gpus", "2", "--fail-rank", "1"], 2)
+    assert out.returncode != 0
+    assert "rank 1 exited with 3" in out.stderr
+
+
+def test_bench_main_becomes_the_launcher_only_without_a_rendezvous(monkeypatch):
+    """`python bench.py --gpus N` launches; under torch.distributed.run (WORLD_SIZE set) the same command line is a rank"""
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = []
+    monkeypatch.setattr(bench, "launch_ranks", lambda n, argv, **kw: calls.append((n, argv)) or 0)
+    monkeypatch.setattr(bench, "worker", lambda args: calls.append(("worker", args.gpus)))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.main(["--gpus", "8", "--envs", "32768"]) == 0
+    assert calls == [(8, ["--gpus", "8", "--envs", "32768"])]
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    bench.main(["--gpus", "8"])
+    bench.main([])
+    assert calls[1:] == [("worker", 8), ("worker", 1)]

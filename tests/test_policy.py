@@ -129,4 +129,7 @@ def test_mixed_play_through_the_device_move_buffer(hip_lib, oracle):
                     ref["timeStep"][e] += 1
         assert env.get_state().tobytes() == ref.tobytes()
         assert np.array_equal(env.policy_memory(), mems)
+        with pytest.raises(RuntimeError):
+            env.close()  # a view of the handle's move buffer is still alive
+        del mv
         env.close()
