@@ -350,6 +350,16 @@ __global__ __launch_bounds__(64, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 
         m1 = p.agent_mem[4 * np + tile_id * 64 + lane];
     }
     bool restarted = POLICY && !FRESH && __shfl((int)reload_d, ec) != 0; /* lane ec moved env ec's rows */
+    /* the first tick's moves do not depend on the record: hash / fetch them while the record is on its way */
+    uint64_t draw0 = 0;
+    int4 moves0 = make_int4(0, 0, 0, 0);
+    if (!POLICY) {
+        if (p.moves) {
+            if (valid) moves0 = reinterpret_cast<const int4*>(p.moves)[e];
+        } else {
+            draw0 = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick0);
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the DMA rows have landed (one wavefront per workgroup: no barrier) */
     PomLane L;
     int time_step = 0;
@@ -436,10 +446,11 @@ __global__ __launch_bounds__(64, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 
                 mv[2] = acc.template gbcast<2>(mv_own);
                 mv[3] = acc.template gbcast<3>(mv_own);
             } else if (p.moves) {
-                const int4 m = reinterpret_cast<const int4*>(p.moves)[e];
-                mv[0] = m.x; mv[1] = m.y; mv[2] = m.z; mv[3] = m.w;
+                mv[0] = moves0.x; mv[1] = moves0.y; mv[2] = moves0.z; mv[3] = moves0.w; /* explicit moves: one tick per launch */
             } else {
-                pom_rng_moves(p.seed, (uint32_t)(p.env_offset + e), p.tick0 + (uint32_t)tk, p.dist, mv);
+                const uint64_t r = tk == 0 ? draw0 : pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick0 + (uint32_t)tk);
+#pragma unroll
+                for (int i = 0; i < 4; i++) mv[i] = pom_rng_pick((uint32_t)(r >> (16 * i)) & 0xFFFFu, p.dist);
             }
             const uint32_t ub_before = L.ub;
             L.ub = 0;
@@ -1309,7 +1320,10 @@ static int ensure_agent_mem(PomBatch* h)
     return POM_OK;
 }
 
-static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int dist, int ticks, bool policy = false)
+/* `one_launch`: the whole batch in ONE launch on the caller's stream.  For steps that have to be joined with the caller's stream
+ * every tick (explicit moves): forking into sub-streams and joining them again costs more than the overlap gains
+ * (65,536 envs, MI355X: 23.3 us per step as one launch, 43.8 as two, 60.2 as three; profiles/r02a_explicit_streams.txt). */
+static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int dist, int ticks, bool policy = false, bool one_launch = false)
 {
     StepParams p;
     p.agent_mem = h->agent_mem;
@@ -1338,12 +1352,13 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
     p.diag = h->diag;
 #endif
     const int64_t tiles = h->n_pad / h->epw;
-    int rc = fork_parts(h);
+    const int parts = one_launch ? 1 : h->parts;
+    int rc = one_launch ? join_parts(h) : fork_parts(h);
     if (rc) return rc;
-    for (int k = 0; k < h->parts; k++) {
-        const int64_t b0 = tiles * k / h->parts, b1 = tiles * (k + 1) / h->parts;
+    for (int k = 0; k < parts; k++) {
+        const int64_t b0 = tiles * k / parts, b1 = tiles * (k + 1) / parts;
         if (b1 <= b0) continue;
-        hipStream_t st = (h->parts == 1 || k < h->main_part) ? h->stream : h->sub[k];
+        hipStream_t st = (parts == 1 || k < h->main_part) ? h->stream : h->sub[k];
         p.block0 = b0;
         const dim3 grid((unsigned)(b1 - b0));
         /* per-launch timing (pom_batch_profile): start / stop events attached to the dispatch itself, i.e. the kernel's own
@@ -1373,10 +1388,7 @@ int pom_batch_step_device(PomBatch* h, const int32_t* moves_dev)
     if (!h || !moves_dev) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     /* the moves were produced on the caller's stream and may be overwritten there right after this call */
-    int rc = join_parts(h);
-    if (!rc) rc = launch_step(h, moves_dev, 0, 0, 1);
-    if (!rc) rc = join_parts(h);
-    return rc;
+    return launch_step(h, moves_dev, 0, 0, 1, false, true);
 }
 
 int pom_batch_step(PomBatch* h, const int32_t* moves_host)
@@ -1386,7 +1398,7 @@ int pom_batch_step(PomBatch* h, const int32_t* moves_host)
     int rc = join_parts(h); /* the previous step's parts still read moves_dev */
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(h->moves_dev, moves_host, (size_t)h->n * 16, hipMemcpyHostToDevice, h->stream));
-    return launch_step(h, h->moves_dev, 0, 0, 1);
+    return launch_step(h, h->moves_dev, 0, 0, 1, false, true);
 }
 
 int pom_batch_step_random(PomBatch* h, uint64_t seed, int32_t dist, int32_t ticks, int32_t ticks_per_launch)

@@ -144,6 +144,7 @@ struct PomStepper {
     PomLane& L;
     uint32_t oldp_ = 0; /* the agents' positions before the tick, a byte each (x | y << 4) */
     int irregular_ = 0; /* a bounce put an agent somewhere else than where he stood before the tick */
+    int folded_ = 0;    /* between the bomb pass and TickBombs: the queued words already carry this tick's timer decrement */
     POM_HD PomStepper(A& a_, PomLane& l_) : a(a_), L(l_) {}
 
     POM_HD int bomb_at(int i) const { return a.bomb(wrap20(L.bIdx + i)); }
@@ -224,6 +225,12 @@ struct PomStepper {
         for (int i = at + 1 + a.sub(); i < L.bCnt; i += A::G) {
             const int v = bomb_at(i);
             put_bomb_at(i - 1, v);
+        }
+        if (folded_) {
+            /* The slot that falls out of the live range keeps its word (stale slots are state) — in the reference
+             * the word as it was BEFORE TickBombs, which has not run yet there: take the folded decrement back out of it. */
+            const int w = bomb_at(L.bCnt - 1);
+            set_bomb_at(L.bCnt - 1, (w & (1 << 24)) ? (w & ~(1 << 24)) : (int)((uint32_t)w + (1u << 16)));
         }
         L.bCnt--;
     }
@@ -709,27 +716,56 @@ struct PomStepper {
         /* agent loop, step.cpp:35-185 */
         int agents_done = 0;
         if (A::G == 4) {
-            /* Quad fast path: lane m handles agent m, all four in ONE pass.  Sound when the order of the loop cannot
-             * matter: no dependency edge (every agent is a root, visited 0,1,2,3) and no two live agents on one cell.
-             * Then an agent reads and writes only its own cell, its destination (shared destinations block both,
-             * step_utility.cpp:264-277, whichever comes first; a shared flame kills both), its own registers and its
-             * own queue slot.  Queue order of planters = agent order = exclusive prefix count below. */
-            int alone = nroots == 4;
+            /* Quad path: lane m handles agent m.  The reference's loop visits the agents chain by chain (root, the agent that
+             * waits for the root's cell, the one that waits for his, ...; step.cpp:36-61).  An agent reads and writes only his
+             * own cell, his destination (shared destinations block both, step_utility.cpp:264-277, whichever comes first; a
+             * shared flame kills both), his own registers and his own queue slot, and the only cell two agents of one tick both
+             * care about is a dependant's destination = his predecessor's cell.  So the loop is run in ROUNDS: round d takes, in
+             * parallel, every agent at depth d of his chain — all of round d-1 is written before round d reads.  Usually nobody
+             * waits for anybody (nroots == 4): one round.  Queue order of planters = the reference's visiting order (`rank`).
+             * Left to the literal loop below: two live agents on one cell (their writes would collide), a dependency cycle
+             * (ouroboros) and lost agents (somebody the chains do not reach). */
+            int par = !ouroboros;
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = i + 1; j < 4; j++)
-                    alone &= ((deadmask >> i) & 1) | ((deadmask >> j) & 1) | (px[i] != px[j]) | (py[i] != py[j]);
-            if (alone) {
+                    par &= ((deadmask >> i) & 1) | ((deadmask >> j) & 1) | (px[i] != px[j]) | (py[i] != py[j]);
+            uint32_t rankp = 0x3210u, depthp = 0u; /* nibble per agent: position in the reference's visiting order, depth in his chain */
+            int rounds = 1;
+            if (par && nroots != 4) {
+                rankp = 0u;
+                int n = 0, md = 0;
+#pragma unroll
+                for (int ri = 0; ri < 4; ri++) {
+                    int i = ri < nroots ? (int)((roots >> (4 * ri)) & 0xF) : 0xF;
+#pragma unroll
+                    for (int d = 0; d < 4; d++) { /* down the chain of root ri: dep[i] = who waits for agent i's cell */
+                        const int on = i != 0xF;
+                        const int sh = 4 * (i & 3);
+                        rankp |= on ? (uint32_t)n << sh : 0u;
+                        depthp |= on ? (uint32_t)d << sh : 0u;
+                        md = (on && d > md) ? d : md;
+                        n += on;
+                        i = on ? (int)((dep >> sh) & 0xF) : 0xF;
+                    }
+                }
+                par = n == 4; /* everybody is reached: nobody lost */
+                rounds = md + 1;
+            }
+            if (par) {
                 agents_done = 1;
                 const int m = a.sub();
                 int av = sel4(m, L.a0), a1v = sel4(m, L.a1);
                 const int mvm = (mvp >> (4 * m)) & 0xF;
                 const int live = !ag_dead(av);
-                /* plants: PlantBombModifiedLife(x, y, m, 11), bboard.cpp:125-146 */
+                const int myrank = (int)((rankp >> (4 * m)) & 0xF), mydepth = (int)((depthp >> (4 * m)) & 0xF);
+                /* plants: PlantBombModifiedLife(x, y, m, 11), bboard.cpp:125-146 — independent of everybody's movement */
                 const int wants = live && mvm == POM_MOVE_BOMB && pom_sext8((uint32_t)av >> 16) < pom_sext16((uint32_t)a1v);
                 const int w_all = a.gor(wants << m);
-                const int slot_off = __builtin_popcount(w_all & ((1 << m) - 1));
+                int slot_off = 0; /* planters visited before me */
+#pragma unroll
+                for (int j = 0; j < 4; j++) slot_off += ((w_all >> j) & 1) & ((int)((rankp >> (4 * j)) & 0xF) < myrank);
                 const int fits = wants && L.bCnt + slot_off < POM_Q;
                 int ubm = (wants && !fits) ? POM_UB_QUEUE_OVERFLOW : 0;
                 int planted_moving = 0; /* PlantBomb leaves the slot's old direction nibble in place: the new bomb may move */
@@ -744,69 +780,79 @@ struct PomStepper {
                     a.put_bomb(slot, b);
                     av = ag_bombcount_add(av, 1);
                 }
-                int died = 0;
-                /* where the agent wants to go and what is there, for all four at once (nothing has been written yet) */
+                /* where the agent wants to go */
                 const int walks = live && mvm != POM_MOVE_IDLE && mvm != POM_MOVE_BOMB;
                 const int x = ag_x(av), y = ag_y(av);
                 const int dkey = (dstp >> (8 * m)) & 0xFF;
                 const int ddx = (dkey & 0xF) - 1, ddy = (dkey >> 4) - 1;
                 const int goes = walks && !oob(ddx, ddy);
                 const int dc = ddy * POM_N + ddx, oc = y * POM_N + x;
-                int item = 0, collide = 0;
-                if (goes) {
-                    item = a.cell(dc);
+                const int vacated = ((on_bomb >> m) & 1) ? POM_C_BOMB : POM_C_PASSAGE;
+                int died_sum = 0;
+                POM_NOUNROLL
+                for (int r = 0; r < rounds; r++) {
+                    const int act = goes && mydepth == r;
+                    int item = 0, collide = 0;
+                    if (act) { /* what is there now: everything the earlier rounds did has been written */
+                        item = a.cell(dc);
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        collide |= (j != m) & !((deadmask >> j) & 1) & (((dstp >> (8 * j)) & 0xFF) == (uint32_t)dkey);
-                }
-                /* Will any bomb move this tick?  One has a direction already, somebody is about to kick one, or a bomb
-                 * planted just now inherited one. */
-                const int kicks = goes && !pc_is_flame(item) && !collide && item == POM_C_BOMB && ag_kick(av);
-                const int bombs_move = ((on_bomb >> 4) & 1) | a.gor(kicks | planted_moving);
-                if (goes) {
-                    const int vacated = ((on_bomb >> m) & 1) ? POM_C_BOMB : POM_C_PASSAGE;
-                    if (pc_is_flame(item)) { /* step.cpp:84-99 */
-                        died = 1;
-                        av |= 1 << 25;
-                        if (a.cell(oc) == (POM_C_AGENT | m)) a.put_cell(oc, vacated);
-                    } else if (!collide) {
-                        if (pc_is_powerup(item)) { /* ConsumePowerup, step_utility.cpp:247-262 */
-                            if (item == POM_EXTRABOMB) a1v = (a1v & ~0xFFFF) | ((a1v + 1) & 0xFFFF);
-                            else if (item == POM_INCRRANGE) a1v += 1 << 16;
-                            else av |= 1 << 24;
-                            item = POM_C_PASSAGE;
-                        }
-                        if (item == POM_C_PASSAGE) { /* step.cpp:120-140 */
+                        for (int j = 0; j < 4; j++)
+                            collide |= (j != m) & !((deadmask >> j) & 1) & (((dstp >> (8 * j)) & 0xFF) == (uint32_t)dkey);
+                    }
+                    /* Will any bomb move this tick?  One has a direction already, somebody is about to kick one, or a bomb
+                     * planted just now inherited one.  Only asked when nobody waits for anybody (the shortcut below). */
+                    int bombs_move = 1;
+                    if (nroots == 4) {
+                        const int kicks = act && !pc_is_flame(item) && !collide && item == POM_C_BOMB && ag_kick(av);
+                        bombs_move = ((on_bomb >> 4) & 1) | a.gor(kicks | planted_moving);
+                    }
+                    int died = 0;
+                    if (act) {
+                        if (pc_is_flame(item)) { /* step.cpp:84-99 */
+                            died = 1;
+                            av |= 1 << 25;
                             if (a.cell(oc) == (POM_C_AGENT | m)) a.put_cell(oc, vacated);
-                            a.put_cell(dc, POM_C_AGENT | m);
-                            av = ag_setpos(av, ddx, ddy);
-                        } else if (item == POM_C_BOMB) { /* step.cpp:147-184 */
-                            /* Stepping onto a resting bomb without kicking it while no bomb moves at all: the agent loop
-                             * would put him there, bomb loop A (step.cpp:195-227) would find the bomb blocked by him and
-                             * bounce him straight back (nobody can have entered the cell he left: no dependency edge; no
-                             * bomb can be heading for it: none moves), restoring both cells and his position.  The pair
-                             * is skipped — provided a queued bomb really sits there (a BOMB item without one bounces nobody)
-                             * and his own cell shows him, so that "restoring" it changes nothing. */
-                            if (!bombs_move && a.cell(oc) == (POM_C_AGENT | m) && bomb_index_alone(ddx | (ddy << 4)) >= 0) {
-                            } else {
-                                a.put_cell(oc, vacated);
+                        } else if (!collide) {
+                            if (pc_is_powerup(item)) { /* ConsumePowerup, step_utility.cpp:247-262 */
+                                if (item == POM_EXTRABOMB) a1v = (a1v & ~0xFFFF) | ((a1v + 1) & 0xFFFF);
+                                else if (item == POM_INCRRANGE) a1v += 1 << 16;
+                                else av |= 1 << 24;
+                                item = POM_C_PASSAGE;
+                            }
+                            if (item == POM_C_PASSAGE) { /* step.cpp:120-140 */
+                                if (a.cell(oc) == (POM_C_AGENT | m)) a.put_cell(oc, vacated);
                                 a.put_cell(dc, POM_C_AGENT | m);
                                 av = ag_setpos(av, ddx, ddy);
-                                if (ag_kick(av)) {
-                                    const int bi = bomb_index_alone(ddx | (ddy << 4)); /* GetBomb; the lanes are on different cells */
-                                    if (bi < 0) ubm |= POM_UB_NULL_BOMB; /* step.cpp:167 dereferences nullptr */
-                                    else put_bomb_at(bi, pb_set(bomb_at(bi), 0xF00000u, (uint32_t)mvm << 20));
+                            } else if (item == POM_C_BOMB) { /* step.cpp:147-184 */
+                                /* Stepping onto a resting bomb without kicking it while no bomb moves at all: the agent loop
+                                 * would put him there, bomb loop A (step.cpp:195-227) would find the bomb blocked by him and
+                                 * bounce him straight back (nobody can have entered the cell he left: no dependency edge; no
+                                 * bomb can be heading for it: none moves), restoring both cells and his position.  The pair
+                                 * is skipped — provided a queued bomb really sits there (a BOMB item without one bounces nobody)
+                                 * and his own cell shows him, so that "restoring" it changes nothing. */
+                                if (!bombs_move && a.cell(oc) == (POM_C_AGENT | m) && bomb_index_alone(ddx | (ddy << 4)) >= 0) {
+                                } else {
+                                    a.put_cell(oc, vacated);
+                                    a.put_cell(dc, POM_C_AGENT | m);
+                                    av = ag_setpos(av, ddx, ddy);
+                                    if (ag_kick(av)) {
+                                        const int bi = bomb_index_alone(ddx | (ddy << 4)); /* GetBomb; the lanes are on different cells */
+                                        if (bi < 0) ubm |= POM_UB_NULL_BOMB; /* step.cpp:167 dereferences nullptr */
+                                        else put_bomb_at(bi, pb_set(bomb_at(bi), 0xF00000u, (uint32_t)mvm << 20));
+                                    }
                                 }
                             }
                         }
                     }
+                    died_sum += died;
+                    if (r + 1 < rounds) deadmask |= a.gor(died << m); /* HasDPCollision skips the dead, step_utility.cpp:268 */
                 }
                 /* back to identical registers in all four lanes */
                 L.a0[0] = a.template gbcast<0>(av); L.a0[1] = a.template gbcast<1>(av);
                 L.a0[2] = a.template gbcast<2>(av); L.a0[3] = a.template gbcast<3>(av);
                 L.a1[0] = a.template gbcast<0>(a1v); L.a1[1] = a.template gbcast<1>(a1v);
                 L.a1[2] = a.template gbcast<2>(a1v); L.a1[3] = a.template gbcast<3>(a1v);
-                L.alive -= a.gadd(died);
+                L.alive -= a.gadd(died_sum);
                 L.bCnt += a.gadd(fits);
                 L.ub |= (uint32_t)a.gor(ubm);
             }
@@ -925,11 +971,25 @@ struct PomStepper {
             int ripe = 0; /* some bomb's own cell shows a walkable item or a flame: the only cells loop B's resting case acts on */
             uint32_t cand = 0; /* queue offsets of the resting bombs under an agent that walked onto them this tick */
             uint32_t occ[4] = {0, 0, 0, 0};
+            /* TickBombs' timer decrement (step_utility.cpp:226-231) is folded into this pass: nothing between here and TickBombs
+             * reads a timer, and loops A / B only replace the position and direction fields of a word, which commutes with
+             * `- (1 << 16)` as long as that does not borrow.  A bomb whose timer is already 0 (out-of-order timers)
+             * WOULD borrow into the fields above: it is left as it is, marked in the (just cleared, otherwise unused) moved
+             * nibble, and decremented where the reference does it, after loop B (the cold pass below). */
+            int late = 0;
             POM_NOUNROLL
             for (int k = a.sub(); k < L.bCnt; k += A::G) { /* split: each lane its own slots, combined below */
-                const int b = pb_set(bomb_at(k), 0xF000000u, 0);
+                int b = pb_set(bomb_at(k), 0xF000000u, 0);
+                const int key = bomb_target_key(b);
+                if (pb_time(b) == 0) {
+                    late = 1;
+                    b |= 1 << 24;
+                } else {
+                    b = (int)((uint32_t)b - (1u << 16));
+                }
                 put_bomb_at(k, b);
-                a.put_bdest(k, bomb_target_key(b));
+                if (k == 0) top = b;
+                a.put_bdest(k, key);
                 moving |= pb_dir(b) != 0;
                 const int idx = pb_y(b) * POM_N + pb_x(b);
                 const int w = idx >> 5;
@@ -957,6 +1017,9 @@ struct PomStepper {
             }
             cand = (uint32_t)a.gor((int)cand);
             ripe = a.gor(ripe);
+            late = a.gor(late);
+            folded_ = 1;
+            int touched = cand != 0; /* did anything after the pass get to write the queue?  (then its head is read again) */
             if (A::G > 1) { /* two lanes' bombs share a cell iff the lanes' cell sets overlap: |union| < sum of |set| */
                 int mine = 0, all = 0;
 #pragma unroll
@@ -992,6 +1055,7 @@ struct PomStepper {
             for (int k = next; k < L.bCnt; k++) loop_a_bomb(mvp, oldp, k, moving);
             POM_STAMP(L, POM_PH_BOMB_A);
             /* bomb loop B, step.cpp:230-278 */
+            touched |= moving | shared | ripe;
             if (!moving && !shared && !ripe) {
                 /* Every bomb rests on a cell of its own that showed neither a walkable item nor a flame when the pass above
                  * looked, and loop A in between only ever writes agent and BOMB items: loop B finds nothing to do. */
@@ -1059,15 +1123,20 @@ struct PomStepper {
                 }
             }
             POM_STAMP(L, POM_PH_BOMB_B);
-            /* TickBombs, step_utility.cpp:224-245, first half: the timers; the head after the decrement comes from the lane
-             * that wrote it */
-            POM_NOUNROLL
-            for (int k = a.sub(); k < L.bCnt; k += A::G) { /* split */
-                const int nb = (int)((uint32_t)bomb_at(k) - (1u << 16));
-                put_bomb_at(k, nb);
-                if (k == 0) top = nb;
+            /* TickBombs, step_utility.cpp:224-245, first half: the timers were decremented in the pass above, except the marked
+             * ones (cold: only states with out-of-order timers have them) */
+            if (late) {
+                POM_NOUNROLL
+                for (int k = a.sub(); k < L.bCnt; k += A::G) { /* split */
+                    const int b = bomb_at(k);
+                    if (b & (1 << 24)) put_bomb_at(k, (int)(((uint32_t)b & ~(1u << 24)) - (1u << 16)));
+                }
+                touched = 1;
             }
+            folded_ = 0;
+            /* the head of the queue: what lane 0 wrote in the pass, unless something has touched the queue since */
             top = a.template gbcast<0>(top);
+            if (touched && L.bCnt > 0) top = bomb_at(0);
             n = L.bCnt;
         }
     }
