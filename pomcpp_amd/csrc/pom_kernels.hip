@@ -245,6 +245,23 @@ __device__ __forceinline__ void store_tile16_x4(uint32_t* base, int64_t np, cons
         g += stride;
     }
 }
+/*
+ * The restart snapshot is kept array-of-structs: env e's record is the 448 contiguous bytes snap[e * 112 .. e * 112 + 111].
+ * A restart needs ONE env's whole record, and in the struct-of-arrays layout of the state buffer that is 112 dwords in 112
+ * different 64-byte sectors (4 useful bytes each: 18 MB of HBM fetch per step at 65,536 envs for the 3.8 % of envs that
+ * restart, a fifth of the kernel's whole traffic; profiles/r02a_head1_summary.txt).  Here the whole wavefront fetches the
+ * record of one restarting env — lane l takes dwords l and l + 64, seven fully used sectors — and writes it into that env's
+ * tile column.  `src` = &snap[e * 112]; ROWS = how many leading rows the caller needs.
+ */
+template <int EPW, int ROWS = POM_REC_DWORDS>
+__device__ __forceinline__ void restart_column(uint32_t* col, const uint32_t* src, int lane)
+{
+    const uint32_t v0 = src[lane];
+    const uint32_t v1 = lane + 64 < ROWS ? src[lane + 64] : 0u;
+    col[lane * EPW] = v0;
+    if (lane + 64 < ROWS) col[(lane + 64) * EPW] = v1;
+}
+
 /* the register-resident rows (timeStep, meta, agents) of one env, out of / into its tile column */
 __device__ __forceinline__ void lane_from_tile(PomLane& L, int& time_step, uint32_t& status, const uint32_t* t, int epw)
 {
@@ -315,7 +332,6 @@ __global__ __launch_bounds__(64, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 
     const int el = lane % EPW, sub = lane / EPW;
     const int64_t e_d = tile_id * EPW + el;
     uint32_t* col_d = p.state + e_d;         /* buffers hold n_pad columns: in range for every lane */
-    const uint32_t* scol_d = p.snap + e_d;
     /* the tick: G = 1: the lanes with sub == 0 own env el; G = 4: lane -> (env lane/4, member lane%4), all lanes run */
     const int ec = G == 1 ? el : lane >> 2;
     const int member = G == 1 ? 0 : lane & 3;
@@ -330,26 +346,13 @@ __global__ __launch_bounds__(64, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 
 #endif
     long long c_steps = 0, c_episodes = 0, c_resets = 0, c_ub = 0;
 
-    /* a finished env restarts from its snapshot: pick the source column per lane, one pass over the record */
-    bool reload_d = e_d < p.n && env_mode && p.auto_reset && !FRESH && ((col_d[POM_REC_META2 * np] >> 8) & POM_ST_DONE);
-    if (EPW == 16) {
-        /* everything from the state buffer in 16-byte pieces; the (rarer) restarting envs' columns are then overwritten from
-         * the snapshot, lanes masked — both land in issue order, the wait in between is only for the second pass's sake */
-        load_tile16_x4(p.state + tile_id * EPW, np, tile, lane);
-        if (__any(reload_d)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (reload_d) load_tile<EPW>(scol_d, np, tile, sub);
-        }
-    } else {
-        load_tile<EPW>(reload_d ? scol_d : col_d, np, tile, sub);
-    }
-    c_resets += __popcll(__ballot(reload_d && sub == 0));
+    if (EPW == 16) load_tile16_x4(p.state + tile_id * EPW, np, tile, lane); /* 16-byte pieces, 7 instructions */
+    else load_tile<EPW>(col_d, np, tile, sub);
     uint32_t m0 = 0, m1 = 0; /* POLICY: this lane's agent's memory */
     if (POLICY) {
         m0 = p.agent_mem[tile_id * 64 + lane];
         m1 = p.agent_mem[4 * np + tile_id * 64 + lane];
     }
-    bool restarted = POLICY && !FRESH && __shfl((int)reload_d, ec) != 0; /* lane ec moved env ec's rows */
     /* the first tick's moves do not depend on the record: hash / fetch them while the record is on its way */
     uint64_t draw0 = 0;
     int4 moves0 = make_int4(0, 0, 0, 0);
@@ -365,6 +368,7 @@ __global__ __launch_bounds__(64, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 
     int time_step = 0;
     uint32_t status = 0;
     lane_from_tile(L, time_step, status, t, EPW);
+    bool restarted = false;
 
     LdsEnv<EPW, G> acc{t, member};
     PomStepper<LdsEnv<EPW, G>> stepper(acc, L);
@@ -398,18 +402,23 @@ __global__ __launch_bounds__(64, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 
             if (reload) lane_from_tile(L, time_step, status, t, EPW); /* the register-resident rows, from the new record */
             restarted = reload;
             c_resets += __popcll(__ballot(reload && owner));
-        } else if (tk > 0) {
-            /* the lanes that move env el's rows need the verdict of the lane that owns env el */
-            const int done_d = __shfl((int)(status & POM_ST_DONE), G == 1 ? el : 4 * el);
-            reload_d = e_d < p.n && env_mode && p.auto_reset && done_d;
+        } else {
+            /* a finished env restarts from its snapshot (tick 0: as the record says; later ticks of a launch: as the epilogue
+             * found), one restarting env after the other, by the whole wavefront */
             const bool reload = e < p.n && env_mode && p.auto_reset && (status & POM_ST_DONE) && runs;
-            if (__any(reload_d)) {
-                if (reload_d) load_tile<EPW>(scol_d, np, tile, sub); /* EXEC-masked: only the restarting envs' columns are overwritten */
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (reload) lane_from_tile(L, time_step, status, t, EPW);
+            uint64_t todo = __ballot(reload && owner);
+            if (todo) {
+                c_resets += __popcll(todo);
+                do {
+                    const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)todo) - 1); /* an owner lane */
+                    todo &= todo - 1;
+                    const int ec_u = G == 1 ? src : src >> 2;
+                    restart_column<EPW>(tile + ec_u, p.snap + (tile_id * EPW + ec_u) * POM_REC_DWORDS, lane);
+                } while (todo);
+                asm volatile("" ::: "memory"); /* other lanes wrote this lane's column: no read of it may be scheduled earlier */
+                if (reload) lane_from_tile(L, time_step, status, t, EPW); /* the register-resident rows, from the new record */
             }
             restarted = reload;
-            c_resets += __popcll(__ballot(reload && owner));
         }
         const bool active = valid && !(env_mode && (status & POM_ST_DONE));
         bool newly_done = false, new_ub = false;
@@ -556,40 +565,32 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
 #if defined(POM_DIAG)
     long long t_last = (long long)clock64(), t_acc[POM_PP_N] = {0, 0, 0, 0, 0, 0, 0};
 #endif
-    /* data movement: lane -> (env lane%16, row group lane/16) */
-    const int el = lane & 15, sub = lane >> 4;
-    const int64_t e_d = tile_id * 16 + el;
-    const bool restart_d = e_d < p.n && env_mode && p.auto_reset && ((p.state[POM_REC_META2 * np + e_d] >> 8) & POM_ST_DONE);
     load_tile16_x4<POL_LOAD_ROWS>(p.state + tile_id * 16, np, tile, lane);
-    if (!p.fresh && __any(restart_d)) { /* restarting envs are judged on their snapshot: overwrite those columns, lanes masked */
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (restart_d) {
-            const uint32_t* g = p.snap + e_d + (int64_t)sub * np;
-#pragma unroll 4
-            for (int r0 = 0; r0 < POL_ROWS; r0 += 4) {
-                dma_rows(g, tile + r0 * 16);
-                g += 4 * np;
-            }
-        }
-    }
     /* the policy: lane -> (env lane/4, agent lane%4) */
     const int ec = lane >> 2, id = lane & 3;
     const int64_t e = tile_id * 16 + ec;
     const int64_t slot = e * 4 + id; /* = tile_id * 64 + lane */
     uint32_t m0 = p.agent_mem[slot], m1 = p.agent_mem[4 * np + slot];
-    const bool restart = __shfl((int)restart_d, ec) != 0;
-    if (restart) m0 = m1 = 0; /* a new game gets fresh agents */
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (p.fresh) { /* the same board the tick kernel is about to draw for a restarting env; the tick counts the episode */
-        uint64_t todo = __ballot(restart && id == 0 && e < p.n);
+    /* an env the tick is about to restart is judged on the board it will restart on: its snapshot record (array of structs,
+     * fetched by the whole wavefront: restart_column) or, with fresh boards, the board the tick kernel is about to draw for it
+     * (the tick counts the episode) */
+    const bool restart = e < p.n && env_mode && p.auto_reset && ((tile[POM_REC_META2 * 16 + ec] >> 8) & POM_ST_DONE);
+    if (restart) m0 = m1 = 0; /* a new game gets fresh agents */
+    {
+        uint64_t todo = __ballot(restart && id == 0);
         while (todo) {
             const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)todo) - 1);
             todo &= todo - 1;
             const int ec_u = src >> 2;
-            const uint32_t ep = p.episode[tile_id * 16 + ec_u] + 1u;
-            const uint32_t key = pom_board_key(p.board_seed, (uint32_t)(p.env_offset + tile_id * 16 + ec_u),
-                                               (uint32_t)__builtin_amdgcn_readfirstlane((int)ep));
-            pom_boardgen_wave<16, POL_ROWS>(tile + ec_u, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), lane);
+            if (p.fresh) {
+                const uint32_t ep = p.episode[tile_id * 16 + ec_u] + 1u;
+                const uint32_t key = pom_board_key(p.board_seed, (uint32_t)(p.env_offset + tile_id * 16 + ec_u),
+                                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)ep));
+                pom_boardgen_wave<16, POL_ROWS>(tile + ec_u, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), lane);
+            } else {
+                restart_column<16, POL_ROWS>(tile + ec_u, p.snap + (tile_id * 16 + ec_u) * POM_REC_DWORDS, lane);
+            }
         }
         asm volatile("" ::: "memory");
     }
@@ -872,7 +873,11 @@ __global__ __launch_bounds__(64) void pom_generate_kernel(uint32_t* state, uint3
     __syncthreads();
     /* whole tiles: the buffers hold n_pad columns; columns past n are blank records here, as after creation */
     store_tile16_x4(state + tile_id * 16, np, tile, lane);
-    store_tile16_x4(snap + tile_id * 16, np, tile, lane);
+    for (int ec = 0; ec < 16; ec++) { /* the snapshot: array of structs (restart_column); columns past n are blank like the state's */
+        uint32_t* rec = snap + (tile_id * 16 + ec) * POM_REC_DWORDS;
+        rec[lane] = tile[lane * 16 + ec];
+        if (lane + 64 < POM_REC_DWORDS) rec[lane + 64] = tile[(lane + 64) * 16 + ec];
+    }
 }
 
 /* ---- boundary kernels ----------------------------------------------------------------------- */
@@ -899,8 +904,8 @@ __global__ void pom_pack_kernel(const int32_t* __restrict__ aos, int64_t first, 
         for (int d = 0; d < POM_REC_DWORDS; d++) col[d * np] = 0; /* inert blank board ... */
         col[POM_REC_META2 * np] = (uint32_t)POM_ST_DONE << 8;     /* ... that is never stepped in ENV mode */
     }
-    uint32_t* s = snap + first + i;
-    for (int d = 0; d < POM_REC_DWORDS; d++) s[d * np] = col[d * np];
+    uint32_t* s = snap + (first + i) * POM_REC_DWORDS; /* the snapshot is array-of-structs (restart_column) */
+    for (int d = 0; d < POM_REC_DWORDS; d++) s[d] = col[d * np];
 }
 
 __global__ void pom_unpack_kernel(const uint32_t* __restrict__ state, int64_t first, int64_t count, int64_t np, int32_t* aos)
@@ -933,7 +938,7 @@ __global__ void pom_snapshot_kernel(const uint32_t* __restrict__ state, uint32_t
     for (int d = 0; d < POM_REC_DWORDS; d++) {
         uint32_t v = state[d * np + e];
         if (d == POM_REC_META2) v &= 0xFFu; /* a snapshot starts an episode: status and flags clear */
-        snap[d * np + e] = v;
+        snap[e * POM_REC_DWORDS + d] = v;    /* array of structs (restart_column) */
     }
 }
 

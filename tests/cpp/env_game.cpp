@@ -69,11 +69,14 @@ int main(int argc, char** argv)
 #endif
         bboard::Environment env;
         env.Step();  // before MakeGame: a no-op (environment.cpp:125)
-        env.MakeGame({&a[0], &a[1], &a[2], &a[3]}, (g & 1) != 0);
+        env.MakeGame({&a[0], &a[1], &a[2], &a[3]}, false);  // (true shuffles the corners from std::random_device: not for a test)
         env.SetStepListener([&listened](const bboard::Environment&) { ++listened; });
         for (bboard::AgentInfo& info : env.GetState().agents) info.canKick = (g % 3) == 0;  // as main.cpp:18-21 does
-        if (g % 4 == 3) bboard::InitBoardItems(env.GetState(), 1000 + g);                   // other boards
-        if (g % 4 == 3) env.GetState().PutAgentsInCorners(0, 1, 2, 3);
+        if (g % 4 != 0) {  // other boards, other corners
+            bboard::InitBoardItems(env.GetState(), 1000 + g);
+            for (bboard::AgentInfo& info : env.GetState().agents) info.x = info.y = 0;  // PutAgentsInCorners relies on zeroed positions
+            env.GetState().PutAgentsInCorners(g % 4, (g + 1) % 4, (g + 2) % 4, (g + 3) % 4);
+        }
         const bboard::State start = env.GetState();
         const int32_t header[2] = {0x504F4D45, g};
         put(f, header, sizeof header);
