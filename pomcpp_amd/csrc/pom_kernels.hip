@@ -110,7 +110,7 @@ struct StepParams {
     uint64_t seed;
     uint32_t tick0;
     int32_t dist, ticks, mode, auto_reset, max_steps;
-    int64_t block0; /* this launch covers tiles block0 .. block0 + gridDim.x - 1 (sub-batch of a split step) */
+    int64_t block0, block_end; /* this launch covers tiles block0 .. block_end - 1 (sub-batch of a split step) */
     uint32_t* agent_mem; /* POLICY instantiation: SimpleAgent memory, [2][4 * n_pad] */
     uint32_t* episode;   /* games started so far per env (fresh boards: keys the next board) */
     uint64_t board_seed;
@@ -299,11 +299,16 @@ struct PolicyStore {
 #ifndef POM_QUAD_WAVES
 #define POM_QUAD_WAVES 4
 #endif
+/* wavefronts per workgroup.  Every wavefront works on a tile of its own in its own slice of the workgroup's LDS and never
+ * synchronises with the others; more than one per workgroup only means fewer workgroups for the dispatcher to place. */
+#ifndef POM_WPB
+#define POM_WPB 1
+#endif
 /* POLICY: the moves are not read but decided here — lane m of an env's quad is agent m and runs SimpleAgent::act
  * (pom_policy_body.h) on the tile the tick is about to work on: Environment::Step with four SimpleAgents in ONE kernel, one
  * record load per tick instead of two and no Move[4] round trip (pom_batch_step_simple). */
 template <int EPW, int G, bool FRESH, bool POLICY = false>
-__global__ __launch_bounds__(64, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW == 32 ? 2 : 1)) void pom_step_kernel(StepParams p)
+__global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW == 32 ? 2 : 1)) void pom_step_kernel(StepParams p)
 {
     static_assert(G == 1 || (G == 4 && EPW == 16), "a quad per env needs 16 envs per wavefront");
     static_assert(!POLICY || G == 4, "the policy runs one agent per lane of the quad");
@@ -312,10 +317,11 @@ __global__ __launch_bounds__(64, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 
      * wavefronts per CU, i.e. all of 65,536 envs resident at once. */
     constexpr int ROWS = POLICY ? POM_REC_DWORDS + 44 : LDS_ROWS;
     static_assert(ROWS >= LDS_ROWS, "the tick's scratch rows fit under the overlay");
-    __shared__ __attribute__((aligned(16))) uint32_t tile[ROWS * EPW];
+    __shared__ __attribute__((aligned(16))) uint32_t tiles_[POM_WPB][ROWS * EPW];
+    uint32_t* const tile = tiles_[POM_WPB == 1 ? 0 : threadIdx.x >> 6];
     uint8_t* const danger = reinterpret_cast<uint8_t*>(tile + POM_REC_DWORDS * EPW);
     uint32_t* const sets = tile + (POM_REC_DWORDS + 32) * EPW;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     /* XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own
      * L2).  With fewer than 64 envs per wavefront neighbouring tiles share 128-B lines of every record row, so they are
      * given to workgroups of the SAME XCD: the second touch of a line is an L2 hit instead of a second HBM fetch
@@ -324,6 +330,10 @@ __global__ __launch_bounds__(64, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 
     {
         const int64_t b = blockIdx.x, nb = gridDim.x, q = nb / 8, r = nb % 8, x = b % 8;
         tile_local = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
+    }
+    if (POM_WPB > 1) {
+        tile_local = tile_local * POM_WPB + (threadIdx.x >> 6);
+        if (p.block0 + tile_local >= p.block_end) return; /* the last workgroup of a launch may be short of tiles */
     }
     const int64_t tile_id = p.block0 + tile_local;
     const int64_t np = p.n_pad;
@@ -1365,18 +1375,19 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
         if (b1 <= b0) continue;
         hipStream_t st = (parts == 1 || k < h->main_part) ? h->stream : h->sub[k];
         p.block0 = b0;
-        const dim3 grid((unsigned)(b1 - b0));
+        p.block_end = b1;
+        const dim3 grid((unsigned)((b1 - b0 + POM_WPB - 1) / POM_WPB));
         /* per-launch timing (pom_batch_profile): start / stop events attached to the dispatch itself, i.e. the kernel's own
          * duration as a profiler reports it, not the stream's period (events recorded around a launch also time the gap) */
         const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
         hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
         const bool fresh = h->fresh && h->mode == POM_MODE_ENV && h->auto_reset;
 #define POM_LAUNCH(E, G) \
-    (fresh ? hipExtLaunchKernelGGL((pom_step_kernel<E, G, true>), grid, dim3(64), 0, st, ev0, ev1, 0, p) \
-           : hipExtLaunchKernelGGL((pom_step_kernel<E, G, false>), grid, dim3(64), 0, st, ev0, ev1, 0, p))
+    (fresh ? hipExtLaunchKernelGGL((pom_step_kernel<E, G, true>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p) \
+           : hipExtLaunchKernelGGL((pom_step_kernel<E, G, false>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p))
         if (policy) { /* the caller checked h->quad */
-            fresh ? hipExtLaunchKernelGGL((pom_step_kernel<16, 4, true, true>), grid, dim3(64), 0, st, ev0, ev1, 0, p)
-                  : hipExtLaunchKernelGGL((pom_step_kernel<16, 4, false, true>), grid, dim3(64), 0, st, ev0, ev1, 0, p);
+            fresh ? hipExtLaunchKernelGGL((pom_step_kernel<16, 4, true, true>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p)
+                  : hipExtLaunchKernelGGL((pom_step_kernel<16, 4, false, true>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p);
         } else if (h->epw == 64) POM_LAUNCH(64, 1);
         else if (h->epw == 32) POM_LAUNCH(32, 1);
         else if (h->quad) POM_LAUNCH(16, 4);
@@ -1581,6 +1592,19 @@ int pom_diag_read(PomBatch* h, long long out[POM_PH_N])
     for (int64_t w = 0; w < h->n_waves; w++)
         for (int k = 0; k < POM_PH_N; k++) out[k] += tmp[w * POM_PH_N + k];
     delete[] tmp;
+    return POM_OK;
+}
+#endif
+
+#if defined(POM_DIAG)
+/* diagnostic build only: the per-wavefront accumulators as they are (n_waves x POM_PH_N), then cleared */
+extern "C" int pom_diag_read_raw(PomBatch* h, long long* out, long long max_waves)
+{
+    if (!h || !h->diag || max_waves < h->n_waves) return POM_E_ARG;
+    if (int jr = join_parts(h)) return jr;
+    HIPCHK(hipMemcpyAsync(out, h->diag, (size_t)h->n_waves * POM_PH_N * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemsetAsync(h->diag, 0, (size_t)h->n_waves * POM_PH_N * 8, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return POM_OK;
 }
 #endif

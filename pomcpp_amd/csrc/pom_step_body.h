@@ -288,10 +288,25 @@ struct PomStepper {
         return room < s ? room : s;
     }
 
+    /* Kill (bboard.hpp:474-481) for every agent in the bit set `victims`; all lanes of the group hold the same set */
+    POM_HD void kill_set(int victims)
+    {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int hit = (victims >> j) & 1 & !ag_dead(L.a0[j]);
+            L.a0[j] |= hit << 25;
+            L.alive -= hit;
+        }
+    }
+
     /* `top_word`: for rem == REM_TOP the caller may pass the head of the queue it has just looked at (-1: not known) */
     POM_HD void explode(int x, int y, int strength, int rem, int top_word = -1)
     {
         int s = strength < 0 ? 0 : strength > POM_N ? POM_N : strength;
+        if (s > 2) { /* a long blast: no look-ahead, the segment engine takes ray after ray (explode_long) */
+            explode_long(x, y, strength, rem);
+            return;
+        }
         /* Split fast path.  Read-only scan of the four rays (lane `sub` takes rays sub, sub+G, ...): how far does
          * each reach, and does any of them touch a BOMB or an agent cell?  If none does, no chain and no kill can
          * happen along the rays, every cell belongs to exactly one ray, and the order +x,-x,+y,-y is immaterial:
@@ -329,15 +344,9 @@ struct PomStepper {
                 }
                 lens |= (uint32_t)len << (4 * r);
             }
-            if (!a.gor(chains)) {
+            if (__builtin_expect(!a.gor(chains), 1)) {
                 flame_prologue(x, y, strength, e0);
-                victims = a.gor(victims);
-#pragma unroll
-                for (int j = 0; j < 4; j++) { /* Kill, bboard.hpp:474-481, for every agent a ray met */
-                    const int hit = (victims >> j) & 1 & !ag_dead(L.a0[j]);
-                    L.a0[j] |= hit << 25;
-                    L.alive -= hit;
-                }
+                kill_set(a.gor(victims)); /* Kill, bboard.hpp:474-481, for every agent a ray met */
                 POM_NOUNROLL
                 for (int r = a.sub(); r < 4; r += A::G) { /* no reads: the scan has seen every cell it writes */
                     const int len = (lens >> (4 * r)) & 0xF;
@@ -410,6 +419,129 @@ struct PomStepper {
             }
             if (go_on) i++;
             else { dir++; i = 1; }
+        }
+    }
+
+    /* Long blasts (strength > 2: power-ups collected, the stress boards).  SpawnFlame's recursion (bboard.cpp:24-57,111-118,
+     * 198-263) as a loop over ray SEGMENTS, without the look-ahead of explode(): with long rays and many bombs most blasts
+     * meet a bomb anyway.  The lanes of the group take the next cells of the current ray, one cell each (lane j: distance
+     * i + j; with one lane per env the same code walks the four cells itself).  The first cell — in ray order — at which
+     * something happens decides: a rigid cell or the end of the ray stops it before, wood stops it after, a queued bomb
+     * under a BOMB / agent item starts the nested explosion (the frame is suspended, bboard.cpp:30-40).  The cells before
+     * that one are ordinary: their agents die, they take the flame, independently of each other, so they are written in
+     * parallel.  After a nested explosion the ray is picked up at the cell that triggered it (SpawnFlameItem's tail,
+     * bboard.cpp:42-56) and everything beyond is read afresh — the nested chain may have changed it.  Nested blasts of any
+     * strength stay in this loop (the literal engine of explode() likewise keeps the long blasts nested in a short one). */
+    POM_HD void explode_long(int x, int y, int strength, int rem)
+    {
+        int s = strength < 0 ? 0 : strength > POM_N ? POM_N : strength;
+        flame_prologue(x, y, strength);
+        int dir = 0, i = 1, sp = 0, resume = 0;
+        constexpr int NJ = 4 / A::G;
+        POM_NOUNROLL
+        for (;;) {
+            if (!resume) { /* skip exhausted rays: length s or the board edge, whichever is nearer */
+                POM_NOUNROLL
+                for (; dir < 4; dir++, i = 1) {
+                    if (i <= ray_room(x, y, s, dir)) break;
+                }
+            }
+            if (dir >= 4) { /* all four rays done: the caller's bookkeeping, then back into the parent */
+                explode_epilogue(rem);
+                if (sp == 0) return;
+                sp--;
+                const int fr = a.frame(sp);
+                x = fr & 0xF; y = (fr >> 4) & 0xF; s = (fr >> 8) & 0xF;
+                dir = (fr >> 12) & 7; i = (fr >> 15) & 0xF; rem = (fr >> 19) & 63;
+                resume = 1; /* continue inside SpawnFlameItem, after its ExplodeBombAt */
+            }
+            const int c0 = y * POM_N + x;
+            if (resume) { /* SpawnFlameItem tail, bboard.cpp:42-56, for the cell whose bomb has just gone off: read again */
+                const int c = ray_cell(c0, dir, i);
+                const int e = a.cell(c);
+                int go_on = 0;
+                if (e != POM_C_RIGID) {
+                    const int was_wood = pc_is_wood(e);
+                    a.set_cell(c, POM_C_FLAME | ((c0 << 3) + (was_wood ? (e & 3) : 0)));
+                    go_on = !was_wood;
+                }
+                resume = 0;
+                if (go_on) i++;
+                else { dir++; i = 1; }
+                continue;
+            }
+            const int lim = ray_room(x, y, s, dir);
+            int cj[NJ], ej[NJ];
+            int first = 0x7FFFFFFF; /* (j << 12 | what happens there), smallest j wins */
+#pragma unroll
+            for (int q = 0; q < NJ; q++) {
+                const int j = a.sub() + q * A::G, d = i + j;
+                const int on = d <= lim;
+                cj[q] = ray_cell(c0, dir, on ? d : lim);
+                ej[q] = a.cell(cj[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < NJ; q++) {
+                const int j = a.sub() + q * A::G, d = i + j;
+                const int e = ej[q];
+                int kind = 0, idx = 0; /* kind: 0 ordinary, 1 the ray stops before this cell, 2 wood: stops after it, 3 a queued bomb */
+                if (d > lim || e == POM_C_RIGID) {
+                    kind = 1;
+                } else if (e == POM_C_BOMB || pc_is_agent(e)) {
+                    const int cy = cj[q] / POM_N;
+                    idx = bomb_index_alone((cj[q] - cy * POM_N) | (cy << 4));
+                    kind = idx >= 0 ? 3 : 0;
+                    idx = idx >= 0 ? idx : 0;
+                } else if (pc_is_wood(e)) {
+                    kind = 2;
+                }
+                const int key = (j << 12) | (kind << 10) | (pc_is_agent(e) << 9) | ((e & 3) << 7) | idx;
+                first = (kind != 0 && key < first) ? key : first;
+            }
+            first = a.gmin(first);
+            const int fj = first == 0x7FFFFFFF ? 4 : first >> 12;
+            int victims = 0;
+#pragma unroll
+            for (int q = 0; q < NJ; q++) { /* the ordinary cells before the deciding one */
+                const int j = a.sub() + q * A::G;
+                if (j < fj) {
+                    if (pc_is_agent(ej[q])) victims |= 1 << (ej[q] & 3);
+                    a.put_cell(cj[q], POM_C_FLAME | (c0 << 3));
+                }
+            }
+            kill_set(a.gor(victims));
+            if (fj == 4) { /* four ordinary cells: on along the ray */
+                i += 4;
+                continue;
+            }
+            const int kind = (first >> 10) & 3;
+            if (kind == 3) { /* SpawnFlameItem head, bboard.cpp:26-40: the agent on the cell dies, the bomb under it goes off */
+                const int d = i + fj, jq = first & 0x1F;
+                if ((first >> 9) & 1) kill((first >> 7) & 3);
+                if (sp >= POM_STACK_DEPTH) { /* cannot happen with <= 20 queued bombs */
+                    L.ub |= POM_UB_BAD_INDEX;
+                    dir = 4; /* give up on this explosion in a defined way: no further rays */
+                    continue;
+                }
+                a.set_frame(sp, x | (y << 4) | (s << 8) | (dir << 12) | (d << 15) | (rem << 19));
+                sp++;
+                const int st2 = owner_strength(bomb_at(jq));
+                const int c = ray_cell(c0, dir, d);
+                y = c / POM_N;
+                x = c - y * POM_N;
+                rem = jq;
+                flame_prologue(x, y, st2);
+                s = st2 < 0 ? 0 : st2 > POM_N ? POM_N : st2;
+                dir = 0;
+                i = 1;
+                continue;
+            }
+            if (kind == 2) { /* wood burns and keeps its flag, the ray ends (bboard.cpp:44-55) */
+                const int c = ray_cell(c0, dir, i + fj);
+                a.set_cell(c, POM_C_FLAME | ((c0 << 3) + ((first >> 7) & 3)));
+            }
+            dir++;
+            i = 1;
         }
     }
 
@@ -968,7 +1100,7 @@ struct PomStepper {
              * bomb of this env is moving and whether two bombs share a cell (121-bit occupancy in 4 registers):
              * if neither, loop B below cannot see a collision and collapses to one cell test per bomb. */
             int moving = 0, shared = 0;
-            int ripe = 0; /* some bomb's own cell shows a walkable item or a flame: the only cells loop B's resting case acts on */
+            int ripe = 0; /* some bomb's own cell shows PASSAGE or a flame: the only cells loop B's resting case acts on */
             uint32_t cand = 0; /* queue offsets of the resting bombs under an agent that walked onto them this tick */
             uint32_t occ[4] = {0, 0, 0, 0};
             /* TickBombs' timer decrement (step_utility.cpp:226-231) is folded into this pass: nothing between here and TickBombs
@@ -1004,7 +1136,7 @@ struct PomStepper {
                  * agent that walked onto it this tick means a bounce-back */
                 if (idx < POM_CELLS) {
                     const int e = a.cell(idx);
-                    ripe |= pc_is_walkable(e) | pc_is_flame(e);
+                    ripe |= (e == POM_C_PASSAGE) | pc_is_flame(e);
                     if (pc_is_static_block(e) || pc_is_agent(e)) {
                         const int ag = get_agent(pb_x(b), pb_y(b));
                         if (ag > -1) {
@@ -1056,14 +1188,14 @@ struct PomStepper {
             POM_STAMP(L, POM_PH_BOMB_A);
             /* bomb loop B, step.cpp:230-278 */
             touched |= moving | shared | ripe;
-            if (!moving && !shared && !ripe) {
-                /* Every bomb rests on a cell of its own that showed neither a walkable item nor a flame when the pass above
-                 * looked, and loop A in between only ever writes agent and BOMB items: loop B finds nothing to do. */
-            } else if (!moving && !shared) {
-                /* every bomb rests on a cell of its own: HasBombCollision is false for all of them, each "moves"
-                 * onto its own cell (step.cpp:243-272): a walkable cell there becomes BOMB, a flame detonates it.
-                 * Split: first only look (does any bomb sit in a flame?); without a detonation the writes are
-                 * independent and done in parallel, with one the queue is walked in order */
+            /* While no bomb moves and no two share a cell, HasBombCollision is false for every bomb and each one "moves" onto its
+             * own cell (step.cpp:243-272): PASSAGE there becomes BOMB, a flame detonates the bomb, anything else stays (a static
+             * item makes the reference set the already idle bomb idle).  If the pass above saw neither passage nor flame under a
+             * bomb, loop B has nothing to do (loop A in between only writes agent and BOMB items).  Otherwise look first: without
+             * a detonation the writes are independent and done in parallel; with one — as with moving bombs or shared cells — the
+             * queue is walked in order by the literal loop. */
+            int general = moving | shared;
+            if (!general && ripe) {
                 int in_flame = 0;
                 POM_NOUNROLL
                 for (int k = a.sub(); k < L.bCnt; k += A::G) {
@@ -1075,19 +1207,13 @@ struct PomStepper {
                     for (int k = a.sub(); k < L.bCnt; k += A::G) {
                         const int b = bomb_at(k);
                         const int c = pb_y(b) * POM_N + pb_x(b);
-                        if (pc_is_walkable(a.cell(c))) a.put_cell(c, POM_C_BOMB);
+                        if (a.cell(c) == POM_C_PASSAGE) a.put_cell(c, POM_C_BOMB);
                     }
                 } else {
-                    POM_NOUNROLL
-                    for (int k = 0; k < L.bCnt; k++) {
-                        const int b = bomb_at(k);
-                        const int c = pb_y(b) * POM_N + pb_x(b);
-                        const int e = a.cell(c);
-                        if (pc_is_walkable(e)) a.set_cell(c, POM_C_BOMB);
-                        else if (pc_is_flame(e)) explode(pb_x(b), pb_y(b), owner_strength(b), k);
-                    }
+                    general = 1;
                 }
-            } else
+            }
+            if (general)
             POM_NOUNROLL
             for (int k = 0; k < L.bCnt; k++) {
                 int b = bomb_at(k);
