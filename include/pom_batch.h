@@ -51,7 +51,16 @@ typedef struct PomBatchOptions {
     int32_t device;       /* HIP device ordinal */
     void*   stream;       /* hipStream_t to run on, or NULL: the library creates one */
     int32_t mode;         /* POM_MODE_RAW / POM_MODE_ENV */
-    int32_t auto_reset;   /* ENV mode: a finished env is reloaded from its snapshot and stepped in the same tick */
+    int32_t auto_reset;   /* ENV mode, what happens to a finished env (POM_RESET_*):
+                             0 nothing: it stays finished and is not stepped (Environment::Step, environment.cpp:125-128);
+                             1 POM_RESET_AT_START: the NEXT tick first puts it back on its start state (snapshot, or the next
+                               generated board) and steps that in the same tick — the caller never sees the start state, and a
+                               move supplied for that tick was chosen looking at the finished game;
+                             2 POM_RESET_AT_END: the tick that finishes the episode also puts the env on its next start state.
+                               State, observation and status then show the new episode's first state (status bit "restarted"),
+                               the next move is a move for it, and the finished episode's outcome and final State are kept
+                               (pom_batch_last_results, pom_batch_download_terminal) until the env finishes again.  The
+                               sequence of states stepped is the same in both modes. */
     int32_t max_steps;    /* ENV mode: env is done once timeStep reaches this (0 = no limit); StartGame's bound, environment.cpp:71 */
     int64_t env_offset;   /* global index of env 0, keys the synthetic move stream when a job is sharded over GPUs */
     int32_t envs_per_wave; /* 0 = default (16); else 16, 32 or 64 envs per wavefront (results are identical) */
@@ -64,6 +73,8 @@ typedef struct PomBatchOptions {
                               device inside the tick, the host is not involved */
     uint64_t board_seed;   /* seed of those boards; pom_batch_generate replaces it */
 } PomBatchOptions;
+
+enum { POM_RESET_OFF = 0, POM_RESET_AT_START = 1, POM_RESET_AT_END = 2 };
 
 typedef struct PomBatch PomBatch;
 
@@ -121,6 +132,14 @@ int pom_batch_set_tick(PomBatch* h, int64_t tick);
 int pom_batch_status(PomBatch* h, int64_t first, int64_t count, int32_t* done, int32_t* winner, int32_t* draw,
                      int32_t* alive, int32_t* time_step, uint32_t* ubflags);
 
+/* POM_RESET_AT_END: per env of [first, first+count), any output may be NULL: `finished` = 1 if the env's latest tick ended an
+ * episode (the env now stands on its next start state); winner / draw / length (timeStep reached) / alive of the env's most
+ * recently finished episode (-1 / 0 / 0 / 0 while it has not finished any); pom_batch_download_terminal gives that
+ * episode's final State (all-zero while there is none).  POM_E_ARG in the other reset modes. */
+int pom_batch_last_results(PomBatch* h, int64_t first, int64_t count, int32_t* finished, int32_t* winner, int32_t* draw,
+                           int32_t* length, int32_t* alive);
+int pom_batch_download_terminal(PomBatch* h, void* states, int64_t first, int64_t count);
+
 int pom_batch_counters(PomBatch* h, int64_t out[POM_CNT_N]);
 /* same totals left in device memory (int64[POM_CNT_N]) on the handle's stream, e.g. for an RCCL all-reduce */
 int pom_batch_counters_device(PomBatch* h, void* dev_int64x4);
@@ -160,7 +179,8 @@ int pom_batch_device_view(PomBatch* h, void** base, int64_t* n_pad, int32_t* rec
  *          uint8, IEEE half or float (all values are small integers, exact in each).
  * agent_attrs (nullable): int32 [n][4][8] = x, y, alive, ammo (maxBombCount - bombCount), bombCount, maxBombCount,
  *          bombStrength, canKick.   env_attrs (nullable): int32 [n][4] = timeStep, aliveAgents, status (1 done | 2 draw |
- *          4 timed out), winner (-1 = none) — the values pom_batch_status reports.
+ *          4 timed out | 8 restarted: POM_RESET_AT_END put the env on this start state at the end of the last tick), winner
+ *          (-1 = none) — the values pom_batch_status reports.
  */
 enum { POM_OBS_U8 = 0, POM_OBS_F16 = 1, POM_OBS_F32 = 2 };
 enum { POM_OBS_PLANES = 16, POM_OBS_AGENT_ATTRS = 8, POM_OBS_ENV_ATTRS = 4 };

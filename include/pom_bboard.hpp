@@ -417,9 +417,12 @@ private:
 // (environment.cpp:139-146); a dead agent's entry is IDLE.
 class BatchEnvironment {
 public:
-    // freshBoards: with autoReset, a finished game restarts on a newly drawn board (InitState's distribution, bboard.cpp:339-382,
-    // generated on the device; include/pom_boardgen.h) instead of replaying the one handed to MakeGame
-    explicit BatchEnvironment(int64_t n, int device = 0, bool autoReset = false, int maxSteps = 0, bool freshBoards = false,
+    // autoReset: POM_RESET_OFF (finished games stay finished), POM_RESET_AT_START (the next Step restarts and steps them) or
+    // POM_RESET_AT_END (the Step that finishes a game leaves the next game's start state behind: what agents are shown next
+    // is the state their move will be applied to; LastResults() has the finished game's outcome).
+    // freshBoards: a restarting game gets a newly drawn board (InitState's distribution, bboard.cpp:339-382, generated on the
+    // device; include/pom_boardgen.h) instead of replaying the one handed to MakeGame
+    explicit BatchEnvironment(int64_t n, int device = 0, int autoReset = POM_RESET_OFF, int maxSteps = 0, bool freshBoards = false,
                               uint64_t boardSeed = 0)
         : n_(n), states_(size_t(n))
     {
@@ -468,6 +471,14 @@ public:
         winner.resize(size_t(n_));
         draw.resize(size_t(n_));
         pom_check(pom_batch_status(h_, 0, n_, done.data(), winner.data(), draw.data(), nullptr, nullptr, nullptr));
+    }
+    // POM_RESET_AT_END: which games finished with the latest Step, and how (winner -1: nobody)
+    void LastResults(std::vector<int32_t>& finished, std::vector<int32_t>& winner, std::vector<int32_t>& draw)
+    {
+        finished.resize(size_t(n_));
+        winner.resize(size_t(n_));
+        draw.resize(size_t(n_));
+        pom_check(pom_batch_last_results(h_, 0, n_, finished.data(), winner.data(), draw.data(), nullptr, nullptr));
     }
     // Environment's per-game queries (bboard.hpp:597-636, environment.cpp:176-208) for game e; each call downloads what it
     // needs — game loops that look at every game should use GetStates() / Status() once per tick instead

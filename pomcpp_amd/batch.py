@@ -26,6 +26,7 @@ from .state import STATE_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 MODE_RAW, MODE_ENV = 0, 1
+RESET_OFF, RESET_AT_START, RESET_AT_END = 0, 1, 2  # PomBatchOptions.auto_reset (True = RESET_AT_START)
 DIST_HARMLESS, DIST_RANDOM, DIST_STRESS = 0, 1, 2
 CNT_STEPS, CNT_EPISODES, CNT_RESETS, CNT_UB_TICKS = 0, 1, 2, 3
 UB_LOST_AGENT, UB_NULL_BOMB, UB_QUEUE_OVERFLOW, UB_REVERT_LOOP, UB_BAD_INDEX = 1, 2, 4, 8, 16
@@ -95,6 +96,9 @@ def load_library() -> C.CDLL:
     lib.pom_batch_step_simple.argtypes = [P, U64, I32]
     lib.pom_batch_policy_memory.argtypes = [P, I64, I64, VP]
     lib.pom_batch_status.argtypes = [P, I64, I64, VP, VP, VP, VP, VP, VP]
+    if not os.environ.get("POM_LIB") or hasattr(lib, "pom_batch_last_results"):  # (POM_LIB: older experimental builds lack these)
+        lib.pom_batch_last_results.argtypes = [P, I64, I64, VP, VP, VP, VP, VP]
+        lib.pom_batch_download_terminal.argtypes = [P, VP, I64, I64]
     lib.pom_batch_counters.argtypes = [P, VP]
     lib.pom_batch_counters_device.argtypes = [P, VP]
     lib.pom_batch_reset_counters.argtypes = [P]
@@ -233,6 +237,22 @@ class BatchEnvironment:
         _check(self._lib, self._lib.pom_batch_status(self._h, first, count, *[a.ctypes.data for a in arrs]))
         out = dict(zip(names, arrs))
         out["ubflags"] = out["ubflags"].view(np.uint32)
+        return out
+
+    def last_results(self, first: int = 0, count: Optional[int] = None) -> dict:
+        """auto_reset=RESET_AT_END: `finished` = the env's latest tick ended an episode (it now stands on its next start state);
+        winner / draw / length / alive describe the env's most recently finished episode."""
+        count = self.n - first if count is None else count
+        names = ["finished", "winner", "draw", "length", "alive"]
+        arrs = [np.zeros(count, dtype=np.int32) for _ in names]
+        _check(self._lib, self._lib.pom_batch_last_results(self._h, first, count, *[a.ctypes.data for a in arrs]))
+        return dict(zip(names, arrs))
+
+    def get_terminal_state(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        """auto_reset=RESET_AT_END: the final State of each env's most recently finished episode (zeros: none yet)"""
+        count = self.n - first if count is None else count
+        out = np.zeros(count, dtype=STATE_DTYPE)
+        _check(self._lib, self._lib.pom_batch_download_terminal(self._h, out.ctypes.data, first, count))
         return out
 
     def is_done(self) -> np.ndarray:

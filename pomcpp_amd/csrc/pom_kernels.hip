@@ -111,6 +111,7 @@ struct StepParams {
     uint32_t tick0;
     int32_t dist, ticks, mode, auto_reset, max_steps;
     int64_t block0, block_end; /* this launch covers tiles block0 .. block_end - 1 (sub-batch of a split step) */
+    uint32_t* terminal;  /* auto_reset == POM_RESET_AT_END: the last finished episode's final record per env, array of structs */
     uint32_t* agent_mem; /* POLICY instantiation: SimpleAgent memory, [2][4 * n_pad] */
     uint32_t* episode;   /* games started so far per env (fresh boards: keys the next board) */
     uint64_t board_seed;
@@ -307,11 +308,12 @@ struct PolicyStore {
 /* POLICY: the moves are not read but decided here — lane m of an env's quad is agent m and runs SimpleAgent::act
  * (pom_policy_body.h) on the tile the tick is about to work on: Environment::Step with four SimpleAgents in ONE kernel, one
  * record load per tick instead of two and no Move[4] round trip (pom_batch_step_simple). */
-template <int EPW, int G, bool FRESH, bool POLICY = false>
+template <int EPW, int G, bool FRESH, bool POLICY = false, bool ATEND = false>
 __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW == 32 ? 2 : 1)) void pom_step_kernel(StepParams p)
 {
     static_assert(G == 1 || (G == 4 && EPW == 16), "a quad per env needs 16 envs per wavefront");
     static_assert(!POLICY || G == 4, "the policy runs one agent per lane of the quad");
+    static_assert(!ATEND || G == 4, "the end-of-tick reset is built for the quad shape only");
     /* POLICY: the danger map (32 rows of bytes) and the cell sets (12 rows) live where the tick keeps its bomb destinations
      * and explosion frames (26 rows) — the policy of a tick is over before its tick begins.  156 rows = 9,984 B: 16
      * wavefronts per CU, i.e. all of 65,536 envs resident at once. */
@@ -389,11 +391,13 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
 #endif
 
     for (int tk = 0; tk < p.ticks; tk++) {
-        if (FRESH) { /* a separate instantiation: the replay kernel carries none of this */
+        if (ATEND) {
+            /* POM_RESET_AT_END (a separate instantiation): nobody is finished when a tick begins; see the end of the tick */
+        } else if (FRESH) { /* a separate instantiation: the replay kernel carries none of this */
             /* fresh boards: a finished env starts its next game on the board (board_seed, env, games played) of
              * pom_boardgen.h, drawn into its tile column by the whole wavefront, one restarting env after the other —
              * the one place, first tick included */
-            const bool reload = e < p.n && env_mode && p.auto_reset && (status & POM_ST_DONE) && runs;
+            const bool reload = e < p.n && env_mode && p.auto_reset == POM_RESET_AT_START && (status & POM_ST_DONE) && runs;
             uint64_t todo = __ballot(reload && owner);
             while (todo) {
                 const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)todo) - 1); /* an owner lane */
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         } else {
             /* a finished env restarts from its snapshot (tick 0: as the record says; later ticks of a launch: as the epilogue
              * found), one restarting env after the other, by the whole wavefront */
-            const bool reload = e < p.n && env_mode && p.auto_reset && (status & POM_ST_DONE) && runs;
+            const bool reload = e < p.n && env_mode && p.auto_reset == POM_RESET_AT_START && (status & POM_ST_DONE) && runs;
             uint64_t todo = __ballot(reload && owner);
             if (todo) {
                 c_resets += __popcll(todo);
@@ -473,6 +477,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
             }
             const uint32_t ub_before = L.ub;
             L.ub = 0;
+            status &= ~(uint32_t)POM_ST_RESTARTED;
             if (POLICY) {
                 /* a fresh view of the tile for the tick: keeps the compiler from computing the tick's addresses before the
                  * policy and carrying them through it (the fused kernel otherwise wants 170 VGPRs) */
@@ -495,6 +500,57 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         c_steps += __popcll(__ballot(active && owner));
         c_episodes += __popcll(__ballot(newly_done && owner));
         c_ub += __popcll(__ballot(new_ub && owner));
+        if (ATEND) {
+            /* The tick that finishes an episode also starts the next one: the final record goes to the terminal buffer, the
+             * env's column is replaced by its start state (snapshot record, or the next generated board), the agents' memory
+             * is wiped.  What the caller reads next — state, observation, status — is the new episode's first state, marked
+             * POM_ST_RESTARTED; the move it then supplies is a move for THAT state. */
+            uint64_t todo = __ballot(newly_done && owner);
+            if (todo) {
+                c_resets += __popcll(todo);
+                if (newly_done && owner) { /* the register-resident rows of the final record */
+                    t[POM_REC_TIMESTEP * EPW] = (uint32_t)time_step;
+                    t[POM_REC_META * EPW] = pom_lane_meta(L);
+                    t[POM_REC_META2 * EPW] = pom_lane_meta2(L, status);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        t[(POM_REC_AGENTS + 2 * i) * EPW] = (uint32_t)L.a0[i];
+                        t[(POM_REC_AGENTS + 2 * i + 1) * EPW] = (uint32_t)L.a1[i];
+                    }
+                }
+                asm volatile("" ::: "memory");
+                do {
+                    const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)todo) - 1); /* an owner lane */
+                    todo &= todo - 1;
+                    const int ec_u = G == 1 ? src : src >> 2;
+                    const int64_t e_u = tile_id * EPW + ec_u;
+                    uint32_t* tr = p.terminal + e_u * POM_REC_DWORDS;
+                    tr[lane] = tile[lane * EPW + ec_u];
+                    if (lane + 64 < POM_REC_DWORDS) tr[lane + 64] = tile[(lane + 64) * EPW + ec_u];
+                    if (FRESH) {
+                        uint32_t ep = 0;
+                        if (lane == src) {
+                            ep = p.episode[e_u] + 1u;
+                            p.episode[e_u] = ep;
+                        }
+                        ep = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)ep, src));
+                        const uint32_t key = pom_board_key(p.board_seed, (uint32_t)(p.env_offset + e_u), ep);
+                        pom_boardgen_wave<EPW, POM_REC_DWORDS>(tile + ec_u, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), lane);
+                    } else {
+                        restart_column<EPW>(tile + ec_u, p.snap + e_u * POM_REC_DWORDS, lane);
+                    }
+                } while (todo);
+                asm volatile("" ::: "memory");
+                if (newly_done && runs) {
+                    lane_from_tile(L, time_step, status, t, EPW);
+                    status |= POM_ST_RESTARTED;
+                    if (POLICY) { /* a new game gets fresh agents */
+                        p.agent_mem[tile_id * 64 + lane] = 0u;
+                        p.agent_mem[4 * np + tile_id * 64 + lane] = 0u;
+                    }
+                }
+            }
+        }
         POM_STAMP(L, POM_PH_EPILOGUE);
     }
 
@@ -585,7 +641,7 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
     /* an env the tick is about to restart is judged on the board it will restart on: its snapshot record (array of structs,
      * fetched by the whole wavefront: restart_column) or, with fresh boards, the board the tick kernel is about to draw for it
      * (the tick counts the episode) */
-    const bool restart = e < p.n && env_mode && p.auto_reset && ((tile[POM_REC_META2 * 16 + ec] >> 8) & POM_ST_DONE);
+    const bool restart = e < p.n && env_mode && p.auto_reset == POM_RESET_AT_START && ((tile[POM_REC_META2 * 16 + ec] >> 8) & POM_ST_DONE);
     if (restart) m0 = m1 = 0; /* a new game gets fresh agents */
     {
         uint64_t todo = __ballot(restart && id == 0);
@@ -859,7 +915,8 @@ __global__ __launch_bounds__(64) void pom_observe_kernel(ObserveParams p)
     }
     if (lane < 16 && tile_id * 16 + lane < p.n && p.env_attrs) {
         const uint32_t m = tile[POM_REC_META * 16 + lane], st = (tile[POM_REC_META2 * 16 + lane] >> 8) & 0xFF;
-        const int status = (int)((st & POM_ST_DONE) ? 1 : 0) | (int)((st & POM_ST_DRAW) ? 2 : 0) | (int)((st & POM_ST_TIMEOUT) ? 4 : 0);
+        const int status = (int)((st & POM_ST_DONE) ? 1 : 0) | (int)((st & POM_ST_DRAW) ? 2 : 0) | (int)((st & POM_ST_TIMEOUT) ? 4 : 0) |
+                           (int)((st & POM_ST_RESTARTED) ? 8 : 0);
         reinterpret_cast<int4*>(p.env_attrs)[tile_id * 16 + lane] =
             make_int4((int)tile[POM_REC_TIMESTEP * 16 + lane], pom_sext8(m), status, (int)((st >> POM_ST_WINNER_SHIFT) & 7) - 1);
     }
@@ -941,6 +998,30 @@ __global__ void pom_status_kernel(const uint32_t* __restrict__ state, int64_t fi
     out[5 * count + i] = (int32_t)(m2 >> 16);
 }
 
+/* POM_RESET_AT_END: out = 5 arrays of `count` int32: finished (the state's "restarted" mark), then winner, draw, length, alive
+ * of the terminal record (array of structs; all-zero = no episode finished yet) */
+__global__ void pom_results_kernel(const uint32_t* __restrict__ state, const uint32_t* __restrict__ terminal, int64_t first, int64_t count,
+                                   int64_t np, int32_t* out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t now = (state[POM_REC_META2 * np + first + i] >> 8) & 0xFF;
+    const uint32_t* rec = terminal + (first + i) * POM_REC_DWORDS;
+    const uint32_t st = (rec[POM_REC_META2] >> 8) & 0xFF;
+    out[0 * count + i] = (now & POM_ST_RESTARTED) ? 1 : 0;
+    out[1 * count + i] = (int)((st >> POM_ST_WINNER_SHIFT) & 7) - 1;
+    out[2 * count + i] = (st & POM_ST_DRAW) ? 1 : 0;
+    out[3 * count + i] = (int32_t)rec[POM_REC_TIMESTEP];
+    out[4 * count + i] = (st & POM_ST_DONE) ? pom_sext8(rec[POM_REC_META]) : 0;
+}
+
+__global__ void pom_unpack_aos_kernel(const uint32_t* __restrict__ recs, int64_t first, int64_t count, int32_t* aos)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    pom_unpack_state(recs + (first + i) * POM_REC_DWORDS, 1, aos + i * (POM_STATE_BYTES / 4));
+}
+
 __global__ void pom_snapshot_kernel(const uint32_t* __restrict__ state, uint32_t* snap, int64_t np)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -992,7 +1073,8 @@ struct PomBatch {
     bool quad = false; /* EPW 16 with four lanes per env (pom_step_kernel<16, 4>) */
     int mode = POM_MODE_ENV, auto_reset = 0, max_steps = 0;
     uint32_t* state = nullptr;
-    uint32_t* snap = nullptr;
+    uint32_t* snap = nullptr;       /* restart snapshot, array of structs */
+    uint32_t* terminal = nullptr;   /* POM_RESET_AT_END: final record of each env's last finished episode, array of structs */
     int32_t* moves_dev = nullptr;   /* n_pad x 4 */
     uint32_t* agent_mem = nullptr;  /* SimpleAgent memory, [2][4 * n_pad], allocated on first use */
     uint32_t* episode = nullptr;    /* games started per env (fresh boards) */
@@ -1058,6 +1140,7 @@ int pom_batch_destroy(PomBatch* h)
         if (h->prof_ev[k]) (void)hipEventDestroy(h->prof_ev[k]);
     (void)hipFree(h->state);
     (void)hipFree(h->snap);
+    (void)hipFree(h->terminal);
     (void)hipFree(h->moves_dev);
     (void)hipFree(h->agent_mem);
     (void)hipFree(h->episode);
@@ -1089,6 +1172,10 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
     }
     if (o.mode != POM_MODE_RAW && o.mode != POM_MODE_ENV) {
         snprintf(g_err, sizeof g_err, "pom_batch_create: bad mode %d", o.mode);
+        return POM_E_ARG;
+    }
+    if (o.auto_reset < POM_RESET_OFF || o.auto_reset > POM_RESET_AT_END) {
+        snprintf(g_err, sizeof g_err, "pom_batch_create: auto_reset must be 0 (off), 1 (at the start of the next tick) or 2 (at the end of the tick)");
         return POM_E_ARG;
     }
     int ndev = 0;
@@ -1160,6 +1247,12 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
         if (v >= 1 && v <= PomBatch::MAX_PARTS) h->parts = v;
     }
     if ((int64_t)h->parts > h->n_pad / h->epw) h->parts = (int)(h->n_pad / h->epw);
+    if (o.auto_reset == POM_RESET_AT_END && !h->quad) {
+        snprintf(g_err, sizeof g_err, "pom_batch_create: auto_reset = POM_RESET_AT_END is built for the default kernel shape "
+                 "(envs_per_wave 16, lanes_per_env 4) only");
+        delete h;
+        return POM_E_ARG;
+    }
     h->mode = o.mode;
     h->auto_reset = o.auto_reset;
     h->max_steps = o.max_steps;
@@ -1200,6 +1293,7 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
     ALLOC(h->totals_dev, POM_CNT_N * 8);
     ALLOC(h->first_bad, sizeof(int));
     ALLOC(h->episode, (size_t)h->n_pad * 4);
+    if (h->auto_reset == POM_RESET_AT_END) ALLOC(h->terminal, rec_bytes);
 #undef ALLOC
     /* all-zero records are inert blank boards; padded envs are marked finished */
     hipError_t e1 = hipMemsetAsync(h->state, 0, rec_bytes, h->stream);
@@ -1207,6 +1301,7 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
     hipError_t e3 = hipMemsetAsync(h->moves_dev, 0, (size_t)h->n_pad * 16, h->stream);
     hipError_t e4 = hipMemsetAsync(h->wave_counters, 0, (size_t)h->n_waves * POM_CNT_N * 8, h->stream);
     if (e4 == hipSuccess) e4 = hipMemsetAsync(h->episode, 0, (size_t)h->n_pad * 4, h->stream);
+    if (e4 == hipSuccess && h->terminal) e4 = hipMemsetAsync(h->terminal, 0, rec_bytes, h->stream);
     hipError_t e5 = hipStreamSynchronize(h->stream);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
         set_err("initial memset", e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4 != hipSuccess ? e4 : e5);
@@ -1253,6 +1348,7 @@ int pom_batch_upload(PomBatch* h, const void* states, int64_t first, int64_t cou
         }
     }
     HIPCHK(hipMemsetAsync(h->episode + first, 0, (size_t)count * 4, h->stream)); /* an uploaded state is episode 0 of its env */
+    if (h->terminal) HIPCHK(hipMemsetAsync(h->terminal + first * POM_REC_DWORDS, 0, (size_t)count * POM_REC_DWORDS * 4, h->stream));
     if (h->agent_mem) { /* uploaded envs start new games: fresh agents */
         HIPCHK(hipMemsetAsync(h->agent_mem + first * 4, 0, (size_t)count * 16, h->stream));
         HIPCHK(hipMemsetAsync(h->agent_mem + 4 * h->n_pad + first * 4, 0, (size_t)count * 16, h->stream));
@@ -1344,6 +1440,7 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
     p.agent_mem = h->agent_mem;
     p.state = h->state;
     p.snap = h->snap;
+    p.terminal = h->terminal;
     p.moves = moves_dev;
     p.wave_counters = h->wave_counters;
     p.n = h->n;
@@ -1385,13 +1482,18 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
 #define POM_LAUNCH(E, G) \
     (fresh ? hipExtLaunchKernelGGL((pom_step_kernel<E, G, true>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p) \
            : hipExtLaunchKernelGGL((pom_step_kernel<E, G, false>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p))
-        if (policy) { /* the caller checked h->quad */
-            fresh ? hipExtLaunchKernelGGL((pom_step_kernel<16, 4, true, true>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p)
-                  : hipExtLaunchKernelGGL((pom_step_kernel<16, 4, false, true>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p);
+#define POM_LAUNCH_Q(F, P, A) hipExtLaunchKernelGGL((pom_step_kernel<16, 4, F, P, A>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p)
+        const bool at_end = h->auto_reset == POM_RESET_AT_END && h->mode == POM_MODE_ENV; /* quad shape only: checked at creation */
+        if (at_end) {
+            if (policy) fresh ? POM_LAUNCH_Q(true, true, true) : POM_LAUNCH_Q(false, true, true);
+            else fresh ? POM_LAUNCH_Q(true, false, true) : POM_LAUNCH_Q(false, false, true);
+        } else if (policy) { /* the caller checked h->quad */
+            fresh ? POM_LAUNCH_Q(true, true, false) : POM_LAUNCH_Q(false, true, false);
         } else if (h->epw == 64) POM_LAUNCH(64, 1);
         else if (h->epw == 32) POM_LAUNCH(32, 1);
         else if (h->quad) POM_LAUNCH(16, 4);
         else POM_LAUNCH(16, 1);
+#undef POM_LAUNCH_Q
 #undef POM_LAUNCH
         HIPCHK(hipGetLastError());
         if (prof) h->prof_n++;
@@ -1454,6 +1556,53 @@ int pom_batch_status(PomBatch* h, int64_t first, int64_t count, int32_t* done, i
         for (int k = 0; k < 6; k++)
             if (outs[k])
                 HIPCHK(hipMemcpyAsync((int32_t*)outs[k] + off, h->staging + (int64_t)k * c, (size_t)c * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return POM_OK;
+}
+
+int pom_batch_last_results(PomBatch* h, int64_t first, int64_t count, int32_t* finished, int32_t* winner, int32_t* draw,
+                           int32_t* length, int32_t* alive)
+{
+    int rc = check_range(h, first, count);
+    if (rc) return rc;
+    if (!h->terminal) {
+        snprintf(g_err, sizeof g_err, "pom_batch_last_results: the batch was not created with auto_reset = POM_RESET_AT_END");
+        return POM_E_ARG;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
+    void* outs[5] = {finished, winner, draw, length, alive};
+    for (int64_t off = 0; off < count; off += h->staging_envs) {
+        const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
+        pom_results_kernel<<<dim3((unsigned)((c + 255) / 256)), dim3(256), 0, h->stream>>>(h->state, h->terminal, first + off, c, h->n_pad,
+                                                                                            h->staging);
+        HIPCHK(hipGetLastError());
+        for (int k = 0; k < 5; k++)
+            if (outs[k])
+                HIPCHK(hipMemcpyAsync((int32_t*)outs[k] + off, h->staging + (int64_t)k * c, (size_t)c * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return POM_OK;
+}
+
+int pom_batch_download_terminal(PomBatch* h, void* states, int64_t first, int64_t count)
+{
+    int rc = check_range(h, first, count);
+    if (rc || !states) return rc ? rc : POM_E_ARG;
+    if (!h->terminal) {
+        snprintf(g_err, sizeof g_err, "pom_batch_download_terminal: the batch was not created with auto_reset = POM_RESET_AT_END");
+        return POM_E_ARG;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    if (int jr = join_parts(h)) return jr;
+    for (int64_t off = 0; off < count; off += h->staging_envs) {
+        const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
+        HIPCHK(hipMemsetAsync(h->staging, 0, (size_t)c * POM_STATE_BYTES, h->stream));
+        pom_unpack_aos_kernel<<<dim3((unsigned)((c + 63) / 64)), dim3(64), 0, h->stream>>>(h->terminal, first + off, c, h->staging);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync((char*)states + off * POM_STATE_BYTES, h->staging, (size_t)c * POM_STATE_BYTES, hipMemcpyDeviceToHost,
+                              h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return POM_OK;
@@ -1535,6 +1684,7 @@ int pom_batch_generate(PomBatch* h, uint64_t board_seed)
                                                                                          h->env_offset, board_seed);
     HIPCHK(hipGetLastError());
     if (h->agent_mem) HIPCHK(hipMemsetAsync(h->agent_mem, 0, (size_t)h->n_pad * 32, h->stream)); /* new games: fresh agents */
+    if (h->terminal) HIPCHK(hipMemsetAsync(h->terminal, 0, (size_t)h->n_pad * POM_REC_DWORDS * 4, h->stream));
     return POM_OK;
 }
 

@@ -49,7 +49,9 @@ enum {
     POM_ST_DONE = 1,     /* Environment::finished, environment.cpp:152-168 */
     POM_ST_DRAW = 2,     /* Environment::isDraw */
     POM_ST_WINNER_SHIFT = 2, /* 3 bits: agentWon + 1 (0 = nobody) */
-    POM_ST_TIMEOUT = 32  /* timeStep reached max_steps (StartGame's loop bound, environment.cpp:71) */
+    POM_ST_TIMEOUT = 32, /* timeStep reached max_steps (StartGame's loop bound, environment.cpp:71) */
+    POM_ST_RESTARTED = 64 /* auto_reset at the end of the tick (POM_RESET_AT_END): the previous tick finished this env's episode and
+                             put it on its next start state; the finished episode's record is in the terminal buffer */
 };
 
 enum { POM_C_PASSAGE = 0, POM_C_RIGID = 1, POM_C_BOMB = 3, POM_C_FLAME = 0x4000, POM_C_AGENT = 0x8000 };
