@@ -239,7 +239,11 @@ def parse_args(argv=None):
                     help="random: Move[4] from the counter stream (--dist); simple: the device SimpleAgent policy (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config3", action="store_true", help="skip the other-config segments (profiling runs: one kernel shape only)")
-    ap.add_argument("--streams", type=int, default=0, help="sub-batches per step (0 = measured in an untimed tuning pass)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="sub-batches per step (0 = the library's default on one GPU; with several ranks, measured in an untimed pass)")
+    ap.add_argument("--burn-in", type=int, default=300,
+                    help="untimed ticks played before the warm-up so that the batch is a steady mix of openings, mid-games and restarts "
+                         "(all games start at tick 0 together: nothing explodes before tick 10 and the first deaths come in waves)")
     ap.add_argument("--fresh-boards", action="store_true",
                     help="boards drawn on the device (pom_batch_generate) and a new one per episode instead of the snapshot replay "
                          "BASELINE's configs prescribe (SURVEY §8 f3)")
@@ -321,11 +325,17 @@ def worker(args) -> None:
     else:
         def run_steps(k: int) -> None:
             env.step_random(args.seed, dist_id, ticks=k * tpl, ticks_per_launch=tpl)
+    # Input preparation, untimed: play the fresh games forward until the batch is a steady mix of game phases.  (The step time is
+    # flat from tick ~100 on, scripts/phase_drift.py; the first ticks of 65,536 synchronised openings are much cheaper.)
+    if args.burn_in > 0:
+        run_steps(args.burn_in)
+        env.sync()
     tuned, tuning_steps = None, 0
-    if args.streams == 0:
+    if args.streams == 0 and world > 1:
         # Untimed: how many sub-batches per step?  More parts overlap more load/store with compute, but ROCm maps all streams
         # of the process onto 4 hardware queues and parts that share a queue serialize (profiles/r01_streams.txt) — how many
-        # are free depends on the process (torch, RCCL), so measure instead of guessing.  Results do not depend on the choice.
+        # are free depends on the process (torch, RCCL's streams), so with a communicator in the process measure instead of
+        # guessing.  A single-GPU run uses the library's default (3 from 49,152 envs up).  Results do not depend on the choice.
         tuned = {}
         for k in (3, 2, 1):  # first touch of a sub-stream creates its hardware queue (~10 ms once): keep that out of the timings
             env.set_streams(k)
@@ -345,18 +355,16 @@ def worker(args) -> None:
                 best_k = dt if best_k is None else min(best_k, dt)
                 tuning_steps += 50
             tuned[k] = best_k
-        best = min(tuned, key=tuned.get)
-        if world > 1:  # every rank must run the same shape: take the vote of the slowest rank's best
-            votes = torch.tensor([tuned[1], tuned[2], tuned[3]], dtype=torch.float64, device=device)
-            _all_reduce(votes, dist.ReduceOp.MAX, dist)
-            best = int(torch.argmin(votes).item()) + 1
-        env.set_streams(best)
+        votes = torch.tensor([tuned[1], tuned[2], tuned[3]], dtype=torch.float64, device=device)
+        _all_reduce(votes, dist.ReduceOp.MAX, dist)  # every rank must run the same shape: the slowest rank's best
+        env.set_streams(int(torch.argmin(votes).item()) + 1)
     run_steps(args.warmup)
     env.counters_into(counters.data_ptr())
     reduce_counters(counters, dist)  # warm the RCCL communicator outside the timed region
     env.reset_counters()
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    env.fork()  # the sub-streams are ordered behind the setup above now, not inside the timed region
     barrier()
     t0 = time.perf_counter()
     ev0.record(stream)
@@ -410,7 +418,7 @@ def worker(args) -> None:
             e2 = BatchEnvironment(n_o, device=local_rank, mode=MODE_ENV, auto_reset=True, max_steps=args.max_steps,
                                   stream=stream.cuda_stream)
             e2.make_game(pa.make_boards(n_o, seed=args.seed * 1000003, kind=kind_o))
-            e2.step_random(args.seed, dist_o, ticks=60)
+            e2.step_random(args.seed, dist_o, ticks=300)
             e2.sync()
             ev4, ev5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             n_o_steps = 200
@@ -422,25 +430,31 @@ def worker(args) -> None:
             ms_o = ev4.elapsed_time(ev5) / n_o_steps
             other[name] = {"value": n_o / (ms_o * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_o, "steps": n_o_steps}
             e2.close()
-        # explicit moves from device memory: 8 pre-drawn Move[4] arrays cycled, one pom_batch_step_device per tick
+        # explicit moves from device memory, as an RL loop steps: auto_reset = RESET_AT_END (what is observed is what the next move
+        # applies to), 8 pre-drawn Move[4] arrays cycled, one pom_batch_step_device per tick (one launch, joined with the
+        # caller's stream every tick)
+        from pomcpp_amd.batch import RESET_AT_END
         gen = torch.Generator(device=device).manual_seed(args.seed)
         mv_dev = torch.randint(0, 6, (8, plan["n_envs"], 4), dtype=torch.int32, device=device, generator=gen)
-        env.make_game(start)
+        e3 = BatchEnvironment(plan["n_envs"], device=local_rank, mode=MODE_ENV, auto_reset=RESET_AT_END, max_steps=args.max_steps,
+                              stream=stream.cuda_stream)
+        e3.make_game(start)
         torch.cuda.synchronize()
-        for t in range(40):
-            env.step_device(mv_dev[t % 8].data_ptr())
-        env.sync()
+        for t in range(300):
+            e3.step_device(mv_dev[t % 8].data_ptr())
+        e3.sync()
         ev6, ev7 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n_x = 200
         ev6.record(stream)
         for t in range(n_x):
-            env.step_device(mv_dev[t % 8].data_ptr())
+            e3.step_device(mv_dev[t % 8].data_ptr())
         ev7.record(stream)
-        env.sync()
+        e3.sync()
         ms_x = ev6.elapsed_time(ev7) / n_x
+        e3.close()
         other["explicit_moves_device_65536_envs"] = {
             "value": plan["n_envs"] / (ms_x * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_x, "steps": n_x,
-            "note": "pom_batch_step_device: Move[4] from device memory, sub-batches joined with the caller's stream every tick"}
+            "note": "pom_batch_step_device with auto_reset = POM_RESET_AT_END: Move[4] from device memory, one launch per tick on the caller's stream"}
     total_steps = int(counters[CNT_STEPS].item())
     expect = plan["global_envs"] * args.steps * tpl
     if total_steps != expect:
@@ -476,7 +490,7 @@ def worker(args) -> None:
                 "policy": args.policy,
                 "envs_per_gpu": args.envs, "global_envs": plan["global_envs"], "ticks_per_launch": tpl,
                 "envs_per_wave": epw, "lanes_per_env": lpe, "launches_per_step": parts,
-                "launches_per_step_tuning_ms": tuned, "untimed_tuning_steps": tuning_steps,
+                "burn_in_ticks": args.burn_in, "launches_per_step_tuning_ms": tuned, "untimed_tuning_steps": tuning_steps,
                 "parallelism": f"env-shard x{world}", "ranks": world, "collective_backend": backend,
                 "rccl_ranks": dist.get_world_size() if world > 1 else 1,
                 "episodes_finished": int(counters[1].item()),

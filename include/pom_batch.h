@@ -148,6 +148,10 @@ int pom_batch_sync(PomBatch* h);
 /* order everything stepped so far before whatever is queued next on the handle's stream, without blocking the host
  * (steps run on internal sub-streams; every other call of this API does this implicitly) */
 int pom_batch_flush(PomBatch* h);
+/* the opposite, ahead of time: order the internal sub-streams behind what is queued on the handle's stream NOW, so that the
+ * next step's launches need no cross-stream event first (a latency-sensitive caller does this before it starts its clock;
+ * stepping does it by itself otherwise) */
+int pom_batch_fork(PomBatch* h);
 /* change the number of sub-batches a step is issued as (1..8, see PomBatchOptions.streams); results do not depend on it,
  * the best value depends on how many hardware queues the process has free — a caller may try a few and keep the fastest */
 int pom_batch_set_streams(PomBatch* h, int32_t streams);

@@ -104,6 +104,8 @@ def load_library() -> C.CDLL:
     lib.pom_batch_reset_counters.argtypes = [P]
     lib.pom_batch_sync.argtypes = [P]
     lib.pom_batch_flush.argtypes = [P]
+    if not os.environ.get("POM_LIB") or hasattr(lib, "pom_batch_fork"):
+        lib.pom_batch_fork.argtypes = [P]
     lib.pom_batch_set_streams.argtypes = [P, I32]
     lib.pom_batch_profile.argtypes = [P, C.c_int]
     lib.pom_batch_profile_read.argtypes = [P, C.POINTER(C.c_double), C.POINTER(I64)]
@@ -336,6 +338,10 @@ class BatchEnvironment:
     def flush(self) -> None:
         """Make the handle's stream wait for all steps issued so far (host does not block)."""
         _check(self._lib, self._lib.pom_batch_flush(self._h))
+
+    def fork(self) -> None:
+        """Order the internal sub-streams behind the handle's stream now (the next step then needs no cross-stream event first)."""
+        _check(self._lib, self._lib.pom_batch_fork(self._h))
 
     def set_streams(self, streams: int) -> None:
         _check(self._lib, self._lib.pom_batch_set_streams(self._h, streams))

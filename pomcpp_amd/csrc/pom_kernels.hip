@@ -1903,6 +1903,13 @@ int pom_batch_policy_memory(PomBatch* h, int64_t first, int64_t count, int32_t* 
     return POM_OK;
 }
 
+int pom_batch_fork(PomBatch* h)
+{
+    if (!h) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    return fork_parts(h);
+}
+
 int pom_batch_flush(PomBatch* h)
 {
     if (!h) return POM_E_ARG;
