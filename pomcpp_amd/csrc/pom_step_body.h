@@ -1217,36 +1217,45 @@ struct PomStepper {
             POM_NOUNROLL
             for (int k = 0; k < L.bCnt; k++) {
                 int b = bomb_at(k);
-                if (pb_dir(b) == 0) {
-                    if (bomb_collision(mvp, k)) continue;
-                }
                 const int bx = pb_x(b), by = pb_y(b), d = pb_dir(b);
-                const int tx = bx + mv_dx(d), ty = by + mv_dy(d);
-                int free_way = !oob(tx, ty);
-                int tc = 0, te = 0;
-                if (free_way) {
-                    tc = ty * POM_N + tx;
-                    te = a.cell(tc);
-                    free_way = !pc_is_static_block(te);
-                }
-                if (free_way) {
-                    if (d != 0 && bomb_collision(mvp, k)) continue; /* an idle bomb was tested above; nothing changed since */
+                int tx = bx, ty = by; /* where a flame may set a bomb off at the end of this iteration */
+                if (d == 0) {
+                    if (bomb_collision(mvp, k)) continue;
+                    /* A resting bomb "moves" onto its own cell (step.cpp:243-272 with target == position): its word does not
+                     * change, its old cell still holds a bomb (itself), so all that is left is the cell test — PASSAGE becomes
+                     * BOMB, a flame sets off the first bomb queued on the cell (GetBombIndex: possibly an earlier one, SURVEY
+                     * Q8); a static item there makes the reference set the already resting bomb to rest. */
+                    const int c = by * POM_N + bx;
+                    const int e = a.cell(c);
+                    if (e == POM_C_PASSAGE) a.set_cell(c, POM_C_BOMB);
+                    if (!pc_is_flame(e)) continue;
+                } else {
+                    tx = bx + mv_dx(d);
+                    ty = by + mv_dy(d);
+                    int free_way = !oob(tx, ty);
+                    int tc = 0, te = 0;
+                    if (free_way) {
+                        tc = ty * POM_N + tx;
+                        te = a.cell(tc);
+                        free_way = !pc_is_static_block(te);
+                    }
+                    if (!free_way) {
+                        set_bomb_at(k, pb_set(b, 0xF00000u, 0));
+                        continue;
+                    }
+                    if (bomb_collision(mvp, k)) continue;
                     b = bomb_at(k);
                     set_bomb_at(k, pb_set(b, 0xFFu, (uint32_t)tx + ((uint32_t)ty << 4)));
                     if (bomb_index(bx | (by << 4)) < 0 && a.cell(by * POM_N + bx) == POM_C_BOMB)
                         a.set_cell(by * POM_N + bx, POM_C_PASSAGE);
                     te = a.cell(tc);
-                    if (pc_is_walkable(te)) {
-                        a.set_cell(tc, POM_C_BOMB);
-                    } else if (pc_is_flame(te)) {
-                        /* ExplodeBombAt(GetBombIndex(target)), bboard.cpp:111-118 */
-                        const int j = bomb_index(tx | (ty << 4));
-                        const int jb = bomb_at(j);
-                        explode(pb_x(jb), pb_y(jb), owner_strength(jb), j);
-                    }
-                } else {
-                    set_bomb_at(k, pb_set(b, 0xF00000u, 0));
+                    if (pc_is_walkable(te)) a.set_cell(tc, POM_C_BOMB);
+                    if (!pc_is_flame(te)) continue;
                 }
+                /* ExplodeBombAt(GetBombIndex(target)), bboard.cpp:111-118 */
+                const int j = bomb_index(tx | (ty << 4));
+                const int jb = bomb_at(j);
+                explode(pb_x(jb), pb_y(jb), owner_strength(jb), j);
             }
             POM_STAMP(L, POM_PH_BOMB_B);
             /* TickBombs, step_utility.cpp:224-245, first half: the timers were decremented in the pass above, except the marked
