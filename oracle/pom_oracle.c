@@ -343,6 +343,13 @@ static void chain_reversion(PomState *s, const int32_t *moves, const Pos *dest_b
                 s->board[ob.y][ob.x] = POM_AGENT0 + agent_id;
                 return;
             }
+            if (oob(ob.x, ob.y)) {
+                /* The bomb would be put back onto a cell outside the board: the reference writes board[y][-1] & co. there
+                 * (step_utility.cpp:107-111 has no bounds test) — undefined behaviour, on this toolchain a write into the
+                 * neighbouring row.  Defined fallback, as on the device: flag the tick, leave the bomb where it is. */
+                *ub |= POM_UB_BAD_INDEX;
+                return;
+            }
             int has_agent = get_agent(s, ob.x, ob.y);
             *b = set_field(*b, 0xF00000u, 0);
             *b = set_field(*b, 0xFFu, (unsigned)ob.x + ((unsigned)ob.y << 4));

@@ -571,8 +571,20 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
 #if defined(POM_DIAG)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     POM_STAMP(L, POM_PH_STORE);
-    if (lane == 0 && p.diag) /* one slot per wavefront: no contended atomics that would distort the timing */
-        for (int k = 0; k < POM_PH_N; k++) p.diag[tile_id * POM_PH_N + k] += L.t_acc[k];
+    if (p.diag) { /* one slot per wavefront: no contended atomics that would distort the timing.  Phases entered by some envs
+                     only (the blast engines) are booked by the lanes inside; everybody else books the same time on the phase
+                     around them — so the wavefront reports the lane that spent the most time inside */
+        long long inside = 0;
+        for (int k = POM_PH_X_SCAN; k < POM_PH_N; k++) inside += L.t_acc[k];
+        long long best = inside;
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long w = __shfl_xor(best, o);
+            best = w > best ? w : best;
+        }
+        const uint64_t who = __ballot(inside == best);
+        if (lane == __ffsll((unsigned long long)who) - 1)
+            for (int k = 0; k < POM_PH_N; k++) p.diag[tile_id * POM_PH_N + k] += L.t_acc[k];
+    }
 #endif
     if (lane == 0) {
         /* each wavefront owns its slot, so nothing contends; the adds are returnless atomics only because those are

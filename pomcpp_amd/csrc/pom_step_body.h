@@ -68,7 +68,8 @@
 #define POM_STAMP(L, k) ((void)0)
 #endif
 enum { POM_PH_LOAD = 0, POM_PH_FLAMES, POM_PH_AGENT_PREP, POM_PH_AGENT_LOOP, POM_PH_BOMB_PASS, POM_PH_BOMB_A, POM_PH_BOMB_B,
-       POM_PH_TICK_BOMBS, POM_PH_EPILOGUE, POM_PH_STORE, POM_PH_N };
+       POM_PH_TICK_BOMBS, POM_PH_EPILOGUE, POM_PH_STORE,
+       POM_PH_X_SCAN, POM_PH_X_COMMIT, POM_PH_X_EPILOGUE, POM_PH_X_NEST, POM_PH_X_SHORT, POM_PH_N }; /* X_*: inside explode_long / explode (their time is NOT in the phase that called them) */
 
 struct PomLane { /* the register-resident part of one env */
     int a0[4];   /* x:8 | y:8 | bombCount:8 | canKick@24 | dead@25 — only ever indexed statically */
@@ -303,6 +304,7 @@ struct PomStepper {
     POM_HD void explode(int x, int y, int strength, int rem, int top_word = -1)
     {
         int s = strength < 0 ? 0 : strength > POM_N ? POM_N : strength;
+        POM_STAMP(L, POM_PH_TICK_BOMBS); /* diagnostic builds: what ran before the blast is booked on the phase of the top explosions */
         if (s > 2) { /* a long blast: no look-ahead, the segment engine takes ray after ray (explode_long) */
             explode_long(x, y, strength, rem);
             return;
@@ -422,126 +424,201 @@ struct PomStepper {
         }
     }
 
+    /* The cells on which a queued bomb sits, as a 121-bit set in four words (bit c = y * 11 + x): one look at every queue slot,
+     * the lanes of the group each taking a quarter of them.  Replicated result. */
+    POM_HD void bomb_cells(uint32_t occ[4]) const
+    {
+        occ[0] = occ[1] = occ[2] = occ[3] = 0u;
+        constexpr int NS = POM_Q / A::G; /* slots per lane */
+        int w[NS];
+#pragma unroll
+        for (int q = 0; q < NS; q++) w[q] = bomb_at(a.sub() + q * A::G); /* offsets past the count read stale slots: filtered below */
+#pragma unroll
+        for (int q = 0; q < NS; q++) {
+            const int k = a.sub() + q * A::G;
+            const int idx = pb_y(w[q]) * POM_N + pb_x(w[q]);
+            const uint32_t m = (k < L.bCnt && idx < POM_CELLS) ? 1u << (idx & 31) : 0u;
+            const int wd = idx >> 5;
+            occ[0] |= wd == 0 ? m : 0u;
+            occ[1] |= wd == 1 ? m : 0u;
+            occ[2] |= wd == 2 ? m : 0u;
+            occ[3] |= wd == 3 ? m : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) occ[k] = (uint32_t)a.gor((int)occ[k]);
+    }
+    POM_HD static int cell_in(const uint32_t occ[4], int c)
+    {
+        const int w = c >> 5;
+        const uint32_t v = w == 0 ? occ[0] : w == 1 ? occ[1] : w == 2 ? occ[2] : occ[3];
+        return (int)((v >> (c & 31)) & 1u);
+    }
+    /* first queue offset whose bomb sits on pos, or -1 — bomb_index() with every lane's slots fetched at once */
+    POM_HD int bomb_index_wide(int pos) const
+    {
+        constexpr int NS = POM_Q / A::G;
+        int w[NS];
+#pragma unroll
+        for (int q = 0; q < NS; q++) w[q] = bomb_at(a.sub() + q * A::G);
+        int r = 99;
+#pragma unroll
+        for (int q = NS - 1; q >= 0; q--) {
+            const int k = a.sub() + q * A::G;
+            r = (k < L.bCnt && pb_pos(w[q]) == pos) ? k : r;
+        }
+        r = a.gmin(r);
+        return r == 99 ? -1 : r;
+    }
+
+    /* One ray of a blast, read-only: from distance `start` to `lim`, four cells per LDS round trip.  Reports how far the
+     * flame gets (`len`: the last cell that takes it, start - 1 if none), the flag of the wood it ends on (`ends`, with
+     * `wood` set), the agents it kills on the way (`vict`), and — instead of going on — the first BOMB / agent cell that is in
+     * `occ`, the cells with a queued bomb (`chain`: its distance, 0 = none; `info`: agent there | his id << 1):
+     * SpawnFlameItem, bboard.cpp:24-57, without its writes. */
+    POM_HD void scan_ray(int c0, int r, int start, int lim, const uint32_t occ[4], int& len, int& ends, int& wood, int& vict, int& chain,
+                         int& info)
+    {
+        len = start - 1;
+        ends = wood = vict = chain = info = 0;
+        int open = 1;
+        POM_NOUNROLL
+        for (int i0 = start; open && i0 <= lim; i0 += 4) {
+            int eb[4], cb[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                cb[q] = ray_cell(c0, r, i0 + q <= lim ? i0 + q : lim); /* clamped: stays on the ray */
+                eb[q] = a.cell(cb[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = i0 + q, e = eb[q];
+                if (open && i <= lim) {
+                    if ((e == POM_C_BOMB || pc_is_agent(e)) && cell_in(occ, cb[q])) {
+                        chain = i;
+                        info = pc_is_agent(e) | ((e & 3) << 1);
+                        open = 0;
+                    } else if (e == POM_C_RIGID) {
+                        open = 0;
+                    } else {
+                        if (pc_is_agent(e)) vict |= 1 << (e & 3); /* killed, the ray goes on (bboard.cpp:26-29) */
+                        len = i;
+                        if (pc_is_wood(e)) {
+                            ends = e & 3;
+                            wood = 1;
+                            open = 0;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
     /* Long blasts (strength > 2: power-ups collected, the stress boards).  SpawnFlame's recursion (bboard.cpp:24-57,111-118,
-     * 198-263) as a loop over ray SEGMENTS, without the look-ahead of explode(): with long rays and many bombs most blasts
-     * meet a bomb anyway.  The lanes of the group take the next cells of the current ray, one cell each (lane j: distance
-     * i + j; with one lane per env the same code walks the four cells itself).  The first cell — in ray order — at which
-     * something happens decides: a rigid cell or the end of the ray stops it before, wood stops it after, a queued bomb
-     * under a BOMB / agent item starts the nested explosion (the frame is suspended, bboard.cpp:30-40).  The cells before
-     * that one are ordinary: their agents die, they take the flame, independently of each other, so they are written in
-     * parallel.  After a nested explosion the ray is picked up at the cell that triggered it (SpawnFlameItem's tail,
-     * bboard.cpp:42-56) and everything beyond is read afresh — the nested chain may have changed it.  Nested blasts of any
-     * strength stay in this loop (the literal engine of explode() likewise keeps the long blasts nested in a short one). */
+     * 198-263) as a loop of LOOK and COMMIT over all four rays at once, lane r of the group taking ray r (with one lane per
+     * env the same code takes them in turn).  Look (scan_ray, read-only): every ray from where it stands to its end, or to the
+     * first cell with a queued bomb under a BOMB / agent item.  The rays are independent of each other except through such a
+     * bomb — its nested explosion may change anything — so the FIRST ray (in the reference's order +x, -x, +y, -y) that meets
+     * one decides: the rays before it are written in full, that ray up to the bomb's cell, the rays after it are forgotten
+     * and looked at again after the nested explosion has returned (frame suspended on the stack, bboard.cpp:30-40; picked up
+     * at SpawnFlameItem's tail, bboard.cpp:42-56).  Without such a bomb a whole blast is one look and one commit.
+     * "A queued bomb under the item" is answered from a set of bomb cells built once per call (bomb_cells); explosions only
+     * remove bombs, so the set can only be too large, and the one cell a look settles on is checked against the queue itself
+     * (which also yields the bomb's index): a cell found empty there is struck from the set and the look repeated. */
     POM_HD void explode_long(int x, int y, int strength, int rem)
     {
         int s = strength < 0 ? 0 : strength > POM_N ? POM_N : strength;
+        POM_STAMP(L, POM_PH_TICK_BOMBS);
         flame_prologue(x, y, strength);
-        int dir = 0, i = 1, sp = 0, resume = 0;
-        constexpr int NJ = 4 / A::G;
+        int dir = 0, i = 1, sp = 0; /* the rays before `dir` are done, ray `dir` goes on at distance i, the others start at 1 */
+        constexpr int NR = 4 / A::G;
+        uint32_t occ[4];
+        bomb_cells(occ);
         POM_NOUNROLL
         for (;;) {
-            if (!resume) { /* skip exhausted rays: length s or the board edge, whichever is nearer */
-                POM_NOUNROLL
-                for (; dir < 4; dir++, i = 1) {
-                    if (i <= ray_room(x, y, s, dir)) break;
+            const int c0 = y * POM_N + x;
+            int rs[NR], rlen[NR], rends[NR], rwood[NR], rvict[NR];
+            int first = 0x7FFFFFFF; /* ray << 16 | distance << 12 | info of the first bomb cell met, smallest ray wins */
+#pragma unroll
+            for (int q = 0; q < NR; q++) {
+                const int r = a.sub() + q * A::G;
+                rs[q] = r == dir ? i : 1;
+                int chain = 0, info = 0;
+                rlen[q] = rs[q] - 1;
+                rends[q] = rwood[q] = rvict[q] = 0;
+                if (r >= dir) scan_ray(c0, r, rs[q], ray_room(x, y, s, r), occ, rlen[q], rends[q], rwood[q], rvict[q], chain, info);
+                const int key = (r << 16) | (chain << 12) | info;
+                first = (chain != 0 && key < first) ? key : first;
+            }
+            first = a.gmin(first);
+            const int rstar = first == 0x7FFFFFFF ? 4 : first >> 16;
+            int jq = -1;
+            if (rstar < 4) { /* the cell the look settled on: which bomb is it? */
+                const int c = ray_cell(c0, rstar, (first >> 12) & 0xF);
+                const int cy = c / POM_N;
+                jq = bomb_index_wide((c - cy * POM_N) | (cy << 4));
+                if (jq < 0) { /* none any more (the set is only ever too large): strike the cell and look again */
+                    const uint32_t m = ~(1u << (c & 31));
+                    const int w = c >> 5;
+                    occ[0] &= w == 0 ? m : ~0u; occ[1] &= w == 1 ? m : ~0u; occ[2] &= w == 2 ? m : ~0u; occ[3] &= w == 3 ? m : ~0u;
+                    continue;
                 }
             }
-            if (dir >= 4) { /* all four rays done: the caller's bookkeeping, then back into the parent */
+            POM_STAMP(L, POM_PH_X_SCAN);
+            int victims = 0;
+#pragma unroll
+            for (int q = 0; q < NR; q++) { /* commit: rays dir .. rstar */
+                const int r = a.sub() + q * A::G;
+                if (r >= dir && r <= rstar) {
+                    /* ray rstar stopped its look AT the bomb's cell, so its len / vict cover exactly the cells before it */
+                    victims |= rvict[q];
+                    POM_NOUNROLL
+                    for (int d = rs[q]; d <= rlen[q]; d++)
+                        a.put_cell(ray_cell(c0, r, d), POM_C_FLAME | ((c0 << 3) + ((rwood[q] && d == rlen[q]) ? rends[q] : 0)));
+                }
+            }
+            kill_set(a.gor(victims));
+            POM_STAMP(L, POM_PH_X_COMMIT);
+            if (rstar == 4) { /* the blast is complete: the caller's bookkeeping, then back into the parent */
                 explode_epilogue(rem);
+                POM_STAMP(L, POM_PH_X_EPILOGUE);
                 if (sp == 0) return;
                 sp--;
                 const int fr = a.frame(sp);
                 x = fr & 0xF; y = (fr >> 4) & 0xF; s = (fr >> 8) & 0xF;
                 dir = (fr >> 12) & 7; i = (fr >> 15) & 0xF; rem = (fr >> 19) & 63;
-                resume = 1; /* continue inside SpawnFlameItem, after its ExplodeBombAt */
-            }
-            const int c0 = y * POM_N + x;
-            if (resume) { /* SpawnFlameItem tail, bboard.cpp:42-56, for the cell whose bomb has just gone off: read again */
-                const int c = ray_cell(c0, dir, i);
+                /* SpawnFlameItem tail, bboard.cpp:42-56, for the cell whose bomb has just gone off: read again */
+                const int pc0 = y * POM_N + x;
+                const int c = ray_cell(pc0, dir, i);
                 const int e = a.cell(c);
                 int go_on = 0;
                 if (e != POM_C_RIGID) {
                     const int was_wood = pc_is_wood(e);
-                    a.set_cell(c, POM_C_FLAME | ((c0 << 3) + (was_wood ? (e & 3) : 0)));
+                    a.set_cell(c, POM_C_FLAME | ((pc0 << 3) + (was_wood ? (e & 3) : 0)));
                     go_on = !was_wood;
                 }
-                resume = 0;
                 if (go_on) i++;
                 else { dir++; i = 1; }
                 continue;
             }
-            const int lim = ray_room(x, y, s, dir);
-            int cj[NJ], ej[NJ];
-            int first = 0x7FFFFFFF; /* (j << 12 | what happens there), smallest j wins */
-#pragma unroll
-            for (int q = 0; q < NJ; q++) {
-                const int j = a.sub() + q * A::G, d = i + j;
-                const int on = d <= lim;
-                cj[q] = ray_cell(c0, dir, on ? d : lim);
-                ej[q] = a.cell(cj[q]);
+            /* SpawnFlameItem head, bboard.cpp:26-40: the agent on the cell dies, the bomb under it goes off */
+            const int d = (first >> 12) & 0xF;
+            if (first & 1) kill((first >> 1) & 3);
+            if (sp >= POM_STACK_DEPTH) { /* cannot happen with <= 20 queued bombs */
+                L.ub |= POM_UB_BAD_INDEX;
+                return;
             }
-#pragma unroll
-            for (int q = 0; q < NJ; q++) {
-                const int j = a.sub() + q * A::G, d = i + j;
-                const int e = ej[q];
-                int kind = 0, idx = 0; /* kind: 0 ordinary, 1 the ray stops before this cell, 2 wood: stops after it, 3 a queued bomb */
-                if (d > lim || e == POM_C_RIGID) {
-                    kind = 1;
-                } else if (e == POM_C_BOMB || pc_is_agent(e)) {
-                    const int cy = cj[q] / POM_N;
-                    idx = bomb_index_alone((cj[q] - cy * POM_N) | (cy << 4));
-                    kind = idx >= 0 ? 3 : 0;
-                    idx = idx >= 0 ? idx : 0;
-                } else if (pc_is_wood(e)) {
-                    kind = 2;
-                }
-                const int key = (j << 12) | (kind << 10) | (pc_is_agent(e) << 9) | ((e & 3) << 7) | idx;
-                first = (kind != 0 && key < first) ? key : first;
-            }
-            first = a.gmin(first);
-            const int fj = first == 0x7FFFFFFF ? 4 : first >> 12;
-            int victims = 0;
-#pragma unroll
-            for (int q = 0; q < NJ; q++) { /* the ordinary cells before the deciding one */
-                const int j = a.sub() + q * A::G;
-                if (j < fj) {
-                    if (pc_is_agent(ej[q])) victims |= 1 << (ej[q] & 3);
-                    a.put_cell(cj[q], POM_C_FLAME | (c0 << 3));
-                }
-            }
-            kill_set(a.gor(victims));
-            if (fj == 4) { /* four ordinary cells: on along the ray */
-                i += 4;
-                continue;
-            }
-            const int kind = (first >> 10) & 3;
-            if (kind == 3) { /* SpawnFlameItem head, bboard.cpp:26-40: the agent on the cell dies, the bomb under it goes off */
-                const int d = i + fj, jq = first & 0x1F;
-                if ((first >> 9) & 1) kill((first >> 7) & 3);
-                if (sp >= POM_STACK_DEPTH) { /* cannot happen with <= 20 queued bombs */
-                    L.ub |= POM_UB_BAD_INDEX;
-                    dir = 4; /* give up on this explosion in a defined way: no further rays */
-                    continue;
-                }
-                a.set_frame(sp, x | (y << 4) | (s << 8) | (dir << 12) | (d << 15) | (rem << 19));
-                sp++;
-                const int st2 = owner_strength(bomb_at(jq));
-                const int c = ray_cell(c0, dir, d);
-                y = c / POM_N;
-                x = c - y * POM_N;
-                rem = jq;
-                flame_prologue(x, y, st2);
-                s = st2 < 0 ? 0 : st2 > POM_N ? POM_N : st2;
-                dir = 0;
-                i = 1;
-                continue;
-            }
-            if (kind == 2) { /* wood burns and keeps its flag, the ray ends (bboard.cpp:44-55) */
-                const int c = ray_cell(c0, dir, i + fj);
-                a.set_cell(c, POM_C_FLAME | ((c0 << 3) + ((first >> 7) & 3)));
-            }
-            dir++;
+            a.set_frame(sp, x | (y << 4) | (s << 8) | (rstar << 12) | (d << 15) | (rem << 19));
+            sp++;
+            const int st2 = owner_strength(bomb_at(jq));
+            const int c = ray_cell(c0, rstar, d);
+            y = c / POM_N;
+            x = c - y * POM_N;
+            rem = jq;
+            flame_prologue(x, y, st2);
+            s = st2 < 0 ? 0 : st2 > POM_N ? POM_N : st2;
+            dir = 0;
             i = 1;
+            POM_STAMP(L, POM_PH_X_NEST);
         }
     }
 

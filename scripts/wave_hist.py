@@ -23,10 +23,10 @@ env.make_game(pa.make_boards(a.envs, seed=1, kind=a.kind))
 env.step_random(1, a.dist, ticks=100)
 L = B.load_library()
 nw = (a.envs + 63) // 64 * 64 // 16
-buf = np.zeros((nw, 10), dtype=np.int64)
+buf = np.zeros((nw, 15), dtype=np.int64)
 L.pom_diag_read_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
 assert L.pom_diag_read_raw(env._h, buf.ctypes.data, nw) == 0
-names = ["load", "flames", "prep", "agents", "bomb pass", "loop A", "loop B", "explosions", "epilogue", "store"]
+names = ["load", "flames", "prep", "agents", "bomb pass", "loop A", "loop B", "explosions", "epilogue", "store", "x look", "x commit", "x bookkeeping", "x nest", "x -"]
 tot = []
 per = []
 for t in range(20):
@@ -40,7 +40,7 @@ per = np.concatenate(per)
 q = lambda x, p: np.percentile(x, p)
 print(f"envs {a.envs} {a.kind} dist {a.dist}: per-wavefront tick cycles over 20 launches: mean {tot.mean():.0f} p50 {q(tot,50):.0f} p90 {q(tot,90):.0f} "
       f"p99 {q(tot,99):.0f} p99.9 {q(tot,99.9):.0f} max {tot.max()}")
-comp = per[:, 1:9].sum(axis=1)
+comp = per[:, 1:9].sum(axis=1) + per[:, 10:].sum(axis=1)
 print(f"  compute only (flames..epilogue): mean {comp.mean():.0f} p50 {q(comp,50):.0f} p90 {q(comp,90):.0f} p99 {q(comp,99):.0f} p99.9 {q(comp,99.9):.0f} max {comp.max()}")
 for k, n in enumerate(names):
     c = per[:, k]

@@ -49,6 +49,14 @@ int main(int argc, char** argv)
                 const int32_t *pa = (const int32_t*)&a, *pb = (const int32_t*)&b, *pc = (const int32_t*)&cur;
                 for (int k = 0; k < 251; k++)
                     if (pa[k] != pb[k]) printf("  dword %d: before %d oracle %d emul %d\n", k, pc[k], pa[k], pb[k]);
+                if (const char* f = getenv("POM_FUZZ_DUMP")) { /* the failing input, for a replay under a debugger */
+                    FILE* o = fopen(f, "wb");
+                    if (o) {
+                        fwrite(&cur, sizeof cur, 1, o);
+                        fwrite(mv, sizeof mv, 1, o);
+                        fclose(o);
+                    }
+                }
                 return 1;
             }
             if (ub_o) flagged++;
