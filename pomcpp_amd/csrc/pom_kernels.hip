@@ -16,8 +16,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <new>
+#include <thread>
 
 #include "pom_batch.h"
 #include "pom_boardgen_body.h"
@@ -1110,6 +1112,7 @@ struct PomBatch {
     int main_part = 1; /* part 0 of a split step runs on the caller's stream itself, parts 1.. on sub-streams: one stream
                           fewer for the same overlap (3 parts: 21.2 -> 20.6 us per step at 65,536 envs); POM_MAIN_PART=0: all
                           parts on sub-streams */
+    struct PomIssuer* issuers[MAX_PARTS] = {}; /* helper threads that issue the sub-stream parts of multi-tick calls (launch_many) */
     bool fuse_policy = true; /* pom_batch_step_simple: policy and tick in one kernel (quad shape); POM_FUSE=0 keeps them apart */
     /* optional per-launch timing (pom_batch_profile) */
     bool profiling = false;
@@ -1121,6 +1124,8 @@ struct PomBatch {
 #endif
 };
 
+struct PomIssuer;
+static void stop_issuers(PomBatch* h);
 static int fork_parts(PomBatch* h);
 static int join_parts(PomBatch* h);
 static int ensure_sub_streams(PomBatch* h, int parts);
@@ -1139,6 +1144,7 @@ int pom_device_count(void)
 int pom_batch_destroy(PomBatch* h)
 {
     if (!h) return POM_E_ARG;
+    stop_issuers(h);
     (void)hipSetDevice(h->device);
     for (int k = 0; k < PomBatch::MAX_PARTS; k++)
         if (h->sub[k]) (void)hipStreamSynchronize(h->sub[k]);
@@ -1443,12 +1449,8 @@ static int ensure_agent_mem(PomBatch* h)
     return POM_OK;
 }
 
-/* `one_launch`: the whole batch in ONE launch on the caller's stream.  For steps that have to be joined with the caller's stream
- * every tick (explicit moves): forking into sub-streams and joining them again costs more than the overlap gains
- * (65,536 envs, MI355X: 23.3 us per step as one launch, 43.8 as two, 60.2 as three; profiles/r02a_explicit_streams.txt). */
-static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int dist, int ticks, bool policy = false, bool one_launch = false)
+static int fill_params(PomBatch* h, StepParams& p, const int32_t* moves_dev, uint64_t seed, int dist, int ticks)
 {
-    StepParams p;
     p.agent_mem = h->agent_mem;
     p.state = h->state;
     p.snap = h->snap;
@@ -1468,6 +1470,7 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
     p.episode = h->episode;
     p.board_seed = h->board_seed;
     p.fresh = h->fresh;
+    p.block0 = p.block_end = 0;
 #if defined(POM_DIAG)
     if (!h->diag) {
         HIPCHK(hipMalloc((void**)&h->diag, (size_t)h->n_waves * POM_PH_N * 8));
@@ -1475,6 +1478,40 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
     }
     p.diag = h->diag;
 #endif
+    return POM_OK;
+}
+
+/* one dispatch of the step kernel the handle is configured for, over tiles [p.block0, p.block_end) */
+static hipError_t dispatch_step(const PomBatch* h, const StepParams& p, hipStream_t st, bool policy, hipEvent_t ev0, hipEvent_t ev1)
+{
+    const dim3 grid((unsigned)((p.block_end - p.block0 + POM_WPB - 1) / POM_WPB));
+    const bool fresh = h->fresh && h->mode == POM_MODE_ENV && h->auto_reset;
+#define POM_LAUNCH(E, G) \
+    (fresh ? hipExtLaunchKernelGGL((pom_step_kernel<E, G, true>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p) \
+           : hipExtLaunchKernelGGL((pom_step_kernel<E, G, false>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p))
+#define POM_LAUNCH_Q(F, P, A) hipExtLaunchKernelGGL((pom_step_kernel<16, 4, F, P, A>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p)
+    const bool at_end = h->auto_reset == POM_RESET_AT_END && h->mode == POM_MODE_ENV; /* quad shape only: checked at creation */
+    if (at_end) {
+        if (policy) fresh ? POM_LAUNCH_Q(true, true, true) : POM_LAUNCH_Q(false, true, true);
+        else fresh ? POM_LAUNCH_Q(true, false, true) : POM_LAUNCH_Q(false, false, true);
+    } else if (policy) { /* the caller checked h->quad */
+        fresh ? POM_LAUNCH_Q(true, true, false) : POM_LAUNCH_Q(false, true, false);
+    } else if (h->epw == 64) POM_LAUNCH(64, 1);
+    else if (h->epw == 32) POM_LAUNCH(32, 1);
+    else if (h->quad) POM_LAUNCH(16, 4);
+    else POM_LAUNCH(16, 1);
+#undef POM_LAUNCH_Q
+#undef POM_LAUNCH
+    return hipGetLastError();
+}
+
+/* `one_launch`: the whole batch in ONE launch on the caller's stream.  For steps that have to be joined with the caller's stream
+ * every tick (explicit moves): forking into sub-streams and joining them again costs more than the overlap gains
+ * (65,536 envs, MI355X: 23.3 us per step as one launch, 43.8 as two, 60.2 as three; profiles/r02a_explicit_streams.txt). */
+static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int dist, int ticks, bool policy = false, bool one_launch = false)
+{
+    StepParams p;
+    if (int rc = fill_params(h, p, moves_dev, seed, dist, ticks)) return rc;
     const int64_t tiles = h->n_pad / h->epw;
     const int parts = one_launch ? 1 : h->parts;
     int rc = one_launch ? join_parts(h) : fork_parts(h);
@@ -1485,30 +1522,131 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
         hipStream_t st = (parts == 1 || k < h->main_part) ? h->stream : h->sub[k];
         p.block0 = b0;
         p.block_end = b1;
-        const dim3 grid((unsigned)((b1 - b0 + POM_WPB - 1) / POM_WPB));
         /* per-launch timing (pom_batch_profile): start / stop events attached to the dispatch itself, i.e. the kernel's own
          * duration as a profiler reports it, not the stream's period (events recorded around a launch also time the gap) */
         const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
         hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
-        const bool fresh = h->fresh && h->mode == POM_MODE_ENV && h->auto_reset;
-#define POM_LAUNCH(E, G) \
-    (fresh ? hipExtLaunchKernelGGL((pom_step_kernel<E, G, true>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p) \
-           : hipExtLaunchKernelGGL((pom_step_kernel<E, G, false>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p))
-#define POM_LAUNCH_Q(F, P, A) hipExtLaunchKernelGGL((pom_step_kernel<16, 4, F, P, A>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p)
-        const bool at_end = h->auto_reset == POM_RESET_AT_END && h->mode == POM_MODE_ENV; /* quad shape only: checked at creation */
-        if (at_end) {
-            if (policy) fresh ? POM_LAUNCH_Q(true, true, true) : POM_LAUNCH_Q(false, true, true);
-            else fresh ? POM_LAUNCH_Q(true, false, true) : POM_LAUNCH_Q(false, false, true);
-        } else if (policy) { /* the caller checked h->quad */
-            fresh ? POM_LAUNCH_Q(true, true, false) : POM_LAUNCH_Q(false, true, false);
-        } else if (h->epw == 64) POM_LAUNCH(64, 1);
-        else if (h->epw == 32) POM_LAUNCH(32, 1);
-        else if (h->quad) POM_LAUNCH(16, 4);
-        else POM_LAUNCH(16, 1);
-#undef POM_LAUNCH_Q
-#undef POM_LAUNCH
-        HIPCHK(hipGetLastError());
+        HIPCHK(dispatch_step(h, p, st, policy, ev0, ev1));
         if (prof) h->prof_n++;
+    }
+    return POM_OK;
+}
+
+/* ---- several ticks in one call: one issuing thread per part ---------------------------------------------------------------
+ * A step of `parts` launches every ~18 us leaves the host ~6 us per launch; one thread that also pays the API's own overhead
+ * does not always keep that up, and a short run then measures the host (20-step bursts: 24-36 us per step on a busy box
+ * against 18 in a long run, where the queues have time to fill).  The parts are independent — each has its own stream and
+ * its launches depend only on that stream's order — so part k's launches of ALL the ticks of the call are issued by a
+ * helper thread of its own (created once per handle), part 0's by the caller; the call returns when everything is queued.
+ * Results cannot depend on this: the same kernels with the same arguments go to the same streams in the same per-stream order. */
+struct PomIssuer {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool has_job = false, quit = false, busy = false;
+    /* the job */
+    StepParams p;
+    hipStream_t st = nullptr;
+    int launches = 0, ticks_per_launch = 1, last_ticks = 1;
+    bool policy = false;
+    hipError_t err = hipSuccess;
+};
+
+static void issuer_main(PomBatch* h, PomIssuer* w)
+{
+    (void)hipSetDevice(h->device);
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+        w->cv.wait(lk, [w] { return w->has_job || w->quit; });
+        if (w->quit) return;
+        w->has_job = false;
+        StepParams p = w->p;
+        hipError_t err = hipSuccess;
+        for (int i = 0; i < w->launches && err == hipSuccess; i++) {
+            p.ticks = i + 1 == w->launches ? w->last_ticks : w->ticks_per_launch;
+            err = dispatch_step(h, p, w->st, w->policy, nullptr, nullptr);
+            p.tick0 += (uint32_t)w->ticks_per_launch;
+        }
+        w->err = err;
+        w->busy = false;
+        w->cv.notify_all();
+    }
+}
+
+static void stop_issuers(PomBatch* h)
+{
+    for (int k = 0; k < PomBatch::MAX_PARTS; k++) {
+        PomIssuer* w = h->issuers[k];
+        if (!w) continue;
+        {
+            std::lock_guard<std::mutex> g(w->mu);
+            w->quit = true;
+        }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+        delete w;
+        h->issuers[k] = nullptr;
+    }
+}
+
+/* `launches` dispatches per part (ticks_per_launch ticks each, the last one `last_ticks`), tick counter advanced by the caller */
+static int launch_many(PomBatch* h, uint64_t seed, int dist, int launches, int ticks_per_launch, int last_ticks, bool policy)
+{
+    StepParams p;
+    if (int rc = fill_params(h, p, nullptr, seed, dist, ticks_per_launch)) return rc;
+    const int64_t tiles = h->n_pad / h->epw;
+    const int parts = h->parts;
+    if (int rc = fork_parts(h)) return rc;
+    int started[PomBatch::MAX_PARTS] = {};
+    for (int k = h->main_part; k < parts; k++) { /* the sub-stream parts: hand them to their threads */
+        const int64_t b0 = tiles * k / parts, b1 = tiles * (k + 1) / parts;
+        if (b1 <= b0) continue;
+        if (!h->issuers[k]) {
+            h->issuers[k] = new (std::nothrow) PomIssuer();
+            if (!h->issuers[k]) return POM_E_NOMEM;
+            h->issuers[k]->th = std::thread(issuer_main, h, h->issuers[k]);
+        }
+        PomIssuer* w = h->issuers[k];
+        {
+            std::lock_guard<std::mutex> g(w->mu);
+            w->p = p;
+            w->p.block0 = b0;
+            w->p.block_end = b1;
+            w->st = h->sub[k];
+            w->launches = launches;
+            w->ticks_per_launch = ticks_per_launch;
+            w->last_ticks = last_ticks;
+            w->policy = policy;
+            w->err = hipSuccess;
+            w->busy = true;
+            w->has_job = true;
+        }
+        w->cv.notify_all();
+        started[k] = 1;
+    }
+    hipError_t err = hipSuccess;
+    for (int k = 0; k < (parts == 1 ? 1 : h->main_part); k++) { /* the caller's own part(s) */
+        const int64_t b0 = tiles * k / parts, b1 = tiles * (k + 1) / parts;
+        if (b1 <= b0) continue;
+        StepParams q = p;
+        q.block0 = b0;
+        q.block_end = b1;
+        for (int i = 0; i < launches && err == hipSuccess; i++) {
+            q.ticks = i + 1 == launches ? last_ticks : ticks_per_launch;
+            err = dispatch_step(h, q, h->stream, policy, nullptr, nullptr);
+            q.tick0 += (uint32_t)ticks_per_launch;
+        }
+    }
+    for (int k = 0; k < parts; k++) { /* everything is queued when the call returns */
+        if (!started[k]) continue;
+        PomIssuer* w = h->issuers[k];
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [w] { return !w->busy; });
+        if (w->err != hipSuccess && err == hipSuccess) err = w->err;
+    }
+    if (err != hipSuccess) {
+        set_err("pom_step_kernel launch", err);
+        return POM_E_HIP;
     }
     return POM_OK;
 }
@@ -1535,6 +1673,14 @@ int pom_batch_step_random(PomBatch* h, uint64_t seed, int32_t dist, int32_t tick
 {
     if (!h || ticks < 0 || ticks_per_launch < 1 || dist < POM_DIST_HARMLESS || dist > POM_DIST_STRESS) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    const int32_t launches = (ticks + ticks_per_launch - 1) / ticks_per_launch;
+    if (launches >= 2 && h->parts > 1 && !h->profiling) { /* several launches per part: one issuing thread per part */
+        const int32_t last = ticks - (launches - 1) * ticks_per_launch;
+        int rc = launch_many(h, seed, dist, launches, ticks_per_launch, last, false);
+        if (rc) return rc;
+        h->tick += (uint64_t)ticks;
+        return POM_OK;
+    }
     for (int32_t done = 0; done < ticks;) {
         const int32_t t = ticks - done < ticks_per_launch ? ticks - done : ticks_per_launch;
         int rc = launch_step(h, nullptr, seed, dist, t);
@@ -1875,6 +2021,12 @@ int pom_batch_step_simple(PomBatch* h, uint64_t seed, int32_t ticks)
     HIPCHK(hipSetDevice(h->device));
     if (h->quad && h->fuse_policy) { /* the fused kernel: policy and tick on one load of the record */
         if (int rc = ensure_agent_mem(h)) return rc;
+        if (ticks >= 2 && h->parts > 1 && !h->profiling) {
+            int rc = launch_many(h, seed, 0, ticks, 1, 1, true);
+            if (rc) return rc;
+            h->tick += (uint64_t)ticks;
+            return POM_OK;
+        }
         for (int32_t t = 0; t < ticks; t++) {
             if (int rc = launch_step(h, nullptr, seed, 0, 1, true)) return rc;
             h->tick += 1;

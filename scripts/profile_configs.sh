@@ -2,13 +2,14 @@
 # scripts/profile_configs.sh <tag> — rocprofv3 summaries for every BASELINE single-GPU config (run through gpurun):
 #   head1   config "headline" with ONE launch per step (--streams 1): 65,536 envs in one dispatch, so that
 #           bytes / AverageNs / peak is checkable from the kernel-trace alone
+#   head3   the headline as bench.py runs it by default (3 launches per step on parallel streams): kernel trace only
 #   c5      config 5: 65,536 envs, kick / chain-explosion stress boards and move mix
 #   c3      config 3: 65,536 envs, 4x SimpleAgent policy fused with the tick
 #   c2      config 2: 4,096 envs, random moves
 # Kernel traces and PMC passes are separate runs (never combined with sys/hip traces).  Output: gpurun_out/prof_<tag>/<cfg>/.
 set -u
 TAG=$1; shift
-WHICH=${*:-head1 c5 c3 c2}
+WHICH=${*:-head1 head3 c5 c3 c2}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 TOP=$REPO/gpurun_out/prof_$TAG
 mkdir -p $TOP
@@ -17,6 +18,7 @@ COMMON="--no-cpu-baseline --no-config3 --streams 1"
 for CFG in $WHICH; do
   case $CFG in
     head1) ARGS="--steps 200 --warmup 20 $COMMON" ;;
+    head3) ARGS="--steps 200 --warmup 20 --no-cpu-baseline --no-config3 --streams 3" ;;
     c5)    ARGS="--steps 200 --warmup 60 --kind stress --dist stress $COMMON" ;;
     c3)    ARGS="--steps 200 --warmup 200 --policy simple $COMMON" ;;
     c2)    ARGS="--steps 400 --warmup 60 --envs 4096 $COMMON" ;;
@@ -26,6 +28,13 @@ for CFG in $WHICH; do
   rm -rf $OUT && mkdir -p $OUT
   echo "== $CFG: bench.py $ARGS"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
+  if [ "$CFG" = head3 ]; then
+    tail -1 $OUT/trace.log > $OUT/bench_under_trace.json
+    python3 $REPO/scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+    cat $OUT/summary.txt
+    find $OUT -name "*kernel_trace.csv" -size +8M -delete
+    continue
+  fi
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq1 -- python3 $REPO/bench.py $ARGS > $OUT/sq1.log 2>&1 || { echo "sq1 pass failed"; tail -5 $OUT/sq1.log; exit 1; }
   rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/sq2 -- python3 $REPO/bench.py $ARGS > $OUT/sq2.log 2>&1 || { echo "sq2 pass failed"; tail -5 $OUT/sq2.log; exit 1; }
   if [ "$CFG" = head1 ] || [ "${POM_PROFILE_BYTES:-0}" = 1 ]; then
