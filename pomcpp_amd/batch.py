@@ -341,7 +341,8 @@ class BatchEnvironment:
 
     def fork(self) -> None:
         """Order the internal sub-streams behind the handle's stream now (the next step then needs no cross-stream event first)."""
-        _check(self._lib, self._lib.pom_batch_fork(self._h))
+        if hasattr(self._lib, "pom_batch_fork"):  # (older experimental builds loaded through POM_LIB lack it)
+            _check(self._lib, self._lib.pom_batch_fork(self._h))
 
     def set_streams(self, streams: int) -> None:
         _check(self._lib, self._lib.pom_batch_set_streams(self._h, streams))

@@ -569,8 +569,16 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
             t[(POM_REC_AGENTS + 2 * i + 1) * EPW] = (uint32_t)L.a1[i];
         }
     }
-    if (EPW == 16) store_tile16_x4(p.state + tile_id * EPW, np, tile, lane);
-    else store_tile<EPW>(col_d, np, tile, sub, el);
+    if (EPW == 16) {
+        /* the store addresses are functions of the lane id and the arguments only: left alone the compiler computes them at
+         * the top of the kernel and keeps 14 registers alive (or spilled) through the whole tick — hand it a lane id it cannot
+         * see through, so that they are computed here */
+        int lane_late = lane;
+        asm volatile("" : "+v"(lane_late));
+        store_tile16_x4(p.state + tile_id * EPW, np, tile, lane_late);
+    } else {
+        store_tile<EPW>(col_d, np, tile, sub, el);
+    }
 
 #if defined(POM_DIAG)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
