@@ -16,4 +16,5 @@ from .state import (  # noqa: F401
     is_flame, is_wood, is_powerup, is_agent, queue_get,
 )
 from .boards import make_boards  # noqa: F401
-from .batch import BatchEnvironment, PomError, library_path, load_library  # noqa: F401
+from .batch import (BatchEnvironment, PomError, library_path, load_library,  # noqa: F401
+                    RESET_OFF, RESET_AT_START, RESET_AT_END)
