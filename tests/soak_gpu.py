@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import pomcpp_amd as pa
-from pomcpp_amd.batch import BatchEnvironment, MODE_ENV
+from pomcpp_amd.batch import BatchEnvironment, MODE_ENV, RESET_AT_END
 from tests.oracle_lib import Oracle
 
 ap = argparse.ArgumentParser()
@@ -24,10 +24,14 @@ ora = Oracle()
 N, cap = 65536, 800
 slices = [(0, 384), (21845 - 100, 384), (43690 - 7, 384), (N - 384, 384)]  # around the sub-batch boundaries of a 3-way split
 t_all = time.time()
-for name, fresh, kind, dist in (("replay, ffa, random moves", False, "ffa", 1), ("fresh boards, ffa, random moves", True, "ffa", 1),
-                                ("replay, stress boards, stress moves", False, "stress", 2)):
+for name, fresh, kind, dist, at_end in (("replay, ffa, random moves", False, "ffa", 1, False),
+                                        ("fresh boards, ffa, random moves", True, "ffa", 1, False),
+                                        ("replay, stress boards, stress moves", False, "stress", 2, False),
+                                        ("replay, reset at the END of the tick, ffa, random moves", False, "ffa", 1, True),
+                                        ("replay, reset at the END of the tick, stress", False, "stress", 2, True)):
     seed, bseed = 101, 202
-    env = BatchEnvironment(N, mode=MODE_ENV, auto_reset=True, max_steps=cap, fresh_boards=fresh, board_seed=bseed, streams=3)
+    env = BatchEnvironment(N, mode=MODE_ENV, auto_reset=RESET_AT_END if at_end else True, max_steps=cap, fresh_boards=fresh,
+                           board_seed=bseed, streams=3)
     if fresh:
         env.generate(bseed)
     else:
@@ -52,6 +56,9 @@ for name, fresh, kind, dist in (("replay, ffa, random moves", False, "ffa", 1), 
                 ora.run_random_fresh(r[0], r[1], chunk, seed, bseed, first, tick, dist, cap)
             else:
                 ora.run_random(r[0], r[2], chunk, seed, first, tick, dist, cap)
+            if at_end:  # the oracle restarts a finished env at the start of the next tick, the device already has: same games
+                fin = (r[0]["aliveAgents"] <= 1) | (r[0]["timeStep"] >= cap)
+                r[0][fin] = r[2][fin]
             assert g.tobytes() == r[0].tobytes(), (name, first, tick)
     eps = env.episodes()
     ub = env.status()["ubflags"]
