@@ -612,6 +612,73 @@ def q7_out_of_order_timer_underflow(api):
     api.several_steps(8, s, m)
 
 
+def q13_resting_bomb_on_item_cells(api):
+    """Loop B for resting bombs (step.cpp:243-272 with target == position): PASSAGE under the bomb becomes BOMB, a power-up
+    under it is a static block (the bomb is only set to rest) and stays, two bombs on one cell: only the later one looks."""
+    s = api.make()
+    m = idle()
+    api.corners(s, 0, 1, 2, 3)
+    for a in range(4):
+        s["agents"][0, a]["maxBombCount"] = 5
+    api.plant_bomb(s, 3, 3, 0, False)            # no item set: the cell shows PASSAGE
+    api.plant_bomb(s, 5, 5, 1, False)
+    api.put_item(s, 5, 5, Item.EXTRABOMB)        # a power-up under a queued bomb
+    api.plant_bomb(s, 7, 7, 2, False)
+    api.plant_bomb(s, 7, 7, 3, False)            # shares the cell with the bomb before it
+    api.step(s, m)
+    api.require(s["board"][0, 3, 3] == Item.BOMB)
+    api.require(s["board"][0, 5, 5] == Item.EXTRABOMB)
+    api.require(s["board"][0, 7, 7] == Item.BOMB)
+    api.set_bomb_direction(s, 0, Direction.RIGHT)   # one moving bomb: the general loop, same resting bombs
+    api.several_steps(3, s, m)
+
+
+def q14_agent_chain_with_planting(api):
+    """Three agents in a row all step RIGHT (a dependency chain of depth 2: visited root first), the last one plants; the
+    fourth walks into the tail's old cell one tick later.  Queue order of planters follows the visiting order."""
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 3, 5, 2)
+    api.put_agent(s, 2, 5, 0)
+    api.put_agent(s, 1, 5, 3)
+    api.put_agent(s, 9, 9, 1)
+    for a in range(4):
+        s["agents"][0, a]["maxBombCount"] = 3
+    m[0], m[2], m[3], m[1] = Move.RIGHT, Move.RIGHT, Move.RIGHT, Move.BOMB
+    api.step(s, m)
+    api.require_agent(s, 2, 4, 5)
+    api.require_agent(s, 0, 3, 5)
+    api.require_agent(s, 3, 2, 5)
+    m[3], m[0] = Move.BOMB, Move.BOMB            # planters 3 and 0 in one tick: slots in visiting order
+    api.step(s, m)
+    m[0], m[2], m[3] = Move.LEFT, Move.LEFT, Move.IDLE   # 2 waits for 0's cell, 0 is blocked by 3: nobody moves
+    api.step(s, m)
+    m[3] = Move.UP                               # 3 leaves: 0 follows into his cell, 2 into 0's
+    api.several_steps(2, s, m)
+
+
+def q15_long_blast_chain(api):
+    """Strength-4 blasts: a ray that burns wood, one stopped by rigid, agents killed on the way, a chain through three bombs
+    two of which share a cell, picked up mid-ray after the nested explosions (SpawnFlameItem's tail)."""
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 5, 1, 0)
+    api.put_agent(s, 9, 5, 1)
+    api.put_agent(s, 5, 9, 2)
+    api.put_agent(s, 0, 0, 3)
+    for a in range(4):
+        s["agents"][0, a]["maxBombCount"] = 5
+        s["agents"][0, a]["bombStrength"] = 4
+    api.put_item(s, 2, 5, Item.WOOD + 2)
+    api.put_item(s, 5, 7, Item.RIGID)
+    api.plant_bomb(s, 5, 5, 0, True, 2)          # goes off first
+    api.plant_bomb(s, 7, 5, 1, True, 9)          # on its +x ray
+    api.plant_bomb(s, 7, 5, 2, True, 9)          # same cell: stays queued, sitting in the flame
+    api.plant_bomb(s, 7, 3, 3, True, 9)          # reached by the nested blast's -y ray
+    api.plant_bomb(s, 5, 3, 3, True, 9)          # on the first bomb's -y ray, after the nested ones have run
+    api.several_steps(4, s, m)
+
+
 def full_queues_stress(api):
     """20 live bombs (queue full) detonating in one chain: full-depth explosion stack, flame queue fills."""
     s = api.make()
@@ -636,6 +703,9 @@ EXTRA_CASES = {
     "q7_out_of_order_timer_underflow": q7_out_of_order_timer_underflow,
     "q9_dead_agent_cancels_move": q9_dead_agent_cancels_move,
     "q10_three_cycle_plus_one": q10_three_cycle_plus_one,
+    "q13_resting_bomb_on_item_cells": q13_resting_bomb_on_item_cells,
+    "q14_agent_chain_with_planting": q14_agent_chain_with_planting,
+    "q15_long_blast_chain": q15_long_blast_chain,
     "full_queues_stress": full_queues_stress,
 }
 
