@@ -363,20 +363,27 @@ def worker(args) -> None:
     reduce_counters(counters, dist)  # warm the RCCL communicator outside the timed region
     env.reset_counters()
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     env.fork()  # the sub-streams are ordered behind the setup above now, not inside the timed region
     barrier()
     t0 = time.perf_counter()
-    ev0.record(stream)
     run_steps(args.steps)
-    env.flush()  # steps run as sub-batches on internal streams: order them before the event on this stream
-    ev1.record(stream)
-    env.counters_into(counters.data_ptr())
+    env.counters_into(counters.data_ptr())  # joins the sub-batches' streams, then sums the per-wavefront counters
     reduce_counters(counters, dist)  # the one collective: step / episode totals over all ranks
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = reduce_max(elapsed, device, dist)
-    step_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream: mean time of one step (all its launches)
+    total_steps = int(counters[CNT_STEPS].item())
+    episodes_finished = int(counters[1].item())
+    # the same number of steps again between two HIP events on the launch stream (untimed: the events and the join they need
+    # would add their own latency to the region above): GPU-side time per step, all launches of a step
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record(stream)
+    run_steps(args.steps)
+    env.flush()  # steps run as sub-batches on internal streams: order them before the event on this stream
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    step_ms = ev0.elapsed_time(ev1) / args.steps
     step_ms = reduce_max(step_ms, device, dist)
     # a step is issued as `parts` launches of pom_step_kernel over contiguous sub-batches on parallel streams; time the
     # individual launches too (HIP events attached to each dispatch), outside the timed region
@@ -455,7 +462,6 @@ def worker(args) -> None:
         other["explicit_moves_device_65536_envs"] = {
             "value": plan["n_envs"] / (ms_x * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_x, "steps": n_x,
             "note": "pom_batch_step_device with auto_reset = POM_RESET_AT_END: Move[4] from device memory, one launch per tick on the caller's stream"}
-    total_steps = int(counters[CNT_STEPS].item())
     expect = plan["global_envs"] * args.steps * tpl
     if total_steps != expect:
         raise SystemExit(f"step counter {total_steps} != envs x ticks {expect}")
@@ -493,7 +499,7 @@ def worker(args) -> None:
                 "burn_in_ticks": args.burn_in, "launches_per_step_tuning_ms": tuned, "untimed_tuning_steps": tuning_steps,
                 "parallelism": f"env-shard x{world}", "ranks": world, "collective_backend": backend,
                 "rccl_ranks": dist.get_world_size() if world > 1 else 1,
-                "episodes_finished": int(counters[1].item()),
+                "episodes_finished": episodes_finished,
             },
             "roofline": {
                 "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
