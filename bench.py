@@ -18,8 +18,9 @@ The JSON line carries
   roofline     — `achieved` / `frac`: SURVEY §8(d)'s contract bytes (2024 B per env-step: the reference's 1004-B State read
                  and written + Move[4]) over the SAME clock as `value` (ms_per_step), against the 8 TB/s HBM3E peak;
                  `hbm_achieved` / `hbm_frac`: the bytes the kernel really moves (`traffic`: rocprofv3 PMC FETCH_SIZE /
-                 WRITE_SIZE of this workload, committed under profiles/ and named in `traffic_source`; the packed record's
-                 footprint 2 x 448 B per env otherwise) over the same clock; `launch`: one launch's bytes and mean duration
+                 WRITE_SIZE of this workload, measured by the default run itself in two child runs under rocprofv3 — or the
+                 figure committed under profiles/ where the profiler is missing; `traffic_source` says which; the packed
+                 record's footprint 2 x 448 B per env otherwise) over the same clock; `launch`: one launch's bytes and mean duration
                  from HIP events on the launch stream (what rocprofv3's kernel trace reports as AverageNs);
                  `limiter`: what actually bounds the kernel (profiles/).
   cpu_baseline — the unmodified reference bboard::Step (oracle/_ref, built where /root/reference lies) or the restatement,
@@ -224,6 +225,48 @@ def cpu_baseline(start: np.ndarray, seed: int, dist_id: int, max_steps: int, bud
     return port
 
 
+def measure_traffic(args) -> dict | None:
+    """HBM bytes per step of THIS build on THIS workload, from the PMC counters: two child runs of this script under rocprofv3
+    (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: separate passes, counters only, no tracing), one launch per step so that no
+    concurrent dispatch shares the counters.  gfx950: FETCH_SIZE reports half of a coalesced streaming read (MI355X guide;
+    calibrated in round 1 on a zero-tick launch of this kernel: 0.513), both counters are in KB.  None if the profiler is not
+    there or a pass fails — the caller then falls back to the committed measurement."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--traffic-probe", "--streams", "1", "--steps", "60", "--warmup", "10",
+             "--envs", str(args.envs), "--kind", args.kind, "--dist", args.dist, "--seed", str(args.seed), "--max-steps", str(args.max_steps),
+             "--burn-in", str(args.burn_in), "--no-cpu-baseline", "--no-config3"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(td, counter)
+                subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env, check=True,
+                               capture_output=True, timeout=240)
+                vals = []
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if "pom_step_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            vals.append(float(row["Counter_Value"]))
+                if len(vals) < 40:
+                    return None
+                vals = vals[len(vals) // 2:]  # the steady second half: past the burn-in
+                out[counter] = sum(vals) / len(vals)
+    except Exception:
+        return None
+    bytes_per_step = (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
+    return {"hbm_bytes_per_step": int(round(bytes_per_step)), "fetch_size_kb_raw": out["FETCH_SIZE"], "write_size_kb_raw": out["WRITE_SIZE"],
+            "fetch_correction": 2.0}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,6 +290,8 @@ def parse_args(argv=None):
     ap.add_argument("--fresh-boards", action="store_true",
                     help="boards drawn on the device (pom_batch_generate) and a new one per episode instead of the snapshot replay "
                          "BASELINE's configs prescribe (SURVEY §8 f3)")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure HBM traffic with rocprofv3 child runs (use the committed figure)")
+    ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)  # the child of measure_traffic(): steps only, no JSON extras
     ap.add_argument("--envs-per-wave", type=int, default=0)
     ap.add_argument("--lanes-per-env", type=int, default=0)
     return ap.parse_args(argv)
@@ -475,8 +520,18 @@ def worker(args) -> None:
         # share a process with the timed run); anything else is priced with the packed record's footprint
         traffic, traffic_source = None, None
         tj = os.path.join(ROOT, TRAFFIC_JSON)
-        if os.path.exists(tj) and args.envs == 65536 and tpl == 1 and args.kind == "ffa" and args.dist == "random" \
-                and args.policy == "random" and not args.fresh_boards:
+        headline = (args.envs == 65536 and tpl == 1 and args.kind == "ffa" and args.dist == "random" and args.policy == "random"
+                    and not args.fresh_boards)
+        live = None
+        if world == 1 and tpl == 1 and args.policy == "random" and not args.fresh_boards and not args.no_traffic \
+                and not args.no_config3 and not args.traffic_probe:
+            live = measure_traffic(args)  # the default run measures it itself, on this build (two rocprofv3 child runs)
+        if live:
+            traffic = live["hbm_bytes_per_step"]
+            traffic_source = (f"measured by this run: rocprofv3 --pmc FETCH_SIZE ({live['fetch_size_kb_raw']:.1f} KB raw per step, x 2: the gfx950 "
+                              f"correction) and --pmc WRITE_SIZE ({live['write_size_kb_raw']:.1f} KB) in two separate child runs of this script "
+                              "with one launch per step")
+        elif os.path.exists(tj) and headline:
             traffic = json.load(open(tj))["hbm_bytes_per_step"]  # all launches of one step
             traffic_source = TRAFFIC_JSON + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections applied; " \
                                             "measured on this workload earlier, not in this run)"

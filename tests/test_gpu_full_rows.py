@@ -117,3 +117,26 @@ def test_long_horizon_simple_agents_with_fresh_boards(hip_lib, oracle):
         assert np.array_equal(env.policy_memory(), mems), tick
     assert np.array_equal(env.episodes(), eps) and eps.min() >= 1 and eps.mean() > 4  # 1,200 ticks: a game lasts ~190
     env.close()
+
+
+def test_bench_launcher_runs_two_real_ranks_on_one_gpu(hip_lib):
+    """`python bench.py --gpus 2` as the driver issues it, on a one-GPU box: POM_BENCH_REHEARSAL lets the two ranks share the device
+    (gloo instead of RCCL).  The real worker runs in both ranks: shard plan, env_offset, stepping, counter all-reduce, max-over-ranks
+    timing, the JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, POM_BENCH_REHEARSAL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--envs", "8192", "--steps", "12", "--warmup", "3",
+                          "--burn-in", "40", "--no-cpu-baseline", "--no-config3"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["ranks"] == 2 and r["config"]["rccl_ranks"] == 2 and r["config"]["collective_backend"] == "gloo"
+    assert r["config"]["global_envs"] == 16384 and r["scaling"] == "weak" and "REHEARSAL" in r["data"]
+    assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 16384) < 1.0  # value = all ranks' env-steps over the slowest rank's time
