@@ -250,7 +250,7 @@ def measure_traffic(args) -> dict | None:
             for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 d = os.path.join(td, counter)
                 subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env, check=True,
-                               capture_output=True, timeout=240)
+                               capture_output=True, timeout=120)
                 vals = []
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                     for row in csv.DictReader(open(f)):
