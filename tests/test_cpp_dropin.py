@@ -24,7 +24,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "build")
 EXE = os.path.join(BUILD, "dropin_test")
 REF = "/root/reference"
-REF_SOURCES = ["src/agents/simple_agent.cpp", "src/agents/basic_agents.cpp", "src/bboard/strategy.cpp", "src/main.cpp"]
 REF_OUT = os.path.join(ROOT, "oracle", "_ref")  # binaries built from reference sources live only here (git-ignored)
 LINK = ["-L" + os.path.join(ROOT, "pomcpp_amd"), "-lpom_batch", "-Wl,-rpath," + os.path.join(ROOT, "pomcpp_amd"),
         "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-pthread"]
@@ -50,43 +49,22 @@ def env_game_exe(hip_lib):
     return exe
 
 
-@pytest.fixture(scope="module")
-def reference_objects(hip_lib):
-    """the reference's unmodified agent / game-loop sources compiled against pom_bboard.hpp"""
-    inc = os.path.join(BUILD, "dropin_inc")
-    os.makedirs(inc, exist_ok=True)
-    os.makedirs(REF_OUT, exist_ok=True)
-    for h in ("agents.hpp", "strategy.hpp", "colors.hpp"):  # headers of the agents themselves; bboard.hpp / step_utility.hpp are ours
-        link = os.path.join(inc, h)
-        if os.path.islink(link) or os.path.exists(link):
-            os.remove(link)
-        os.symlink(os.path.join(REF, "include", h), link)
-    objs = {}
-    for src in REF_SOURCES:
-        obj = os.path.join(REF_OUT, "dropin_" + os.path.basename(src).replace(".cpp", ".o"))
-        subprocess.run(["g++", "-std=c++17", "-O1", "-c"] + INC + ["-I" + inc, os.path.join(REF, src), "-o", obj], check=True)
-        objs[os.path.basename(src)] = obj
-    return objs, inc
-
-
 def test_reference_style_code_compiles_against_the_drop_in_header(dropin_exe):
     assert os.path.exists(dropin_exe)
 
 
 @pytest.mark.skipif(not have_reference, reason="the reference tree only exists in the build container")
-def test_unmodified_reference_agents_and_main_compile_and_link_against_the_drop_in_header(reference_objects):
-    objs, inc = reference_objects
-    # src/main.cpp: SimpleAgents + bboard::Environment::MakeGame / GetState / StartGame
-    exe = os.path.join(REF_OUT, "dropin_main")
-    subprocess.run(["g++", "-o", exe, objs["main.cpp"], objs["simple_agent.cpp"], objs["basic_agents.cpp"], objs["strategy.cpp"]] + LINK,
-                   check=True)
-    assert os.path.exists(exe)
-    # the trace program with the reference's own SimpleAgent as the four players; runs on the GPU box (test below)
-    exe2 = os.path.join(REF_OUT, "env_game_ref")
-    subprocess.run(["g++", "-std=c++17", "-O1", "-DPOM_WITH_REFERENCE_AGENTS"] + INC + ["-I" + inc,
-                    os.path.join(ROOT, "tests", "cpp", "env_game.cpp"), objs["simple_agent.cpp"], objs["basic_agents.cpp"],
-                    objs["strategy.cpp"], "-o", exe2] + LINK, check=True)
-    assert os.path.exists(exe2)
+def test_unmodified_reference_agents_and_main_compile_and_link_against_the_drop_in_header(hip_lib):
+    """oracle/Makefile target `dropin` (also run by __graft_entry__.build()): src/agents/simple_agent.cpp, basic_agents.cpp,
+    src/bboard/strategy.cpp and src/main.cpp compiled where they lie against include/pom_bboard.hpp; main.cpp — SimpleAgents +
+    bboard::Environment::MakeGame / GetState / StartGame — linked into oracle/_ref/dropin_main, and the trace program with the
+    reference's own SimpleAgent as the four players into oracle/_ref/env_game_ref (runs on the GPU box, test below)"""
+    for f in ("dropin_main", "env_game_ref", "dropin_main.o", "dropin_simple_agent.o", "dropin_basic_agents.o", "dropin_strategy.o"):
+        path = os.path.join(REF_OUT, f)
+        if os.path.exists(path):
+            os.remove(path)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "dropin"], check=True)
+    assert os.path.exists(os.path.join(REF_OUT, "dropin_main")) and os.path.exists(os.path.join(REF_OUT, "env_game_ref"))
 
 
 def test_host_init_board_items_is_the_boardgen_specification(env_game_exe, oracle, tmp_path):

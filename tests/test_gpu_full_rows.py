@@ -119,6 +119,8 @@ def test_long_horizon_simple_agents_with_fresh_boards(hip_lib, oracle):
     env.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
 def test_bench_launcher_runs_two_real_ranks_on_one_gpu(hip_lib):
     """`python bench.py --gpus 2` as the driver issues it, on a one-GPU box: POM_BENCH_REHEARSAL lets the two ranks share the device
     (gloo instead of RCCL).  The real worker runs in both ranks: shard plan, env_offset, stepping, counter all-reduce, max-over-ranks
