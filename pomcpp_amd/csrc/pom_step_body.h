@@ -429,6 +429,20 @@ struct PomStepper {
     POM_HD void bomb_cells(uint32_t occ[4]) const
     {
         occ[0] = occ[1] = occ[2] = occ[3] = 0u;
+        if (A::G == 1) { /* one lane per env: a plain loop over the live bombs (nothing to keep in flight for other lanes) */
+            POM_NOUNROLL
+            for (int k = 0; k < L.bCnt; k++) {
+                const int b = bomb_at(k);
+                const int idx = pb_y(b) * POM_N + pb_x(b);
+                const uint32_t m = idx < POM_CELLS ? 1u << (idx & 31) : 0u;
+                const int wd = idx >> 5;
+                occ[0] |= wd == 0 ? m : 0u;
+                occ[1] |= wd == 1 ? m : 0u;
+                occ[2] |= wd == 2 ? m : 0u;
+                occ[3] |= wd == 3 ? m : 0u;
+            }
+            return;
+        }
         constexpr int NS = POM_Q / A::G; /* slots per lane */
         int w[NS];
 #pragma unroll
@@ -456,6 +470,7 @@ struct PomStepper {
     /* first queue offset whose bomb sits on pos, or -1 — bomb_index() with every lane's slots fetched at once */
     POM_HD int bomb_index_wide(int pos) const
     {
+        if (A::G == 1) return bomb_index(pos);
         constexpr int NS = POM_Q / A::G;
         int w[NS];
 #pragma unroll
@@ -536,8 +551,37 @@ struct PomStepper {
         POM_NOUNROLL
         for (;;) {
             const int c0 = y * POM_N + x;
-            int rs[NR], rlen[NR], rends[NR], rwood[NR], rvict[NR];
             int first = 0x7FFFFFFF; /* ray << 16 | distance << 12 | info of the first bomb cell met, smallest ray wins */
+            int rstar, jq = -1;
+            if (A::G == 1) {
+                /* one lane per env: the rays in turn, each looked at and committed before the next (their cells are disjoint,
+                 * so this is the same as looking at all of them first), stopping at the first ray that meets a bomb cell */
+                POM_NOUNROLL
+                for (int r = dir; r < 4 && first == 0x7FFFFFFF; r++) {
+                    const int rs1 = r == dir ? i : 1;
+                    int len1, ends1, wood1, vict1, chain1, info1;
+                    scan_ray(c0, r, rs1, ray_room(x, y, s, r), occ, len1, ends1, wood1, vict1, chain1, info1);
+                    if (chain1) {
+                        const int c = ray_cell(c0, r, chain1);
+                        const int cy = c / POM_N;
+                        jq = bomb_index((c - cy * POM_N) | (cy << 4));
+                        if (jq < 0) { /* the set was too large here: strike the cell and look at this ray again */
+                            const uint32_t m = ~(1u << (c & 31));
+                            const int w = c >> 5;
+                            occ[0] &= w == 0 ? m : ~0u; occ[1] &= w == 1 ? m : ~0u; occ[2] &= w == 2 ? m : ~0u; occ[3] &= w == 3 ? m : ~0u;
+                            r--;
+                            continue;
+                        }
+                        first = (r << 16) | (chain1 << 12) | info1;
+                    }
+                    POM_NOUNROLL
+                    for (int d = rs1; d <= len1; d++)
+                        a.put_cell(ray_cell(c0, r, d), POM_C_FLAME | ((c0 << 3) + ((wood1 && d == len1) ? ends1 : 0)));
+                    kill_set(vict1);
+                }
+                rstar = first == 0x7FFFFFFF ? 4 : first >> 16;
+            } else {
+            int rs[NR], rlen[NR], rends[NR], rwood[NR], rvict[NR];
 #pragma unroll
             for (int q = 0; q < NR; q++) {
                 const int r = a.sub() + q * A::G;
@@ -550,8 +594,7 @@ struct PomStepper {
                 first = (chain != 0 && key < first) ? key : first;
             }
             first = a.gmin(first);
-            const int rstar = first == 0x7FFFFFFF ? 4 : first >> 16;
-            int jq = -1;
+            rstar = first == 0x7FFFFFFF ? 4 : first >> 16;
             if (rstar < 4) { /* the cell the look settled on: which bomb is it? */
                 const int c = ray_cell(c0, rstar, (first >> 12) & 0xF);
                 const int cy = c / POM_N;
@@ -577,6 +620,7 @@ struct PomStepper {
                 }
             }
             kill_set(a.gor(victims));
+            }
             POM_STAMP(L, POM_PH_X_COMMIT);
             if (rstar == 4) { /* the blast is complete: the caller's bookkeeping, then back into the parent */
                 explode_epilogue(rem);
