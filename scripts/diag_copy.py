@@ -11,7 +11,7 @@ import torch
 import pomcpp_amd.batch as B
 B.library_path = lambda: lib
 import pomcpp_amd as pa
-for n in (65536, 262144):
+for n in ([int(x) for x in sys.argv[1:]] or [65536, 262144]):
     st = torch.cuda.Stream(); torch.cuda.set_stream(st)
     env = B.BatchEnvironment(n, mode=B.MODE_ENV, auto_reset=True, max_steps=800, stream=st.cuda_stream)
     env.make_game(pa.make_boards(n, seed=1))
