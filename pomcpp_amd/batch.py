@@ -202,9 +202,22 @@ class BatchEnvironment:
             raise ValueError(f"moves must be int32[{self.n}, 4] (dead agents included), got {mv.shape}")
         _check(self._lib, self._lib.pom_batch_step(self._h, mv.ctypes.data))
 
-    def step_device(self, moves_ptr: int) -> None:
-        """moves_ptr: device address of int32[n,4] (e.g. torch_tensor.data_ptr())."""
-        _check(self._lib, self._lib.pom_batch_step_device(self._h, moves_ptr))
+    def step_device(self, moves) -> None:
+        """moves: a device tensor int32[n,4] on this handle's device (anything with data_ptr / shape / dtype, e.g. a torch
+        tensor: shape, element type, contiguity and device are checked), or the raw device address of such an array."""
+        if hasattr(moves, "data_ptr"):
+            shape = tuple(getattr(moves, "shape", ()))
+            if shape != (self.n, 4):
+                raise ValueError(f"moves must be int32[{self.n}, 4] (dead agents included), got shape {shape}")
+            if "int32" not in str(getattr(moves, "dtype", "")):
+                raise ValueError(f"moves must be int32, got {getattr(moves, 'dtype', None)}")
+            if hasattr(moves, "is_contiguous") and not moves.is_contiguous():
+                raise ValueError("moves must be contiguous")
+            dev = getattr(moves, "device", None)
+            if dev is not None and (getattr(dev, "type", "cuda") != "cuda" or getattr(dev, "index", self.device) not in (None, self.device)):
+                raise ValueError(f"moves live on {dev}, the batch on device {self.device}")
+            moves = moves.data_ptr()
+        _check(self._lib, self._lib.pom_batch_step_device(self._h, int(moves)))
 
     def step_random(self, seed: int, dist: int = DIST_RANDOM, ticks: int = 1, ticks_per_launch: int = 1) -> None:
         _check(self._lib, self._lib.pom_batch_step_random(self._h, seed, dist, ticks, ticks_per_launch))

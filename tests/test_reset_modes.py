@@ -106,3 +106,32 @@ def test_results_calls_need_the_mode(hip_lib):
             env.last_results()
     with pytest.raises(PomError):
         BatchEnvironment(64, mode=MODE_ENV, auto_reset=3)
+
+
+def test_moves_from_a_device_tensor_equal_moves_from_the_host(hip_lib):
+    """pom_batch_step_device (what an RL loop calls every tick) against pom_batch_step with the same moves; the Python wrapper
+    checks what it is handed"""
+    import torch
+    n = 3000
+    start = pa.make_boards(n, seed=12)
+    rng = np.random.default_rng(8)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        a = BatchEnvironment(n, mode=MODE_ENV, auto_reset=RESET_AT_END, max_steps=50, stream=stream.cuda_stream)
+        b = BatchEnvironment(n, mode=MODE_ENV, auto_reset=RESET_AT_END, max_steps=50, stream=stream.cuda_stream)
+        a.make_game(start)
+        b.make_game(start)
+        for t in range(120):
+            mv = rng.integers(0, 6, size=(n, 4), dtype=np.int32)
+            a.step(mv)
+            b.step_device(torch.from_numpy(mv).to("cuda", non_blocking=False))
+        assert a.get_state().tobytes() == b.get_state().tobytes()
+        assert all(np.array_equal(x, y) for x, y in zip(a.last_results().values(), b.last_results().values()))
+        with pytest.raises(ValueError):
+            b.step_device(torch.zeros((n, 3), dtype=torch.int32, device="cuda"))
+        with pytest.raises(ValueError):
+            b.step_device(torch.zeros((n, 4), dtype=torch.int64, device="cuda"))
+        with pytest.raises(ValueError):
+            b.step_device(torch.zeros((n, 4), dtype=torch.int32))  # a host tensor
+        a.close()
+        b.close()
