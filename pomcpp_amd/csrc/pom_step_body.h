@@ -889,33 +889,62 @@ struct PomStepper {
             mvp |= (uint32_t)mv[i] << (4 * i);
         }
 
-        /* FillPositions / FillDestPos / FixSwitchMove (step_utility.cpp:130-170); dead agents included */
-        int px[4], py[4], dx[4], dy[4];
-        uint32_t oldp = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            px[i] = ag_x(L.a0[i]);
-            py[i] = ag_y(L.a0[i]);
-            dx[i] = px[i] + mv_dx(mv[i]);
-            dy[i] = py[i] + mv_dy(mv[i]);
-            oldp |= (uint32_t)(px[i] | (py[i] << 4)) << (8 * i);
-            oldp_ = oldp;
-        }
-        /* Does any agent's destination touch another agent's cell (dead agents included: SURVEY Q9)?  If not — the usual
-         * case, the agents are far apart — FixSwitchMove changes nothing and ResolveDependencies makes everyone a root in
-         * index order; the literal pairwise logic below only runs for the envs that need it. */
+        /* FillPositions / FillDestPos / FixSwitchMove (step_utility.cpp:130-170); dead agents included.  Positions travel as a
+         * byte per agent (x | y << 4), destinations as (x+1) | (y+1) << 4.  With a quad per env lane m works out agent m's and
+         * the four are exchanged with quad broadcasts; the pairwise logic below — FixSwitchMove, ResolveDependencies — only
+         * runs for the envs in which some agent's destination touches another agent's cell (dead agents included: SURVEY
+         * Q9).  Otherwise, the usual case (the agents are far apart), FixSwitchMove changes nothing and everyone is a root in
+         * index order. */
+        uint32_t oldp = 0, dstp = 0;
         uint32_t dep = 0xFFFF, roots = 0x3210;
         int nroots = 4;
         int deadmask = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) deadmask |= ag_dead(L.a0[i]) << i;
         int contact = 0;
+        if (A::G == 4) {
+            const int m = a.sub();
+            const int av = sel4(m, L.a0);
+            const int mvm = (int)((mvp >> (4 * m)) & 0xF);
+            const int pxm = ag_x(av), pym = ag_y(av);
+            const int dxm = pxm + mv_dx(mvm), dym = pym + mv_dy(mvm);
+            const int pos8 = pxm | (pym << 4);
+            oldp = (uint32_t)a.template gbcast<0>(pos8) | ((uint32_t)a.template gbcast<1>(pos8) << 8) |
+                   ((uint32_t)a.template gbcast<2>(pos8) << 16) | ((uint32_t)a.template gbcast<3>(pos8) << 24);
+            const int d8 = ((dxm + 1) & 0xF) | (((dym + 1) & 0xF) << 4);
+            dstp = (uint32_t)a.template gbcast<0>(d8) | ((uint32_t)a.template gbcast<1>(d8) << 8) |
+                   ((uint32_t)a.template gbcast<2>(d8) << 16) | ((uint32_t)a.template gbcast<3>(d8) << 24);
+            /* my destination as a position byte: off the board it carries a nibble 15 or 11, which no position has */
+            const uint32_t want = (uint32_t)((dxm & 0xF) | ((dym & 0xF) << 4));
+            int mine = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) mine |= (j != m) & (((oldp >> (8 * j)) & 0xFFu) == want);
+            contact = a.gor(mine);
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (i != j) contact |= (dx[i] == px[j]) & (dy[i] == py[j]);
+            for (int i = 0; i < 4; i++) {
+                const int px = ag_x(L.a0[i]), py = ag_y(L.a0[i]);
+                const int dx = px + mv_dx(mv[i]), dy = py + mv_dy(mv[i]);
+                oldp |= (uint32_t)(px | (py << 4)) << (8 * i);
+                dstp |= (uint32_t)(((dx + 1) & 0xF) | (((dy + 1) & 0xF) << 4)) << (8 * i);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (i != j) contact |= ((((dstp >> (8 * i)) & 0xF) - 1) & 0xF) == ((oldp >> (8 * j)) & 0xF) &&
+                                           ((((dstp >> (8 * i + 4)) & 0xF) - 1) & 0xF) == ((oldp >> (8 * j + 4)) & 0xF);
+        }
+        oldp_ = oldp;
         if (contact) {
+            int px[4], py[4], dx[4], dy[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                px[i] = (int)((oldp >> (8 * i)) & 0xF);
+                py[i] = (int)((oldp >> (8 * i + 4)) & 0xF);
+                dx[i] = px[i] + mv_dx(mv[i]);
+                dy[i] = py[i] + mv_dy(mv[i]);
+            }
             roots = 0xFFFF;
             nroots = 0;
 #pragma unroll
@@ -947,11 +976,14 @@ struct PomStepper {
                     nroots++;
                 }
             }
+            dstp = 0; /* FixSwitchMove may have changed them */
+#pragma unroll
+            for (int i = 0; i < 4; i++) dstp |= (uint32_t)(((dx[i] + 1) & 0xF) | (((dy[i] + 1) & 0xF) << 4)) << (8 * i);
         }
         const int ouroboros = nroots == 0;
-        uint32_t dstp = 0; /* destinations as (x+1) | (y+1)<<4, one byte per agent */
+        int posb[4]; /* the agents' position bytes (x | y << 4) */
 #pragma unroll
-        for (int i = 0; i < 4; i++) dstp |= (uint32_t)(((dx[i] + 1) & 0xF) | (((dy[i] + 1) & 0xF) << 4)) << (8 * i);
+        for (int i = 0; i < 4; i++) posb[i] = (int)((oldp >> (8 * i)) & 0xFF);
 
         /* HasBomb(x, y) is only ever asked about the moving agent's own cell (step.cpp:89,127,152,172) and bombs
          * do not move during the agent loop: one pass over the queue answers it for all four agents */
@@ -961,7 +993,7 @@ struct PomStepper {
             const int bw = bomb_at(k);
             const int bp = pb_pos(bw);
 #pragma unroll
-            for (int j = 0; j < 4; j++) on_bomb |= (bp == (px[j] | (py[j] << 4))) << j;
+            for (int j = 0; j < 4; j++) on_bomb |= (bp == posb[j]) << j;
             on_bomb |= (pb_dir(bw) != 0) << 4;
         }
         on_bomb = a.gor(on_bomb);
@@ -983,7 +1015,7 @@ struct PomStepper {
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = i + 1; j < 4; j++)
-                    par &= ((deadmask >> i) & 1) | ((deadmask >> j) & 1) | (px[i] != px[j]) | (py[i] != py[j]);
+                    par &= ((deadmask >> i) & 1) | ((deadmask >> j) & 1) | (posb[i] != posb[j]);
             uint32_t rankp = 0x3210u, depthp = 0u; /* nibble per agent: position in the reference's visiting order, depth in his chain */
             int rounds = 1;
             if (par && nroots != 4) {
