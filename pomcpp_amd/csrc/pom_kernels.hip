@@ -482,6 +482,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
             const uint32_t ub_before = L.ub;
             L.ub = 0;
             status &= ~(uint32_t)POM_ST_RESTARTED;
+            POM_STAMP(L, POM_PH_RESTART); /* diagnostic builds: the restarts and the move draw */
             if (POLICY) {
                 /* a fresh view of the tile for the tick: keeps the compiler from computing the tick's addresses before the
                  * policy and carrying them through it (the fused kernel otherwise wants 170 VGPRs) */
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                      only (the blast engines) are booked by the lanes inside; everybody else books the same time on the phase
                      around them — so the wavefront reports the lane that spent the most time inside */
         long long inside = 0;
-        for (int k = POM_PH_X_SCAN; k < POM_PH_N; k++) inside += L.t_acc[k];
+        for (int k = POM_PH_X_SCAN; k <= POM_PH_X_SHORT; k++) inside += L.t_acc[k];
         long long best = inside;
         for (int o = 32; o > 0; o >>= 1) {
             const long long w = __shfl_xor(best, o);

@@ -69,7 +69,7 @@
 #endif
 enum { POM_PH_LOAD = 0, POM_PH_FLAMES, POM_PH_AGENT_PREP, POM_PH_AGENT_LOOP, POM_PH_BOMB_PASS, POM_PH_BOMB_A, POM_PH_BOMB_B,
        POM_PH_TICK_BOMBS, POM_PH_EPILOGUE, POM_PH_STORE,
-       POM_PH_X_SCAN, POM_PH_X_COMMIT, POM_PH_X_EPILOGUE, POM_PH_X_NEST, POM_PH_X_SHORT, POM_PH_N }; /* X_*: inside explode_long / explode (their time is NOT in the phase that called them) */
+       POM_PH_X_SCAN, POM_PH_X_COMMIT, POM_PH_X_EPILOGUE, POM_PH_X_NEST, POM_PH_X_SHORT, POM_PH_RESTART, POM_PH_FLAMES_DEC, POM_PH_N }; /* X_*: inside explode_long / explode (their time is NOT in the phase that called them) */
 
 struct PomLane { /* the register-resident part of one env */
     int a0[4];   /* x:8 | y:8 | bombCount:8 | canKick@24 | dead@25 — only ever indexed statically */
@@ -856,6 +856,7 @@ struct PomStepper {
     {
         int ftop, fn, btop, bn;
         flames_dec(ftop, fn); /* step.cpp:15 */
+        POM_STAMP(L, POM_PH_FLAMES_DEC);
         flame_pops(ftop, fn);
         POM_STAMP(L, POM_PH_FLAMES);
         step_middle(mv_in, btop, bn);

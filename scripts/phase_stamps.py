@@ -27,14 +27,14 @@ import pomcpp_amd as pa
 env = B.BatchEnvironment(a.envs, mode=B.MODE_ENV, auto_reset=True, max_steps=800, streams=1)
 env.make_game(pa.make_boards(a.envs, seed=1, kind=a.kind))
 env.step_random(1, a.dist, ticks=50)
-out = (C.c_longlong * 15)()
+out = (C.c_longlong * 17)()
 L = B.load_library()
 L.pom_diag_read.argtypes = [C.c_void_p, C.c_void_p]
 L.pom_diag_read(env._h, out)
 env.step_random(1, a.dist, ticks=a.ticks)
 L.pom_diag_read(env._h, out)
 names = ["load", "tick_flames", "agent_prep", "agent_loop", "bomb reset/classify pass", "bomb_loop_A", "bomb_loop_B", "tick_bombs+explosions", "epilogue", "store",
-         "  long blast: look", "  long blast: commit", "  long blast: bookkeeping", "  long blast: nest", "  (unused)"]
+         "  long blast: look", "  long blast: commit", "  long blast: bookkeeping", "  long blast: nest", "  short blast", "restarts + move draw (before the tick)", "flames: timers (the rest of tick_flames = pops)"]
 v = np.array(list(out), dtype=np.float64)
 epw = env.launch_shape()[0]; waves = (a.envs + epw - 1) // epw
 per = v / (waves * a.ticks)

@@ -23,10 +23,10 @@ env.make_game(pa.make_boards(a.envs, seed=1, kind=a.kind))
 env.step_random(1, a.dist, ticks=100)
 L = B.load_library()
 nw = (a.envs + 63) // 64 * 64 // 16
-buf = np.zeros((nw, 15), dtype=np.int64)
+buf = np.zeros((nw, 17), dtype=np.int64)
 L.pom_diag_read_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
 assert L.pom_diag_read_raw(env._h, buf.ctypes.data, nw) == 0
-names = ["load", "flames", "prep", "agents", "bomb pass", "loop A", "loop B", "explosions", "epilogue", "store", "x look", "x commit", "x bookkeeping", "x nest", "x -"]
+names = ["load", "flames", "prep", "agents", "bomb pass", "loop A", "loop B", "explosions", "epilogue", "store", "x look", "x commit", "x bookkeeping", "x nest", "x short", "restart+draw", "flame timers"]
 tot = []
 per = []
 for t in range(20):
