@@ -466,18 +466,29 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
             p.agent_mem[4 * np + tile_id * 64 + lane] = m1;
         }
         if (active) {
-            int mv[4];
-            if (POLICY) {
-                mv[0] = acc.template gbcast<0>(mv_own);
-                mv[1] = acc.template gbcast<1>(mv_own);
-                mv[2] = acc.template gbcast<2>(mv_own);
-                mv[3] = acc.template gbcast<3>(mv_own);
-            } else if (p.moves) {
-                mv[0] = moves0.x; mv[1] = moves0.y; mv[2] = moves0.z; mv[3] = moves0.w; /* explicit moves: one tick per launch */
+            /* the moves, a nibble per agent.  With a quad per env lane m works out agent m's and the quad exchanges them */
+            uint32_t mvp;
+            if (G == 4) {
+                int mine;
+                if (POLICY) {
+                    mine = mv_own;
+                } else if (p.moves) { /* explicit moves: one tick per launch */
+                    mine = member == 0 ? moves0.x : member == 1 ? moves0.y : member == 2 ? moves0.z : moves0.w;
+                } else {
+                    const uint64_t r = tk == 0 ? draw0 : pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick0 + (uint32_t)tk);
+                    mine = pom_rng_pick((uint32_t)(r >> (16 * member)) & 0xFFFFu, p.dist);
+                }
+                mvp = stepper.pack_moves_quad(mine);
             } else {
-                const uint64_t r = tk == 0 ? draw0 : pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick0 + (uint32_t)tk);
+                int mv[4];
+                if (p.moves) {
+                    mv[0] = moves0.x; mv[1] = moves0.y; mv[2] = moves0.z; mv[3] = moves0.w;
+                } else {
+                    const uint64_t r = tk == 0 ? draw0 : pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick0 + (uint32_t)tk);
 #pragma unroll
-                for (int i = 0; i < 4; i++) mv[i] = pom_rng_pick((uint32_t)(r >> (16 * i)) & 0xFFFFu, p.dist);
+                    for (int i = 0; i < 4; i++) mv[i] = pom_rng_pick((uint32_t)(r >> (16 * i)) & 0xFFFFu, p.dist);
+                }
+                mvp = stepper.pack_moves(mv);
             }
             const uint32_t ub_before = L.ub;
             L.ub = 0;
@@ -490,9 +501,9 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                 asm volatile("" : "+v"(t2));
                 LdsEnv<EPW, G> acc2{t2, member};
                 PomStepper<LdsEnv<EPW, G>> stepper2(acc2, L);
-                stepper2.step(mv);
+                stepper2.step_packed(mvp);
             } else {
-                stepper.step(mv);
+                stepper.step_packed(mvp);
             }
             new_ub = L.ub != 0;
             L.ub |= ub_before;

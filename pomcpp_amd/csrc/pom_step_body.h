@@ -852,14 +852,31 @@ struct PomStepper {
 
     /* bboard::Step, step.cpp:9-284, in four pieces so that a kernel can put its own version of the two event loops
      * (flame pops, top-bomb explosions) between them; step() is the plain sequence. */
-    POM_HD void step(const int mv_in[4])
+    POM_HD void step(const int mv_in[4]) { step_packed(pack_moves(mv_in)); }
+    /* moves as a nibble per agent; anything outside 0..5 acts as "no displacement, not IDLE, not BOMB" -> code 6 */
+    POM_HD static int clamp_move(int m) { return ((unsigned)m <= 5u) ? m : 6; }
+    POM_HD static uint32_t pack_moves(const int mv_in[4])
+    {
+        uint32_t mvp = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) mvp |= (uint32_t)clamp_move(mv_in[i]) << (4 * i);
+        return mvp;
+    }
+    /* a quad per env: lane m hands in agent m's move */
+    POM_HD uint32_t pack_moves_quad(int mine) const
+    {
+        const int c = clamp_move(mine);
+        return (uint32_t)a.template gbcast<0>(c) | ((uint32_t)a.template gbcast<1>(c) << 4) | ((uint32_t)a.template gbcast<2>(c) << 8) |
+               ((uint32_t)a.template gbcast<3>(c) << 12);
+    }
+    POM_HD void step_packed(uint32_t mvp)
     {
         int ftop, fn, btop, bn;
         flames_dec(ftop, fn); /* step.cpp:15 */
         POM_STAMP(L, POM_PH_FLAMES_DEC);
         flame_pops(ftop, fn);
         POM_STAMP(L, POM_PH_FLAMES);
-        step_middle(mv_in, btop, bn);
+        step_middle(mvp, btop, bn);
         top_explosions(btop, bn);
         POM_STAMP(L, POM_PH_TICK_BOMBS);
     }
@@ -876,19 +893,10 @@ struct PomStepper {
     }
     /* everything between the flame pops and the top-bomb explosions; returns the head of the bomb queue after the timer
      * decrement and the number of rounds the explosion loop may take */
-    POM_HD void step_middle(const int mv_in[4], int& top, int& n)
+    POM_HD void step_middle(const uint32_t mvp, int& top, int& n)
     {
         top = 0;
         n = 0;
-
-        /* moves: anything outside 0..5 acts as "no displacement, not IDLE, not BOMB" -> code 6 */
-        int mv[4];
-        uint32_t mvp = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            mv[i] = ((unsigned)mv_in[i] <= 5u) ? mv_in[i] : 6;
-            mvp |= (uint32_t)mv[i] << (4 * i);
-        }
 
         /* FillPositions / FillDestPos / FixSwitchMove (step_utility.cpp:130-170); dead agents included.  Positions travel as a
          * byte per agent (x | y << 4), destinations as (x+1) | (y+1) << 4.  With a quad per env lane m works out agent m's and
@@ -903,6 +911,7 @@ struct PomStepper {
 #pragma unroll
         for (int i = 0; i < 4; i++) deadmask |= ag_dead(L.a0[i]) << i;
         int contact = 0;
+        int clash = 0; /* two live agents on one cell */
         if (A::G == 4) {
             const int m = a.sub();
             const int av = sel4(m, L.a0);
@@ -917,15 +926,23 @@ struct PomStepper {
                    ((uint32_t)a.template gbcast<2>(d8) << 16) | ((uint32_t)a.template gbcast<3>(d8) << 24);
             /* my destination as a position byte: off the board it carries a nibble 15 or 11, which no position has */
             const uint32_t want = (uint32_t)((dxm & 0xF) | ((dym & 0xF) << 4));
-            int mine = 0;
+            int mine = 0; /* bit 0: my destination is somebody's cell; bit 1: I am alive and share my cell with a live agent */
+            const int alive_m = !ag_dead(av);
 #pragma unroll
-            for (int j = 0; j < 4; j++) mine |= (j != m) & (((oldp >> (8 * j)) & 0xFFu) == want);
-            contact = a.gor(mine);
+            for (int j = 0; j < 4; j++) {
+                const uint32_t pj = (oldp >> (8 * j)) & 0xFFu;
+                mine |= (j != m) & (pj == want);
+                mine |= ((j != m) & (pj == (uint32_t)pos8) & alive_m & !((deadmask >> j) & 1)) << 1;
+            }
+            mine = a.gor(mine);
+            contact = mine & 1;
+            clash = mine >> 1;
         } else {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int px = ag_x(L.a0[i]), py = ag_y(L.a0[i]);
-                const int dx = px + mv_dx(mv[i]), dy = py + mv_dy(mv[i]);
+                const int mvi = (int)((mvp >> (4 * i)) & 0xF);
+                const int dx = px + mv_dx(mvi), dy = py + mv_dy(mvi);
                 oldp |= (uint32_t)(px | (py << 4)) << (8 * i);
                 dstp |= (uint32_t)(((dx + 1) & 0xF) | (((dy + 1) & 0xF) << 4)) << (8 * i);
             }
@@ -943,8 +960,9 @@ struct PomStepper {
             for (int i = 0; i < 4; i++) {
                 px[i] = (int)((oldp >> (8 * i)) & 0xF);
                 py[i] = (int)((oldp >> (8 * i + 4)) & 0xF);
-                dx[i] = px[i] + mv_dx(mv[i]);
-                dy[i] = py[i] + mv_dy(mv[i]);
+                const int mvi = (int)((mvp >> (4 * i)) & 0xF);
+                dx[i] = px[i] + mv_dx(mvi);
+                dy[i] = py[i] + mv_dy(mvi);
             }
             roots = 0xFFFF;
             nroots = 0;
@@ -1011,12 +1029,7 @@ struct PomStepper {
              * waits for anybody (nroots == 4): one round.  Queue order of planters = the reference's visiting order (`rank`).
              * Left to the literal loop below: two live agents on one cell (their writes would collide), a dependency cycle
              * (ouroboros) and lost agents (somebody the chains do not reach). */
-            int par = !ouroboros;
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = i + 1; j < 4; j++)
-                    par &= ((deadmask >> i) & 1) | ((deadmask >> j) & 1) | (posb[i] != posb[j]);
+            int par = !ouroboros && !clash;
             uint32_t rankp = 0x3210u, depthp = 0u; /* nibble per agent: position in the reference's visiting order, depth in his chain */
             int rounds = 1;
             if (par && nroots != 4) {
