@@ -10,8 +10,9 @@ before the timed region starts; nothing crosses PCIe inside it.
 
 Multi-GPU: `python bench.py --gpus N` starts N ranks itself (one fresh process per GPU, before anything touches HIP);
 under `torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.  torch.distributed, backend nccl = RCCL; envs are
-sharded contiguously with no data-path collective; the only collective is the all-reduce of the step counters after the
-last tick (weak scaling: per-GPU batch fixed).  The reference fans out the same way, one env per std::thread
+sharded contiguously with no data-path collective; the timed region is exactly K steps between two (barrier +
+torch.cuda.synchronize()) pairs; the only collective besides the barriers is the all-reduce of the step counters, read after
+the region (weak scaling: per-GPU batch fixed).  The reference fans out the same way, one env per std::thread
 (unit_test/bboard/performance_test.cpp:40-50,71-94).
 
 The JSON line carries
@@ -412,11 +413,14 @@ def worker(args) -> None:
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
-    env.counters_into(counters.data_ptr())  # joins the sub-batches' streams, then sums the per-wavefront counters
-    reduce_counters(counters, dist)  # the one collective: step / episode totals over all ranks
-    barrier()
+    barrier()  # torch.cuda.synchronize() waits for every stream of the device, the sub-batches' included
     elapsed = time.perf_counter() - t0
     elapsed = reduce_max(elapsed, device, dist)
+    # bookkeeping, after the region: what the K steps did (per-wavefront counters summed on the device; the one collective:
+    # step / episode totals over all ranks).  Envs shard with no exchange on the path, so nothing of this belongs to a step.
+    env.counters_into(counters.data_ptr())
+    reduce_counters(counters, dist)
+    torch.cuda.synchronize()
     total_steps = int(counters[CNT_STEPS].item())
     episodes_finished = int(counters[1].item())
     # the same number of steps again between two HIP events on the launch stream (untimed: the events and the join they need

@@ -1069,20 +1069,28 @@ __global__ void pom_snapshot_kernel(const uint32_t* __restrict__ state, uint32_t
     }
 }
 
-__global__ void pom_reduce_counters_kernel(const int64_t* __restrict__ wc, int64_t n_waves, int64_t* out)
+__global__ __launch_bounds__(1024) void pom_reduce_counters_kernel(const int64_t* __restrict__ wc, int64_t n_waves, int64_t* out)
 {
-    __shared__ long long part[POM_CNT_N][256];
+    /* one workgroup of 1,024 lanes: 4,096 wavefront slots are four independent 32-byte loads per lane (the kernel sits at
+     * the end of a caller's timed region, after the sub-streams' join: a 256-lane loop of 16 dependent trips took 5-10 us) */
+    __shared__ long long part[POM_CNT_N][16];
     long long acc[POM_CNT_N] = {0, 0, 0, 0};
-    for (int64_t w = threadIdx.x; w < n_waves; w += blockDim.x)
-        for (int k = 0; k < POM_CNT_N; k++) acc[k] += wc[w * POM_CNT_N + k];
-    for (int k = 0; k < POM_CNT_N; k++) part[k][threadIdx.x] = acc[k];
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s)
-            for (int k = 0; k < POM_CNT_N; k++) part[k][threadIdx.x] += part[k][threadIdx.x + s];
-        __syncthreads();
+    for (int64_t w = threadIdx.x; w < n_waves; w += blockDim.x) {
+        const longlong2 lo = *reinterpret_cast<const longlong2*>(wc + w * POM_CNT_N);
+        const longlong2 hi = *reinterpret_cast<const longlong2*>(wc + w * POM_CNT_N + 2);
+        acc[0] += lo.x; acc[1] += lo.y; acc[2] += hi.x; acc[3] += hi.y;
     }
-    if (threadIdx.x < POM_CNT_N) out[threadIdx.x] = part[threadIdx.x][0];
+    static_assert(POM_CNT_N == 4, "two 16-byte loads per slot");
+    for (int k = 0; k < POM_CNT_N; k++)
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < POM_CNT_N; k++) part[k][threadIdx.x >> 6] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < POM_CNT_N) {
+        long long t = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += part[threadIdx.x][i];
+        out[threadIdx.x] = t;
+    }
 }
 
 /* ---- host side: the C-ABI --------------------------------------------------------------------- */
@@ -1637,7 +1645,30 @@ static int launch_many(PomBatch* h, uint64_t seed, int dist, int launches, int t
     const int parts = h->parts;
     if (int rc = fork_parts(h)) return rc;
     int started[PomBatch::MAX_PARTS] = {};
-    for (int k = h->main_part; k < parts; k++) { /* the sub-stream parts: hand them to their threads */
+    hipError_t err = hipSuccess;
+    /* The first launch of EVERY part is issued right here, the caller's own part(s) first: a helper thread takes 10-25 us to
+     * pick its job up (profiles/r02_region_trace.txt), and a part that starts a step late finishes a step late — alone on the
+     * device.  The helpers get the remaining launches of their parts and have one step's time to wake up. */
+    const int head = 1; /* 2 and 3 measured the same (20-step regions, scripts/ab_env.sh) */
+    for (int i = 0; i < head; i++) {
+        const int tk = i + 1 == launches ? last_ticks : ticks_per_launch;
+        for (int pass = 0; pass < 2; pass++) {
+            for (int k = 0; k < parts && err == hipSuccess; k++) {
+                const bool own = parts == 1 || k < h->main_part;
+                if (own != (pass == 0)) continue;
+                const int64_t b0 = tiles * k / parts, b1 = tiles * (k + 1) / parts;
+                if (b1 <= b0) continue;
+                StepParams q = p;
+                q.block0 = b0;
+                q.block_end = b1;
+                q.ticks = tk;
+                err = dispatch_step(h, q, own ? h->stream : h->sub[k], policy, nullptr, nullptr);
+            }
+        }
+        p.tick0 += (uint32_t)ticks_per_launch;
+    }
+    const int rest = launches - head;
+    for (int k = h->main_part; k < parts && rest > 0 && err == hipSuccess; k++) { /* the sub-stream parts: hand them to their threads */
         const int64_t b0 = tiles * k / parts, b1 = tiles * (k + 1) / parts;
         if (b1 <= b0) continue;
         if (!h->issuers[k]) {
@@ -1652,7 +1683,7 @@ static int launch_many(PomBatch* h, uint64_t seed, int dist, int launches, int t
             w->p.block0 = b0;
             w->p.block_end = b1;
             w->st = h->sub[k];
-            w->launches = launches;
+            w->launches = rest;
             w->ticks_per_launch = ticks_per_launch;
             w->last_ticks = last_ticks;
             w->policy = policy;
@@ -1664,15 +1695,14 @@ static int launch_many(PomBatch* h, uint64_t seed, int dist, int launches, int t
         w->cv.notify_all();
         started[k] = 1;
     }
-    hipError_t err = hipSuccess;
-    for (int k = 0; k < (parts == 1 ? 1 : h->main_part); k++) { /* the caller's own part(s) */
+    for (int k = 0; k < (parts == 1 ? 1 : h->main_part); k++) { /* the rest of the caller's own part(s) */
         const int64_t b0 = tiles * k / parts, b1 = tiles * (k + 1) / parts;
         if (b1 <= b0) continue;
         StepParams q = p;
         q.block0 = b0;
         q.block_end = b1;
-        for (int i = 0; i < launches && err == hipSuccess; i++) {
-            q.ticks = i + 1 == launches ? last_ticks : ticks_per_launch;
+        for (int i = 0; i < rest && err == hipSuccess; i++) {
+            q.ticks = i + 1 == rest ? last_ticks : ticks_per_launch;
             err = dispatch_step(h, q, h->stream, policy, nullptr, nullptr);
             q.tick0 += (uint32_t)ticks_per_launch;
         }
@@ -1811,7 +1841,7 @@ int pom_batch_counters_device(PomBatch* h, void* dev_int64x4)
     if (!h || !dev_int64x4) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     if (int jr = join_parts(h)) return jr;
-    pom_reduce_counters_kernel<<<dim3(1), dim3(256), 0, h->stream>>>(h->wave_counters, h->n_waves, (int64_t*)dev_int64x4);
+    pom_reduce_counters_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(h->wave_counters, h->n_waves, (int64_t*)dev_int64x4);
     HIPCHK(hipGetLastError());
     return POM_OK;
 }
