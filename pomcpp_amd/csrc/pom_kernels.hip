@@ -123,6 +123,9 @@ struct StepParams {
 #if defined(POM_DIAG)
     long long* diag; /* POM_PH_N accumulators per wavefront, diagnostic build only */
 #endif
+#if defined(POM_TRUNC)
+    int32_t trunc; /* the tick stops after this phase (POM_CUT in pom_step_body.h); environment POM_TRUNC_AT, default: all of it */
+#endif
 };
 
 /*
@@ -312,9 +315,12 @@ struct PolicyStore {
 /* POLICY: the moves are not read but decided here — lane m of an env's quad is agent m and runs SimpleAgent::act
  * (pom_policy_body.h) on the tile the tick is about to work on: Environment::Step with four SimpleAgents in ONE kernel, one
  * record load per tick instead of two and no Move[4] round trip (pom_batch_step_simple). */
-template <int EPW, int G, bool FRESH, bool POLICY = false, bool ATEND = false>
+/* SINGLE: the launch plays exactly one tick (p.ticks == 1: every launch of the bench, of an RL loop, of the explicit-move
+ * steps) — an instantiation without the tick loop, so that nothing is kept alive "for the next tick". */
+template <int EPW, int G, bool FRESH, bool POLICY = false, bool ATEND = false, bool SINGLE = false>
 __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW == 32 ? 2 : 1)) void pom_step_kernel(StepParams p)
 {
+    static_assert(!SINGLE || G == 4, "the one-tick instantiation exists for the quad shape");
     static_assert(G == 1 || (G == 4 && EPW == 16), "a quad per env needs 16 envs per wavefront");
     static_assert(!POLICY || G == 4, "the policy runs one agent per lane of the quad");
     static_assert(!ATEND || G == 4, "the end-of-tick reset is built for the quad shape only");
@@ -388,13 +394,17 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
 
     LdsEnv<EPW, G> acc{t, member};
     PomStepper<LdsEnv<EPW, G>> stepper(acc, L);
+#if defined(POM_TRUNC)
+    L.trunc = p.trunc;
+#endif
 #if defined(POM_DIAG)
     for (int k = 0; k < POM_PH_N; k++) L.t_acc[k] = 0;
     L.t_last = t_begin;
     POM_STAMP(L, POM_PH_LOAD);
 #endif
 
-    for (int tk = 0; tk < p.ticks; tk++) {
+    const int n_ticks = SINGLE ? 1 : p.ticks;
+    for (int tk = 0; tk < n_ticks; tk++) {
         if (ATEND) {
             /* POM_RESET_AT_END (a separate instantiation): nobody is finished when a tick begins; see the end of the tick */
         } else if (FRESH) { /* a separate instantiation: the replay kernel carries none of this */
@@ -494,6 +504,10 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
             L.ub = 0;
             status &= ~(uint32_t)POM_ST_RESTARTED;
             POM_STAMP(L, POM_PH_RESTART); /* diagnostic builds: the restarts and the move draw */
+#if defined(POM_TRUNC)
+            if (p.trunc <= 0) {
+            } else
+#endif
             if (POLICY) {
                 /* a fresh view of the tile for the tick: keeps the compiler from computing the tick's addresses before the
                  * policy and carrying them through it (the fused kernel otherwise wants 170 VGPRs) */
@@ -1487,6 +1501,9 @@ static int fill_params(PomBatch* h, StepParams& p, const int32_t* moves_dev, uin
     p.terminal = h->terminal;
     p.moves = moves_dev;
     p.wave_counters = h->wave_counters;
+#if defined(POM_TRUNC)
+    p.trunc = getenv("POM_TRUNC_AT") ? atoi(getenv("POM_TRUNC_AT")) : 99;
+#endif
     p.n = h->n;
     p.n_pad = h->n_pad;
     p.env_offset = h->env_offset;
@@ -1519,7 +1536,9 @@ static hipError_t dispatch_step(const PomBatch* h, const StepParams& p, hipStrea
 #define POM_LAUNCH(E, G) \
     (fresh ? hipExtLaunchKernelGGL((pom_step_kernel<E, G, true>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p) \
            : hipExtLaunchKernelGGL((pom_step_kernel<E, G, false>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p))
-#define POM_LAUNCH_Q(F, P, A) hipExtLaunchKernelGGL((pom_step_kernel<16, 4, F, P, A>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p)
+#define POM_LAUNCH_Q(F, P, A)                                                                                                          \
+    (p.ticks == 1 ? hipExtLaunchKernelGGL((pom_step_kernel<16, 4, F, P, A, true>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p) \
+                  : hipExtLaunchKernelGGL((pom_step_kernel<16, 4, F, P, A, false>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p))
     const bool at_end = h->auto_reset == POM_RESET_AT_END && h->mode == POM_MODE_ENV; /* quad shape only: checked at creation */
     if (at_end) {
         if (policy) fresh ? POM_LAUNCH_Q(true, true, true) : POM_LAUNCH_Q(false, true, true);
@@ -1528,7 +1547,7 @@ static hipError_t dispatch_step(const PomBatch* h, const StepParams& p, hipStrea
         fresh ? POM_LAUNCH_Q(true, true, false) : POM_LAUNCH_Q(false, true, false);
     } else if (h->epw == 64) POM_LAUNCH(64, 1);
     else if (h->epw == 32) POM_LAUNCH(32, 1);
-    else if (h->quad) POM_LAUNCH(16, 4);
+    else if (h->quad) fresh ? POM_LAUNCH_Q(true, false, false) : POM_LAUNCH_Q(false, false, false);
     else POM_LAUNCH(16, 1);
 #undef POM_LAUNCH_Q
 #undef POM_LAUNCH

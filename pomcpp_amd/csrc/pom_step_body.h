@@ -67,6 +67,17 @@
 #else
 #define POM_STAMP(L, k) ((void)0)
 #endif
+/* POM_TRUNC (diagnostic build, never shipped, results are wrong by design): the tick stops after phase L.trunc, so that the
+ * instruction counters of ONE truncated launch minus those of the next shorter one give a phase's dynamic instruction count
+ * (scripts/phase_insts.py) */
+#if defined(POM_TRUNC)
+#define POM_CUT(L, k)                 \
+    do {                              \
+        if ((L).trunc <= (k)) return; \
+    } while (0)
+#else
+#define POM_CUT(L, k) ((void)0)
+#endif
 enum { POM_PH_LOAD = 0, POM_PH_FLAMES, POM_PH_AGENT_PREP, POM_PH_AGENT_LOOP, POM_PH_BOMB_PASS, POM_PH_BOMB_A, POM_PH_BOMB_B,
        POM_PH_TICK_BOMBS, POM_PH_EPILOGUE, POM_PH_STORE,
        POM_PH_X_SCAN, POM_PH_X_COMMIT, POM_PH_X_EPILOGUE, POM_PH_X_NEST, POM_PH_X_SHORT, POM_PH_RESTART, POM_PH_FLAMES_DEC, POM_PH_N }; /* X_*: inside explode_long / explode (their time is NOT in the phase that called them) */
@@ -78,6 +89,9 @@ struct PomLane { /* the register-resident part of one env */
     uint32_t ub;
 #if defined(POM_DIAG)
     long long t_last, t_acc[POM_PH_N];
+#endif
+#if defined(POM_TRUNC)
+    int trunc;
 #endif
 };
 
@@ -874,8 +888,10 @@ struct PomStepper {
         int ftop, fn, btop, bn;
         flames_dec(ftop, fn); /* step.cpp:15 */
         POM_STAMP(L, POM_PH_FLAMES_DEC);
+        POM_CUT(L, 1);
         flame_pops(ftop, fn);
         POM_STAMP(L, POM_PH_FLAMES);
+        POM_CUT(L, 2);
         step_middle(mvp, btop, bn);
         top_explosions(btop, bn);
         POM_STAMP(L, POM_PH_TICK_BOMBS);
@@ -1017,6 +1033,7 @@ struct PomStepper {
         }
         on_bomb = a.gor(on_bomb);
         POM_STAMP(L, POM_PH_AGENT_PREP);
+        POM_CUT(L, 3);
         /* agent loop, step.cpp:35-185 */
         int agents_done = 0;
         if (A::G == 4) {
@@ -1262,6 +1279,7 @@ struct PomStepper {
         }
 
         POM_STAMP(L, POM_PH_AGENT_LOOP);
+        POM_CUT(L, 4);
         if (L.bCnt > 0) {
             /* ResetBombFlags + FillBombDestPos, step_utility.cpp:331-337,146-152.  The same pass notes whether any
              * bomb of this env is moving and whether two bombs share a cell (121-bit occupancy in 4 registers):
@@ -1336,6 +1354,7 @@ struct PomStepper {
              * brings onto another resting bomb has position == old position there and is not bounced, so no bomb outside the
              * noted set can come to matter during the loop.)  With a moving bomb in the queue the whole loop runs. */
             POM_STAMP(L, POM_PH_BOMB_PASS);
+            POM_CUT(L, 5);
             int next = 0; /* loop A is done for the offsets below `next` */
             if (!moving) {
                 irregular_ = 0;
@@ -1353,6 +1372,7 @@ struct PomStepper {
             POM_NOUNROLL
             for (int k = next; k < L.bCnt; k++) loop_a_bomb(mvp, oldp, k, moving);
             POM_STAMP(L, POM_PH_BOMB_A);
+            POM_CUT(L, 6);
             /* bomb loop B, step.cpp:230-278 */
             touched |= moving | shared | ripe;
             /* While no bomb moves and no two share a cell, HasBombCollision is false for every bomb and each one "moves" onto its
@@ -1425,6 +1445,7 @@ struct PomStepper {
                 explode(pb_x(jb), pb_y(jb), owner_strength(jb), j);
             }
             POM_STAMP(L, POM_PH_BOMB_B);
+            POM_CUT(L, 7);
             /* TickBombs, step_utility.cpp:224-245, first half: the timers were decremented in the pass above, except the marked
              * ones (cold: only states with out-of-order timers have them) */
             if (late) {

@@ -1,0 +1,29 @@
+#!/bin/bash
+# scripts/phase_insts.sh <out dir> [phase_insts.py args] — one rocprofv3 --pmc run per cut; prints the per-phase differences
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$1; shift
+case $OUT in /*) ;; *) OUT=$REPO/$OUT ;; esac
+mkdir -p $OUT
+python3 $REPO/scripts/phase_insts.py --build-only || exit 1
+cd /tmp && export TMPDIR=/tmp
+for CUT in 0 1 2 3 4 5 6 7 99; do
+  export POM_TRUNC_CUT=$CUT
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $OUT/cut$CUT -- python3 $REPO/scripts/phase_insts.py "$@" > $OUT/cut$CUT.log 2>&1 || { echo "cut $CUT failed"; tail -3 $OUT/cut$CUT.log; exit 1; }
+done
+python3 - $OUT <<'PY'
+import csv, glob, sys
+names = {0: "before the tick (load, restarts, move draw) + epilogue + store", 1: "flame timers", 2: "flame pops", 3: "agent prep", 4: "agent loop", 5: "bomb reset / classify pass",
+         6: "bomb loop A", 7: "bomb loop B", 99: "timer epilogue + top explosions"}
+prev = None
+for cut in (0, 1, 2, 3, 4, 5, 6, 7, 99):
+    f = glob.glob(f"{sys.argv[1]}/cut{cut}/*/*counter_collection.csv")[0]
+    rows = [r for r in csv.DictReader(open(f)) if "pom_step_kernel" in r["Kernel_Name"]]
+    last = max(int(r["Dispatch_Id"]) for r in rows)
+    c = {r["Counter_Name"]: float(r["Counter_Value"]) for r in rows if int(r["Dispatch_Id"]) == last}
+    w = c["SQ_WAVES"]
+    cur = {k: c[k] / w for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES")}
+    d = cur if prev is None else {k: cur[k] - prev[k] for k in cur}
+    print(f"{names[cut]:64s} VALU {d['SQ_INSTS_VALU']:8.1f}  SALU {d['SQ_INSTS_SALU']:8.1f}  LDS {d['SQ_INSTS_LDS']:6.1f}  wave-cycles x4 {d['SQ_WAVE_CYCLES'] * 4:9.0f}   (per wavefront)")
+    prev = cur
+print(f"{'whole tick':64s} VALU {prev['SQ_INSTS_VALU']:8.1f}  SALU {prev['SQ_INSTS_SALU']:8.1f}  LDS {prev['SQ_INSTS_LDS']:6.1f}  wave-cycles x4 {prev['SQ_WAVE_CYCLES'] * 4:9.0f}")
+PY
