@@ -60,8 +60,8 @@ struct LdsEnv {
     __device__ int sub() const { return G == 1 ? 0 : sub_; }
     __device__ bool owner() const { return G == 1 || sub_ == 0; }
     /* quad reductions: lane ^ 1, then lane ^ 2 */
-    __device__ static int dpp_x1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false); }
-    __device__ static int dpp_x2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false); }
+    __device__ static int dpp_x1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
+    __device__ static int dpp_x2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); }
     __device__ int gor(int v) const
     {
         if (G == 1) return v;
@@ -78,7 +78,7 @@ struct LdsEnv {
     __device__ int gbcast(int v) const /* the value held by member J of the quad */
     {
         if (G == 1) return v;
-        return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xF, 0xF, false);
+        return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xF, 0xF, true);
     }
     __device__ int gmin(int v) const
     {
@@ -1502,7 +1502,7 @@ static int fill_params(PomBatch* h, StepParams& p, const int32_t* moves_dev, uin
     p.moves = moves_dev;
     p.wave_counters = h->wave_counters;
 #if defined(POM_TRUNC)
-    p.trunc = getenv("POM_TRUNC_AT") ? atoi(getenv("POM_TRUNC_AT")) : 99;
+    p.trunc = getenv("POM_TRUNC_AT") ? atoi(getenv("POM_TRUNC_AT")) : 990;
 #endif
     p.n = h->n;
     p.n_pad = h->n_pad;

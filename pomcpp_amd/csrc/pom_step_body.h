@@ -130,7 +130,8 @@ POM_HD int sel4(int i, const int v[4])
     POM_IN_VGPR(v1);
     POM_IN_VGPR(v2);
     POM_IN_VGPR(v3);
-    return i == 0 ? v0 : i == 1 ? v1 : i == 2 ? v2 : v3;
+    const int lo = (i & 1) ? v1 : v0, hi = (i & 1) ? v3 : v2; /* two levels of selects: three v_cndmask, no branches */
+    return (i & 2) ? hi : lo;
 }
 POM_HD void put4(int i, int v[4], int x)
 {
@@ -888,10 +889,10 @@ struct PomStepper {
         int ftop, fn, btop, bn;
         flames_dec(ftop, fn); /* step.cpp:15 */
         POM_STAMP(L, POM_PH_FLAMES_DEC);
-        POM_CUT(L, 1);
+        POM_CUT(L, 10);
         flame_pops(ftop, fn);
         POM_STAMP(L, POM_PH_FLAMES);
-        POM_CUT(L, 2);
+        POM_CUT(L, 20);
         step_middle(mvp, btop, bn);
         top_explosions(btop, bn);
         POM_STAMP(L, POM_PH_TICK_BOMBS);
@@ -970,6 +971,7 @@ struct PomStepper {
                                            ((((dstp >> (8 * i + 4)) & 0xF) - 1) & 0xF) == ((oldp >> (8 * j + 4)) & 0xF);
         }
         oldp_ = oldp;
+        POM_CUT(L, 24);
         if (contact) {
             int px[4], py[4], dx[4], dy[4];
 #pragma unroll
@@ -1015,6 +1017,7 @@ struct PomStepper {
 #pragma unroll
             for (int i = 0; i < 4; i++) dstp |= (uint32_t)(((dx[i] + 1) & 0xF) | (((dy[i] + 1) & 0xF) << 4)) << (8 * i);
         }
+        POM_CUT(L, 27);
         const int ouroboros = nroots == 0;
         int posb[4]; /* the agents' position bytes (x | y << 4) */
 #pragma unroll
@@ -1033,7 +1036,7 @@ struct PomStepper {
         }
         on_bomb = a.gor(on_bomb);
         POM_STAMP(L, POM_PH_AGENT_PREP);
-        POM_CUT(L, 3);
+        POM_CUT(L, 30);
         /* agent loop, step.cpp:35-185 */
         int agents_done = 0;
         if (A::G == 4) {
@@ -1279,7 +1282,7 @@ struct PomStepper {
         }
 
         POM_STAMP(L, POM_PH_AGENT_LOOP);
-        POM_CUT(L, 4);
+        POM_CUT(L, 40);
         if (L.bCnt > 0) {
             /* ResetBombFlags + FillBombDestPos, step_utility.cpp:331-337,146-152.  The same pass notes whether any
              * bomb of this env is moving and whether two bombs share a cell (121-bit occupancy in 4 registers):
@@ -1354,7 +1357,7 @@ struct PomStepper {
              * brings onto another resting bomb has position == old position there and is not bounced, so no bomb outside the
              * noted set can come to matter during the loop.)  With a moving bomb in the queue the whole loop runs. */
             POM_STAMP(L, POM_PH_BOMB_PASS);
-            POM_CUT(L, 5);
+            POM_CUT(L, 50);
             int next = 0; /* loop A is done for the offsets below `next` */
             if (!moving) {
                 irregular_ = 0;
@@ -1372,7 +1375,7 @@ struct PomStepper {
             POM_NOUNROLL
             for (int k = next; k < L.bCnt; k++) loop_a_bomb(mvp, oldp, k, moving);
             POM_STAMP(L, POM_PH_BOMB_A);
-            POM_CUT(L, 6);
+            POM_CUT(L, 60);
             /* bomb loop B, step.cpp:230-278 */
             touched |= moving | shared | ripe;
             /* While no bomb moves and no two share a cell, HasBombCollision is false for every bomb and each one "moves" onto its
@@ -1445,7 +1448,7 @@ struct PomStepper {
                 explode(pb_x(jb), pb_y(jb), owner_strength(jb), j);
             }
             POM_STAMP(L, POM_PH_BOMB_B);
-            POM_CUT(L, 7);
+            POM_CUT(L, 70);
             /* TickBombs, step_utility.cpp:224-245, first half: the timers were decremented in the pass above, except the marked
              * ones (cold: only states with out-of-order timers have them) */
             if (late) {

@@ -32,6 +32,6 @@ env = B.BatchEnvironment(a.envs, mode=B.MODE_ENV, auto_reset=True, max_steps=800
 env.make_game(pa.make_boards(a.envs, seed=1000003, kind=a.kind))
 env.step_random(1, a.dist, ticks=a.burn)
 env.sync()
-os.environ["POM_TRUNC_AT"] = os.environ.get("POM_TRUNC_CUT", "99")
+os.environ["POM_TRUNC_AT"] = os.environ.get("POM_TRUNC_CUT", "990")
 env.step_random(1, a.dist, ticks=1)
 env.sync()

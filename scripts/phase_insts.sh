@@ -6,16 +6,17 @@ case $OUT in /*) ;; *) OUT=$REPO/$OUT ;; esac
 mkdir -p $OUT
 python3 $REPO/scripts/phase_insts.py --build-only || exit 1
 cd /tmp && export TMPDIR=/tmp
-for CUT in 0 1 2 3 4 5 6 7 99; do
+for CUT in 0 10 20 24 27 30 40 50 60 70 990; do
   export POM_TRUNC_CUT=$CUT
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $OUT/cut$CUT -- python3 $REPO/scripts/phase_insts.py "$@" > $OUT/cut$CUT.log 2>&1 || { echo "cut $CUT failed"; tail -3 $OUT/cut$CUT.log; exit 1; }
 done
 python3 - $OUT <<'PY'
 import csv, glob, sys
-names = {0: "before the tick (load, restarts, move draw) + epilogue + store", 1: "flame timers", 2: "flame pops", 3: "agent prep", 4: "agent loop", 5: "bomb reset / classify pass",
-         6: "bomb loop A", 7: "bomb loop B", 99: "timer epilogue + top explosions"}
+names = {0: "before the tick (load, restarts, move draw) + epilogue + store", 10: "flame timers", 20: "flame pops", 24: "agent prep: positions, destinations, contact test",
+         27: "agent prep: FixSwitchMove / ResolveDependencies (contact only)", 30: "agent prep: bombs under agents", 40: "agent loop", 50: "bomb reset / classify pass",
+         60: "bomb loop A", 70: "bomb loop B", 990: "timer epilogue + top explosions"}
 prev = None
-for cut in (0, 1, 2, 3, 4, 5, 6, 7, 99):
+for cut in (0, 10, 20, 24, 27, 30, 40, 50, 60, 70, 990):
     f = glob.glob(f"{sys.argv[1]}/cut{cut}/*/*counter_collection.csv")[0]
     rows = [r for r in csv.DictReader(open(f)) if "pom_step_kernel" in r["Kernel_Name"]]
     last = max(int(r["Dispatch_Id"]) for r in rows)
