@@ -148,6 +148,14 @@ POM_HD int ag_setpos(int a0, int x, int y) { return (a0 & ~0xFFFF) | x | (y << 8
 POM_HD int ag_bombcount_add(int a0, int d) { return (a0 & ~0xFF0000) | ((a0 + (d << 16)) & 0xFF0000); }
 
 POM_HD int wrap20(int p) { return p >= POM_Q ? p - POM_Q : p; } /* p < 40 */
+POM_HD int div11(int c) /* c / 11 for a cell index (exact for 0 <= c < 586): one full-rate multiply instead of v_mul_hi_u32's four passes */
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(c, 373) >> 12;
+#else
+    return c / POM_N;
+#endif
+}
 POM_HD int oob(int x, int y) { return (unsigned)x >= (unsigned)POM_N || (unsigned)y >= (unsigned)POM_N; }
 
 /* displacement of a Move / Direction (step_utility.cpp:9-31): 1 up(-y) 2 down(+y) 3 left(-x) 4 right(+x) */
@@ -274,7 +282,12 @@ struct PomStepper {
     POM_HD void flame_prologue(int x, int y, int strength, int e /* the origin cell, as it shows now */)
     {
         int slot = L.fIdx + L.fCnt; /* NextPos(): (index + count) % 20, count may exceed 20 (see tick_flames) */
-        slot = slot >= 2 * POM_Q ? slot % POM_Q : wrap20(slot);
+        if (__builtin_expect(slot >= 2 * POM_Q, 0)) { /* only with more than 20 flames queued; a loop so that no division is speculated */
+            POM_NOUNROLL
+            while (slot >= POM_Q) slot -= POM_Q;
+        } else {
+            slot = wrap20(slot);
+        }
         a.set_flame(slot, x | (y << 8) | (POM_FLAME_LIFETIME << 16) | ((strength & 0xFF) << 24));
         L.fCnt++;
         const int c = y * POM_N + x;
@@ -297,10 +310,26 @@ struct PomStepper {
         }
     }
 
-    POM_HD static int ray_cell(int c0, int dir, int i) { return c0 + (dir == 0 ? i : dir == 1 ? -i : dir == 2 ? POM_N * i : -POM_N * i); }
+    /* rays 0..3 = +x, -x, +y, -y.  Selects on the two bits of the ray number, not a ternary chain: with the ray number a lane's
+     * own (lane r of a quad takes ray r) hipcc turns the chain into nested exec-mask branches — 20 scalar instructions and
+     * three jumps for one multiply. */
+    POM_HD static int ray_step(int dir)
+    {
+        const int mag = (dir & 2) ? POM_N : 1;
+        return (dir & 1) ? -mag : mag;
+    }
+    POM_HD static int ray_cell(int c0, int dir, int i)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return c0 + __mul24(i, ray_step(dir)); /* v_mad_i32_i24: full rate (v_mul_lo_u32 takes four passes) */
+#else
+        return c0 + i * ray_step(dir);
+#endif
+    }
     POM_HD static int ray_room(int x, int y, int s, int dir)
     {
-        const int room = dir == 0 ? POM_N - 1 - x : dir == 1 ? x : dir == 2 ? POM_N - 1 - y : y;
+        const int v = (dir & 2) ? y : x;
+        const int room = (dir & 1) ? v : POM_N - 1 - v;
         return room < s ? room : s;
     }
 
@@ -345,7 +374,7 @@ struct PomStepper {
                     const int e = a.cell(c);
                     if (e == POM_C_BOMB || pc_is_agent(e)) {
                         /* SpawnFlameItem explodes the first queued bomb on this cell, if there is one (bboard.cpp:30-40) */
-                        const int cy = c / POM_N;
+                        const int cy = div11(c);
                         if (bomb_index_alone((c - cy * POM_N) | (cy << 4)) >= 0) {
                             chains = 1;
                             break;
@@ -578,7 +607,7 @@ struct PomStepper {
                     scan_ray(c0, r, rs1, ray_room(x, y, s, r), occ, len1, ends1, wood1, vict1, chain1, info1);
                     if (chain1) {
                         const int c = ray_cell(c0, r, chain1);
-                        const int cy = c / POM_N;
+                        const int cy = div11(c);
                         jq = bomb_index((c - cy * POM_N) | (cy << 4));
                         if (jq < 0) { /* the set was too large here: strike the cell and look at this ray again */
                             const uint32_t m = ~(1u << (c & 31));
@@ -612,7 +641,7 @@ struct PomStepper {
             rstar = first == 0x7FFFFFFF ? 4 : first >> 16;
             if (rstar < 4) { /* the cell the look settled on: which bomb is it? */
                 const int c = ray_cell(c0, rstar, (first >> 12) & 0xF);
-                const int cy = c / POM_N;
+                const int cy = div11(c);
                 jq = bomb_index_wide((c - cy * POM_N) | (cy << 4));
                 if (jq < 0) { /* none any more (the set is only ever too large): strike the cell and look again */
                     const uint32_t m = ~(1u << (c & 31));
@@ -670,7 +699,7 @@ struct PomStepper {
             sp++;
             const int st2 = owner_strength(bomb_at(jq));
             const int c = ray_cell(c0, rstar, d);
-            y = c / POM_N;
+            y = div11(c);
             x = c - y * POM_N;
             rem = jq;
             flame_prologue(x, y, st2);
