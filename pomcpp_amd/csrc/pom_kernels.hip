@@ -483,7 +483,8 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                 if (POLICY) {
                     mine = mv_own;
                 } else if (p.moves) { /* explicit moves: one tick per launch */
-                    mine = member == 0 ? moves0.x : member == 1 ? moves0.y : member == 2 ? moves0.z : moves0.w;
+                    const int lo = (member & 1) ? moves0.y : moves0.x, hi = (member & 1) ? moves0.w : moves0.z;
+                    mine = (member & 2) ? hi : lo;
                 } else {
                     const uint64_t r = tk == 0 ? draw0 : pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick0 + (uint32_t)tk);
                     mine = pom_rng_pick((uint32_t)(r >> (16 * member)) & 0xFFFFu, p.dist);

@@ -153,8 +153,8 @@ struct PomCells {
     POM_HD int has(int c) const
     {
         const int k = c >> 5;
-        const uint32_t v = k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : w[3];
-        return (int)((v >> (c & 31)) & 1u);
+        const uint32_t lo = (k & 1) ? w[1] : w[0], hi = (k & 1) ? w[3] : w[2]; /* two levels of selects, not a chain of branches */
+        return (int)((((k & 2) ? hi : lo) >> (c & 31)) & 1u);
     }
     POM_HD void add(int c)
     {

@@ -133,6 +133,11 @@ POM_HD int sel4(int i, const int v[4])
     const int lo = (i & 1) ? v1 : v0, hi = (i & 1) ? v3 : v2; /* two levels of selects: three v_cndmask, no branches */
     return (i & 2) ? hi : lo;
 }
+POM_HD uint32_t pick4(int i, const uint32_t v[4]) /* v[i], i in 0..3, as two levels of selects (a ternary chain on a lane-varying i becomes branches) */
+{
+    const uint32_t lo = (i & 1) ? v[1] : v[0], hi = (i & 1) ? v[3] : v[2];
+    return (i & 2) ? hi : lo;
+}
 POM_HD void put4(int i, int v[4], int x)
 {
     v[0] = i == 0 ? x : v[0];
@@ -417,8 +422,7 @@ struct PomStepper {
             if (!resume) { /* skip exhausted rays: length s or the board edge, whichever is nearer */
                 POM_NOUNROLL
                 for (; dir < 4; dir++, i = 1) {
-                    const int room = dir == 0 ? POM_N - 1 - x : dir == 1 ? x : dir == 2 ? POM_N - 1 - y : y;
-                    if (i <= (room < s ? room : s)) break;
+                    if (i <= ray_room(x, y, s, dir)) break;
                 }
             }
             if (dir >= 4) { /* all four rays done: the caller's bookkeeping, then back into the parent */
@@ -430,8 +434,9 @@ struct PomStepper {
                 dir = (fr >> 12) & 7; i = (fr >> 15) & 0xF; rem = (fr >> 19) & 63;
                 resume = 1; /* continue inside SpawnFlameItem, after its ExplodeBombAt */
             }
-            const int cx = x + (dir == 0 ? i : dir == 1 ? -i : 0);
-            const int cy = y + (dir == 2 ? i : dir == 3 ? -i : 0);
+            const int st = (dir & 1) ? -i : i; /* selects on the bits of the ray number, see ray_step */
+            const int cx = x + ((dir & 2) ? 0 : st);
+            const int cy = y + ((dir & 2) ? st : 0);
             const int c = cy * POM_N + cx;
             const int e = a.cell(c); /* on resume: re-read, the nested chain may have changed the cell */
             if (!resume) { /* SpawnFlameItem head, bboard.cpp:26-40 */
@@ -508,8 +513,7 @@ struct PomStepper {
     POM_HD static int cell_in(const uint32_t occ[4], int c)
     {
         const int w = c >> 5;
-        const uint32_t v = w == 0 ? occ[0] : w == 1 ? occ[1] : w == 2 ? occ[2] : occ[3];
-        return (int)((v >> (c & 31)) & 1u);
+        return (int)((pick4(w, occ) >> (c & 31)) & 1u);
     }
     /* first queue offset whose bomb sits on pos, or -1 — bomb_index() with every lane's slots fetched at once */
     POM_HD int bomb_index_wide(int pos) const
@@ -1343,7 +1347,7 @@ struct PomStepper {
                 const int idx = pb_y(b) * POM_N + pb_x(b);
                 const int w = idx >> 5;
                 const uint32_t m = 1u << (idx & 31);
-                const uint32_t cur = w == 0 ? occ[0] : w == 1 ? occ[1] : w == 2 ? occ[2] : occ[3];
+                const uint32_t cur = pick4(w, occ);
                 shared |= (cur & m) != 0;
                 occ[0] |= w == 0 ? m : 0u;
                 occ[1] |= w == 1 ? m : 0u;
