@@ -288,6 +288,9 @@ struct PolicyStore {
     uint8_t* dcol;     /* &danger[env_in_wave], a byte per cell, row stride 16 */
     uint32_t* scol;    /* &sets[env_in_wave], row stride 16 */
     int who;           /* lane % 4 */
+#if defined(POM_TRUNC)
+    int trunc = 990;
+#endif
     __device__ int member() const { return who; }
     __device__ int danger(int c) const { return dcol[c * 16]; }
     __device__ void danger_init(int c) { dcol[c * 16] = (uint8_t)POM_DANGER_NONE; }
@@ -459,11 +462,21 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
             if (restarted) m0 = m1 = 0; /* a new game gets fresh agents */
             restarted = false;
             PolicyStore st{t, danger + ec, sets + ec, member};
+#if defined(POM_TRUNC)
+            st.trunc = p.trunc; /* cuts -4 .. -1: none of the policy, + clear, + fill, + safe (act and the tick skipped); 0: the whole policy */
+            if (active) {
+                if (p.trunc > -4) pom_policy_prepare_clear(st);
+                if (p.trunc > -3) pom_policy_prepare_fill(st, PomPolicyEnv{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {L.a1[0], L.a1[1], L.a1[2], L.a1[3]}, L.bIdx, L.bCnt});
+                if (p.trunc > -2) pom_policy_prepare_safe(st);
+            }
+            if (p.trunc > -1)
+#else
             if (active) { /* all four lanes of the env, dead agents' lanes included */
                 pom_policy_prepare_clear(st);
                 pom_policy_prepare_fill(st, PomPolicyEnv{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {L.a1[0], L.a1[1], L.a1[2], L.a1[3]}, L.bIdx, L.bCnt});
                 pom_policy_prepare_safe(st);
             }
+#endif
             if (active && !ag_dead(sel4(member, L.a0))) { /* act() is only asked of live agents, environment.cpp:139-146 */
                 const PomPolicyEnv E{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {L.a1[0], L.a1[1], L.a1[2], L.a1[3]}, L.bIdx, L.bCnt};
                 PomSimplePolicy<PolicyStore> pol(st, E, member, m0, m1);

@@ -439,6 +439,9 @@ struct PomSimplePolicy {
         int adj1 = adjacent_enemy(1), near = adjacent_enemy(7), looping = has_rp_loop();
         POM_DUP(6, (adj1 = adjacent_enemy(1) + 2 * adjacent_enemy(7) + 4 * has_rp_loop()), adj1);
         POM_PSTAMP(POM_PP_PREDICATES);
+#if defined(POM_TRUNC)
+        if (p.trunc <= 1) return (adj1 | near | looping | danger | can_bomb) & 1; /* diagnostic build: keep the predicates alive */
+#endif
         /* Which cell, if any, does this decision want a path to?  In danger: the first safe reachable cell of the scan window
          * (needs the reachable set); else, allowed to bomb, an enemy within 7 and nothing more urgent: that enemy.  The path
          * question itself is then asked at ONE program point for both kinds of agents of the wavefront. */
@@ -453,13 +456,19 @@ struct PomSimplePolicy {
             target = enemy_cell(7);
         }
         POM_PSTAMP(POM_PP_TARGET);
+#if defined(POM_TRUNC)
+        if (p.trunc <= 2) return target & 1;
+#endif
         int mv = POM_MOVE_IDLE;
         if (target >= 0) {
-            const int ty = target / POM_N;
+            const int ty = div11(target);
             POM_DUP(4, mv = move_towards(target - ty * POM_N, ty), mv);
             mv = move_towards(target - ty * POM_N, ty);
         }
         POM_PSTAMP(POM_PP_PATH);
+#if defined(POM_TRUNC)
+        if (p.trunc <= 3) return mv;
+#endif
         /* the three ways out of _Decide that do not end in _MoveSafeOneSpace's tail; everything else falls through to it, at
          * one program point (three inlined copies under three lane masks would cost the wavefront three times) */
         const int px = sx + mv_dx(mv), py = sy + mv_dy(mv);

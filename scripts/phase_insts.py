@@ -17,6 +17,7 @@ ap.add_argument("--kind", default="ffa")
 ap.add_argument("--dist", type=int, default=1)
 ap.add_argument("--burn", type=int, default=300)
 ap.add_argument("--build-only", action="store_true")
+ap.add_argument("--policy", action="store_true", help="4x SimpleAgent fused with the tick (fresh boards)")
 a = ap.parse_args()
 lib = os.path.join(ROOT, "build", "libpom_batch_trunc.so")
 if a.build_only or not os.path.exists(lib):
@@ -28,10 +29,18 @@ if a.build_only or not os.path.exists(lib):
 import pomcpp_amd.batch as B
 B.library_path = lambda: lib
 import pomcpp_amd as pa
-env = B.BatchEnvironment(a.envs, mode=B.MODE_ENV, auto_reset=True, max_steps=800, streams=1)
-env.make_game(pa.make_boards(a.envs, seed=1000003, kind=a.kind))
-env.step_random(1, a.dist, ticks=a.burn)
+if a.policy:
+    env = B.BatchEnvironment(a.envs, mode=B.MODE_ENV, auto_reset=True, max_steps=800, streams=1, fresh_boards=True, board_seed=1)
+    env.generate(1)
+    env.step_simple(1, a.burn)
+else:
+    env = B.BatchEnvironment(a.envs, mode=B.MODE_ENV, auto_reset=True, max_steps=800, streams=1)
+    env.make_game(pa.make_boards(a.envs, seed=1000003, kind=a.kind))
+    env.step_random(1, a.dist, ticks=a.burn)
 env.sync()
 os.environ["POM_TRUNC_AT"] = os.environ.get("POM_TRUNC_CUT", "990")
-env.step_random(1, a.dist, ticks=1)
+if a.policy:
+    env.step_simple(1, 1)
+else:
+    env.step_random(1, a.dist, ticks=1)
 env.sync()
