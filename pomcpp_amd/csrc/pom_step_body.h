@@ -397,7 +397,8 @@ struct PomStepper {
             }
             if (__builtin_expect(!a.gor(chains), 1)) {
                 flame_prologue(x, y, strength, e0);
-                kill_set(a.gor(victims)); /* Kill, bboard.hpp:474-481, for every agent a ray met */
+                const int killed = a.gor(victims);
+                if (killed) kill_set(killed); /* Kill, bboard.hpp:474-481, for every agent a ray met */
                 POM_NOUNROLL
                 for (int r = a.sub(); r < 4; r += A::G) { /* no reads: the scan has seen every cell it writes */
                     const int len = (lens >> (4 * r)) & 0xF;
@@ -1324,6 +1325,7 @@ struct PomStepper {
             int ripe = 0; /* some bomb's own cell shows PASSAGE or a flame: the only cells loop B's resting case acts on */
             uint32_t cand = 0; /* queue offsets of the resting bombs under an agent that walked onto them this tick */
             uint32_t occ[4] = {0, 0, 0, 0};
+            int mine = 0;
             /* TickBombs' timer decrement (step_utility.cpp:226-231) is folded into this pass: nothing between here and TickBombs
              * reads a timer, and loops A / B only replace the position and direction fields of a word, which commutes with
              * `- (1 << 16)` as long as that does not borrow.  A bomb whose timer is already 0 (out-of-order timers)
@@ -1349,6 +1351,7 @@ struct PomStepper {
                 const uint32_t m = 1u << (idx & 31);
                 const uint32_t cur = pick4(w, occ);
                 shared |= (cur & m) != 0;
+                mine += (cur & m) == 0; /* |my cell set| */
                 occ[0] |= w == 0 ? m : 0u;
                 occ[1] |= w == 1 ? m : 0u;
                 occ[2] |= w == 2 ? m : 0u;
@@ -1368,21 +1371,22 @@ struct PomStepper {
                     }
                 }
             }
-            cand = (uint32_t)a.gor((int)cand);
-            ripe = a.gor(ripe);
-            late = a.gor(late);
+            if (A::G > 1) {
+                /* one quad reduction for all the flags: cand (offsets 0..19) | ripe | late | shared | moving */
+                const uint32_t fl = (uint32_t)a.gor((int)(cand | ((uint32_t)ripe << 20) | ((uint32_t)late << 21) | ((uint32_t)shared << 22) |
+                                                          ((uint32_t)moving << 23)));
+                cand = fl & 0xFFFFFu;
+                ripe = (int)((fl >> 20) & 1u);
+                late = (int)((fl >> 21) & 1u);
+                moving = (int)((fl >> 23) & 1u);
+                /* two lanes' bombs share a cell iff the lanes' cell sets overlap: |union| < sum of |set| */
+                int all = 0;
+#pragma unroll
+                for (int w = 0; w < 4; w++) all += __builtin_popcount((uint32_t)a.gor((int)occ[w]));
+                shared = (int)((fl >> 22) & 1u) | (a.gadd(mine) != all);
+            }
             folded_ = 1;
             int touched = cand != 0; /* did anything after the pass get to write the queue?  (then its head is read again) */
-            if (A::G > 1) { /* two lanes' bombs share a cell iff the lanes' cell sets overlap: |union| < sum of |set| */
-                int mine = 0, all = 0;
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    mine += __builtin_popcount(occ[w]);
-                    all += __builtin_popcount((uint32_t)a.gor((int)occ[w]));
-                }
-                shared = a.gor(shared) | (a.gadd(mine) != all);
-                moving = a.gor(moving);
-            }
             /* bomb loop A, step.cpp:195-227.  A resting bomb's "target" is its own cell: it is blocked iff an agent item (or,
              * never in practice, a static item) shows there; setting an idle bomb idle changes nothing, so while no bomb moves
              * the loop only matters for the bombs noted above, whose agent has to be bounced back — and only those are
