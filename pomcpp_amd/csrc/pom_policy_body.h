@@ -399,12 +399,18 @@ struct PomSimplePolicy {
     {
         const int moves = mq_count();
         int removes = 0;
+        /* "is this cell one of the recent positions" on all four bytes of m0 at once: 0x80 in every byte that holds a live entry
+         * (slots index .. index + count - 1, cyclically), and an exact zero-byte test of m0 ^ key-in-every-byte */
+        const int rc = rp_count(), rsh = 8 * rp_index();
+        const uint32_t live0 = rc >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * rc)) - 1u));
+        const uint32_t live = (live0 << rsh) | (rsh ? live0 >> (32 - rsh) : 0u);
         POM_NOUNROLL
         for (int i = 0; i < moves && removes < 4; i++) {
             const int mv = mq_at(i);
             const int key = pos_key(sx + mv_dx(mv), sy + mv_dy(mv));
-            int hit = 0;
-            for (int j = 0; j < 4; j++) hit |= (j < rp_count()) & (rp_key(j) == key);
+            const uint32_t x = m0 ^ ((uint32_t)key * 0x01010101u);
+            const uint32_t zero = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); /* 0x80 exactly in the bytes of x that are 0 */
+            const int hit = (zero & live) != 0u;
             if (hit) {
                 POM_NOUNROLL
                 for (int k = i + 1; k < mq_count(); k++) mq_set((k - 1) & 3, mq_at(k)); /* RemoveAt(i) */
