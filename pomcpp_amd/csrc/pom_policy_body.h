@@ -266,8 +266,14 @@ struct PomSimplePolicy {
         const int v = p.danger(y * POM_N + x);
         return v == POM_DANGER_NONE ? 0 : v;
     }
-    POM_HD static int safe(int danger, int min) { return danger == 0 || danger >= min; } /* _safe_condition, strategy.cpp:199-202 */
-    POM_HD int walkable_at(int x, int y) const { return !oob(x, y) && pc_is_walkable(p.cell(y * POM_N + x)); } /* _CheckPos */
+    POM_HD static int safe(int danger, int min) { return (int)(danger == 0) | (int)(danger >= min); } /* _safe_condition, strategy.cpp:199-202 */
+    POM_HD int walkable_at(int x, int y) const /* _CheckPos */
+    {
+        if (oob(x, y)) return 0;
+        int w = pc_is_walkable(p.cell(y * POM_N + x));
+        POM_IN_VGPR(w); /* an opaque value: hipcc otherwise splits the range test into a chain of exec-mask branches at every use */
+        return w;
+    }
 
     /* (a) FillRMap, strategy.cpp:59-93: which cells get a distance.  A cell can be entered if it is walkable or holds an agent
      * (:43-44); the search continues only through walkable cells, agents are reached but not passed (:50-53). */
@@ -388,12 +394,24 @@ struct PomSimplePolicy {
         if (sy < POM_N - 1) r |= pc_is_wood(p.cell((sy + 1) * POM_N + sx));
         return r;
     }
+    /* _CheckPos(x, y) && _safe_condition(IsInDanger(x, y), 2) without a branch: off the board the cell index is clamped to
+     * the agent's own (both reads stay in the tile) and the answer masked */
+    POM_HD int step_is_safe(int x, int y) const
+    {
+        const int on = !oob(x, y);
+        const int c = on ? y * POM_N + x : sy * POM_N + sx;
+        const int dv = p.danger(c);
+        int ok = on & pc_is_walkable(p.cell(c)) & (int)(dv != 1); /* safe(danger, 2): no danger (map: 99, or a minimum of 0) or >= 2 */
+        POM_IN_VGPR(ok);
+        return ok;
+    }
     POM_HD void safe_directions() /* strategy.cpp:203-226 */
     {
-        if (walkable_at(sx + 1, sy) && safe(in_danger(sx + 1, sy), 2)) mq_add(POM_MOVE_RIGHT);
-        if (walkable_at(sx - 1, sy) && safe(in_danger(sx - 1, sy), 2)) mq_add(POM_MOVE_LEFT);
-        if (walkable_at(sx, sy + 1) && safe(in_danger(sx, sy + 1), 2)) mq_add(POM_MOVE_DOWN);
-        if (walkable_at(sx, sy - 1) && safe(in_danger(sx, sy - 1), 2)) mq_add(POM_MOVE_UP);
+        const int r = step_is_safe(sx + 1, sy), l = step_is_safe(sx - 1, sy), d = step_is_safe(sx, sy + 1), u = step_is_safe(sx, sy - 1);
+        if (r) mq_add(POM_MOVE_RIGHT);
+        if (l) mq_add(POM_MOVE_LEFT);
+        if (d) mq_add(POM_MOVE_DOWN);
+        if (u) mq_add(POM_MOVE_UP);
     }
     POM_HD void sort_directions() /* SortDirections, strategy.hpp:130-152, with FixedQueue::RemoveAt / AddElem on raw slots */
     {

@@ -96,12 +96,14 @@ struct PomLane { /* the register-resident part of one env */
 };
 
 /* ---- cell-code predicates (Item helpers, bboard.hpp:73-109, on 16-bit codes) */
+/* (bitwise | and one unsigned range compare, not || and &&: on lane-varying values hipcc turns the short-circuit forms into
+ * nested exec-mask branches) */
 POM_HD int pc_is_wood(int e) { return (e >> 8) == 2; }
-POM_HD int pc_is_powerup(int e) { return e > 5 && e < 9; }
-POM_HD int pc_is_walkable(int e) { return pc_is_powerup(e) || e == 0; }
+POM_HD int pc_is_powerup(int e) { return (unsigned)(e - 6) < 3u; }
+POM_HD int pc_is_walkable(int e) { return (int)pc_is_powerup(e) | (int)(e == 0); }
 POM_HD int pc_is_flame(int e) { return (e & 0xC000) == POM_C_FLAME; }
 POM_HD int pc_is_agent(int e) { return e >= POM_C_AGENT; }
-POM_HD int pc_is_static_block(int e) { return pc_is_wood(e) || pc_is_powerup(e) || e == 1; }
+POM_HD int pc_is_static_block(int e) { return (int)pc_is_wood(e) | (int)pc_is_powerup(e) | (int)(e == 1); }
 POM_HD int pc_flag_item(int f) { return f == 0 ? 0 : f + 5; } /* FlagItem, bboard.cpp:182-189: 1,2,3 -> 6,7,8 */
 
 /* ---- bomb word (bboard.hpp:261-335) */
