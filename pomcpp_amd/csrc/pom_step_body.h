@@ -155,6 +155,10 @@ POM_HD int ag_setpos(int a0, int x, int y) { return (a0 & ~0xFFFF) | x | (y << 8
 POM_HD int ag_bombcount_add(int a0, int d) { return (a0 & ~0xFF0000) | ((a0 + (d << 16)) & 0xFF0000); }
 
 POM_HD int wrap20(int p) { return p >= POM_Q ? p - POM_Q : p; } /* p < 40 */
+POM_HD uint32_t pom_zero_bytes(uint32_t x) /* 0x80 in exactly the bytes of x that are 0 */
+{
+    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
 POM_HD int div11(int c) /* c / 11 for a cell index (exact for 0 <= c < 586): one full-rate multiply instead of v_mul_hi_u32's four passes */
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -977,16 +981,15 @@ struct PomStepper {
             const int d8 = ((dxm + 1) & 0xF) | (((dym + 1) & 0xF) << 4);
             dstp = (uint32_t)a.template gbcast<0>(d8) | ((uint32_t)a.template gbcast<1>(d8) << 8) |
                    ((uint32_t)a.template gbcast<2>(d8) << 16) | ((uint32_t)a.template gbcast<3>(d8) << 24);
-            /* my destination as a position byte: off the board it carries a nibble 15 or 11, which no position has */
+            /* my destination as a position byte: off the board it carries a nibble 15 or 11, which no position has.  Both
+             * questions — is my destination somebody's cell; do I, alive, share my cell with a live agent — are asked of all
+             * four position bytes at once: an exact zero-byte test of oldp ^ (byte in every byte), my own byte masked out. */
             const uint32_t want = (uint32_t)((dxm & 0xF) | ((dym & 0xF) << 4));
-            int mine = 0; /* bit 0: my destination is somebody's cell; bit 1: I am alive and share my cell with a live agent */
-            const int alive_m = !ag_dead(av);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t pj = (oldp >> (8 * j)) & 0xFFu;
-                mine |= (j != m) & (pj == want);
-                mine |= ((j != m) & (pj == (uint32_t)pos8) & alive_m & !((deadmask >> j) & 1)) << 1;
-            }
+            const uint32_t others = ~(0x80u << (8 * m));
+            const uint32_t dead80 = (((uint32_t)deadmask * 0x00204081u) & 0x01010101u) << 7; /* 0x80 in the bytes of dead agents */
+            const uint32_t hit_d = pom_zero_bytes(oldp ^ (want * 0x01010101u)) & others;
+            const uint32_t hit_p = pom_zero_bytes(oldp ^ ((uint32_t)pos8 * 0x01010101u)) & others & ~dead80;
+            int mine = (int)(hit_d != 0u) | ((int)((hit_p != 0u) & !ag_dead(av)) << 1);
             mine = a.gor(mine);
             contact = mine & 1;
             clash = mine >> 1;
