@@ -360,15 +360,15 @@ struct PomStepper {
     {
         int s = strength < 0 ? 0 : strength > POM_N ? POM_N : strength;
         POM_STAMP(L, POM_PH_TICK_BOMBS); /* diagnostic builds: what ran before the blast is booked on the phase of the top explosions */
-        if (s > 2) { /* a long blast: no look-ahead, the segment engine takes ray after ray (explode_long) */
-            explode_long(x, y, strength, rem);
-            return;
-        }
         /* Split fast path.  Read-only scan of the four rays (lane `sub` takes rays sub, sub+G, ...): how far does
          * each reach, and does any of them touch a BOMB or an agent cell?  If none does, no chain and no kill can
          * happen along the rays, every cell belongs to exactly one ray, and the order +x,-x,+y,-y is immaterial:
          * the rays are then written in parallel.  Otherwise nothing has been written yet and the literal
          * sequential engine below runs (replicated). */
+        if (s > 2) { /* a long blast: no look-ahead, the segment engine takes ray after ray (explode_long) */
+            explode_long(x, y, strength, rem);
+            return;
+        }
         {
             const int c0 = y * POM_N + x;
             const int e0 = a.cell(c0); /* the origin, read together with the rays' first cells: nothing is written before the vote */
@@ -422,62 +422,8 @@ struct PomStepper {
                 return;
             }
         }
-        flame_prologue(x, y, strength);
-        int dir = 0, i = 1, sp = 0, resume = 0;
-        POM_NOUNROLL
-        for (;;) {
-            if (!resume) { /* skip exhausted rays: length s or the board edge, whichever is nearer */
-                POM_NOUNROLL
-                for (; dir < 4; dir++, i = 1) {
-                    if (i <= ray_room(x, y, s, dir)) break;
-                }
-            }
-            if (dir >= 4) { /* all four rays done: the caller's bookkeeping, then back into the parent */
-                explode_epilogue(rem);
-                if (sp == 0) return;
-                sp--;
-                const int fr = a.frame(sp);
-                x = fr & 0xF; y = (fr >> 4) & 0xF; s = (fr >> 8) & 0xF;
-                dir = (fr >> 12) & 7; i = (fr >> 15) & 0xF; rem = (fr >> 19) & 63;
-                resume = 1; /* continue inside SpawnFlameItem, after its ExplodeBombAt */
-            }
-            const int st = (dir & 1) ? -i : i; /* selects on the bits of the ray number, see ray_step */
-            const int cx = x + ((dir & 2) ? 0 : st);
-            const int cy = y + ((dir & 2) ? st : 0);
-            const int c = cy * POM_N + cx;
-            const int e = a.cell(c); /* on resume: re-read, the nested chain may have changed the cell */
-            if (!resume) { /* SpawnFlameItem head, bboard.cpp:26-40 */
-                if (pc_is_agent(e)) kill(e & 0x3FFF);
-                if (e == POM_C_BOMB || pc_is_agent(e)) {
-                    const int j = bomb_index(cx | (cy << 4));
-                    if (j >= 0) {
-                        if (sp >= POM_STACK_DEPTH) { /* cannot happen with <= 20 queued bombs */
-                            L.ub |= POM_UB_BAD_INDEX;
-                        } else {
-                            a.set_frame(sp, x | (y << 4) | (s << 8) | (dir << 12) | (i << 15) | (rem << 19));
-                            sp++;
-                            const int st2 = owner_strength(bomb_at(j));
-                            x = cx; y = cy; rem = j;
-                            flame_prologue(x, y, st2);
-                            s = st2 < 0 ? 0 : st2 > POM_N ? POM_N : st2;
-                            dir = 0;
-                            i = 1;
-                            continue;
-                        }
-                    }
-                }
-            }
-            resume = 0;
-            /* SpawnFlameItem tail, bboard.cpp:42-56 */
-            int go_on = 0;
-            if (e != POM_C_RIGID) {
-                const int was_wood = pc_is_wood(e);
-                a.set_cell(c, POM_C_FLAME | (((y * POM_N + x) << 3) + (was_wood ? (e & 3) : 0)));
-                go_on = !was_wood;
-            }
-            if (go_on) i++;
-            else { dir++; i = 1; }
-        }
+        /* a long blast, or a short one that meets a queued bomb (nothing has been written yet): the look-and-commit engine */
+        explode_long(x, y, strength, rem);
     }
 
     /* The cells on which a queued bomb sits, as a 121-bit set in four words (bit c = y * 11 + x): one look at every queue slot,
