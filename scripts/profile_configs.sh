@@ -29,7 +29,7 @@ for CFG in $WHICH; do
   echo "== $CFG: bench.py $ARGS"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
   if [ "$CFG" = head3 ]; then
-    tail -1 $OUT/trace.log > $OUT/bench_under_trace.json
+    grep "^{\"metric\"" $OUT/trace.log | tail -1 > $OUT/bench_under_trace.json  # (rocprofv3 prints its own lines after the program's)
     python3 $REPO/scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
     cat $OUT/summary.txt
     find $OUT -name "*kernel_trace.csv" -size +8M -delete
@@ -41,7 +41,7 @@ for CFG in $WHICH; do
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $REPO/bench.py $ARGS > $OUT/fetch.log 2>&1 || exit 1
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $REPO/bench.py $ARGS > $OUT/write.log 2>&1 || exit 1
   fi
-  tail -1 $OUT/trace.log > $OUT/bench_under_trace.json
+  grep "^{\"metric\"" $OUT/trace.log | tail -1 > $OUT/bench_under_trace.json  # (rocprofv3 prints its own lines after the program's)
   python3 $REPO/scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
   cat $OUT/summary.txt
   # keep the merge-back small: the raw traces are tens of MB
