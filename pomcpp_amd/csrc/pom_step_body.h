@@ -1038,24 +1038,30 @@ struct PomStepper {
             uint32_t rankp = 0x3210u, depthp = 0u; /* nibble per agent: position in the reference's visiting order, depth in his chain */
             int rounds = 1;
             if (par && nroots != 4) {
-                rankp = 0u;
-                int n = 0, md = 0;
+                /* lane ri walks the chain of root ri (dep[i] = who waits for agent i's cell); the chains' lengths, exchanged in
+                 * the quad, give every chain its first position in the visiting order */
+                const int ri = a.sub();
+                int i = ri < nroots ? (int)((roots >> (4 * ri)) & 0xF) : 0xF;
+                uint32_t dp = 0u, memb = 0u; /* my chain: depth per member, 0xF in the nibble of every member */
+                int len = 0;
 #pragma unroll
-                for (int ri = 0; ri < 4; ri++) {
-                    int i = ri < nroots ? (int)((roots >> (4 * ri)) & 0xF) : 0xF;
-#pragma unroll
-                    for (int d = 0; d < 4; d++) { /* down the chain of root ri: dep[i] = who waits for agent i's cell */
-                        const int on = i != 0xF;
-                        const int sh = 4 * (i & 3);
-                        rankp |= on ? (uint32_t)n << sh : 0u;
-                        depthp |= on ? (uint32_t)d << sh : 0u;
-                        md = (on && d > md) ? d : md;
-                        n += on;
-                        i = on ? (int)((dep >> sh) & 0xF) : 0xF;
-                    }
+                for (int d = 0; d < 4; d++) {
+                    const int on = i != 0xF;
+                    const int sh = 4 * (i & 3);
+                    dp |= on ? (uint32_t)d << sh : 0u;
+                    memb |= on ? 0xFu << sh : 0u;
+                    len += on;
+                    i = on ? (int)((dep >> sh) & 0xF) : 0xF;
                 }
-                par = n == 4; /* everybody is reached: nobody lost */
-                rounds = md + 1;
+                const int l0 = a.template gbcast<0>(len), l1 = a.template gbcast<1>(len), l2 = a.template gbcast<2>(len),
+                          l3 = a.template gbcast<3>(len);
+                const int b_lo = (ri & 1) ? l0 : 0, b_hi = (ri & 1) ? l0 + l1 + l2 : l0 + l1;
+                const int base = (ri & 2) ? b_hi : b_lo; /* the lengths of the chains before mine */
+                rankp = (uint32_t)a.gor((int)((dp + (uint32_t)base * 0x1111u) & memb)); /* depth <= 3, base <= 3: no carry between nibbles */
+                depthp = (uint32_t)a.gor((int)dp);
+                par = l0 + l1 + l2 + l3 == 4; /* everybody is reached: nobody lost */
+                const int m01 = l0 > l1 ? l0 : l1, m23 = l2 > l3 ? l2 : l3;
+                rounds = m01 > m23 ? m01 : m23; /* the longest chain */
             }
             if (par) {
                 agents_done = 1;
