@@ -47,3 +47,7 @@ for k, n in enumerate(names):
     print(f"  {n:12s} mean {c.mean():8.0f} p50 {q(c,50):8.0f} p90 {q(c,90):8.0f} p99 {q(c,99):8.0f} max {c.max():8d}")
 slow = per[tot >= q(tot, 99)]
 print("  the slowest 1 % of wavefront-ticks spend, on average:", {n: int(slow[:, k].mean()) for k, n in enumerate(names)})
+order = np.argsort(-tot)[:12]
+print("  the 12 slowest wavefront-ticks (cycles per phase):")
+for o in order:
+    print("   ", int(tot[o]), {n: int(per[o, k]) for k, n in enumerate(names) if per[o, k] > 600})
