@@ -37,6 +37,9 @@ for CFG in $WHICH; do
   fi
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq1 -- python3 $REPO/bench.py $ARGS > $OUT/sq1.log 2>&1 || { echo "sq1 pass failed"; tail -5 $OUT/sq1.log; exit 1; }
   rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/sq2 -- python3 $REPO/bench.py $ARGS > $OUT/sq2.log 2>&1 || { echo "sq2 pass failed"; tail -5 $OUT/sq2.log; exit 1; }
+  # instruction fetch / branches (round 3): the I-cache counters live in the SQC block, the fetch / branch / SALU-cycle counters in the SQ
+  rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_ICACHE_BUSY_CYCLES --output-format csv -d $OUT/ic1 -- python3 $REPO/bench.py $ARGS > $OUT/ic1.log 2>&1 || { echo "ic1 pass failed"; tail -5 $OUT/ic1.log; }
+  rocprofv3 --pmc SQ_IFETCH SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/ic2 -- python3 $REPO/bench.py $ARGS > $OUT/ic2.log 2>&1 || { echo "ic2 pass failed"; tail -5 $OUT/ic2.log; }
   if [ "$CFG" = head1 ] || [ "${POM_PROFILE_BYTES:-0}" = 1 ]; then
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $REPO/bench.py $ARGS > $OUT/fetch.log 2>&1 || exit 1
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $REPO/bench.py $ARGS > $OUT/write.log 2>&1 || exit 1

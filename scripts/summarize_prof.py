@@ -28,7 +28,7 @@ for kernel in kernels:
         if d:
             d.sort()
             print(f"{kernel}: n={len(d)} mean {sum(d)/len(d)/1e3:.2f} us median {d[len(d)//2]/1e3:.2f} us min {d[0]/1e3:.2f} max {d[-1]/1e3:.2f}")
-    for sub in ("fetch", "write", "sq1", "sq2"):
+    for sub in ("fetch", "write", "sq1", "sq2", "ic1", "ic2"):
         f = find(sub, "*counter_collection.csv")
         if not f:
             print(f"== {sub}: no counter csv ==")

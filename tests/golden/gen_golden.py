@@ -174,8 +174,10 @@ def gen_env_traces():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    if len(sys.argv) > 1 and sys.argv[1] == "env":  # only the new fixture; the others are byte-stable and stay as committed
+    if len(sys.argv) > 1 and sys.argv[1] == "env":  # only that fixture; the others are byte-stable and stay as committed
         gen_env_traces()
+    elif len(sys.argv) > 1 and sys.argv[1] == "cases":  # after adding cases to tests/step_cases.py
+        gen_cases()
     else:
         gen_cases()
         gen_trajectories()

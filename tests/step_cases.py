@@ -697,12 +697,231 @@ def full_queues_stress(api):
     api.several_steps(6, s, m)
 
 
+def q3_current_vs_stored_strength(api):
+    """Q3: ExplodeBombAt (a chained bomb) burns with its owner's CURRENT bombStrength (bboard.cpp:115), ExplodeTopBomb with the
+    strength stored in the bomb word (bboard.cpp:194)."""
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 0, 0, 0)
+    api.put_agent(s, 10, 10, 1)
+    api.kill(s, 2, 3)
+    s["agents"][0, 0]["maxBombCount"] = 5
+    s["agents"][0, 1]["maxBombCount"] = 5
+    api.plant_bomb(s, 2, 3, 1, True, 2)          # head of the queue, strength 1: goes off in the 2nd step
+    api.plant_bomb(s, 3, 3, 0, True, 9)          # stored strength 1, on the first bomb's +x ray
+    s["agents"][0, 0]["bombStrength"] = 3        # the owner collects range afterwards
+    api.plant_bomb(s, 8, 8, 0, True, 4)          # stored strength 3
+    api.several_steps(2, s, m)
+    api.require(is_flame(s["board"][0, 3, 6]))   # the chained bomb burnt 3 cells: the owner's current strength
+    api.require(is_flame(s["board"][0, 6, 3]))
+    s["agents"][0, 0]["bombStrength"] = 1        # ... and loses it again (not reachable in play, legal as an input state)
+    api.several_steps(2, s, m)
+    api.require(is_flame(s["board"][0, 8, 5]))   # the head of the queue burns with the strength it was planted with
+    api.require(is_flame(s["board"][0, 5, 8]))
+    api.several_steps(5, s, m)
+
+
+def q4_flame_overwrite_and_pop_rules(api):
+    """Q4: a flame takes every non-rigid cell; only WOOD keeps its flag; a power-up item and the revealed-power-up flag of an
+    older flame are destroyed; a chained bomb's own cell ends with the OUTER blast's signature; PopFlame clears exactly the
+    cells that still carry its own id (bboard.cpp:24-57,148-180,207,218)."""
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 0, 0, 0)
+    api.put_agent(s, 10, 10, 1)
+    api.kill(s, 2, 3)
+    for a in (0, 1):
+        s["agents"][0, a]["maxBombCount"] = 5
+        s["agents"][0, a]["bombStrength"] = 2
+    api.put_item(s, 6, 5, Item.EXTRABOMB)        # a power-up on the +x ray: burnt
+    api.put_item(s, 4, 5, Item.WOOD + 1)         # flagged wood on the -x ray: reveals its power-up when the flame pops
+    api.put_item(s, 5, 3, Item.WOOD + 2)         # flagged wood on the -y ray, burnt again by the second blast one step later
+    api.plant_bomb(s, 5, 5, 0, True, 1)          # A
+    api.plant_bomb(s, 3, 3, 0, True, 2)          # E: its +x ray crosses (5,3) while that cell is A's flame with flag 2
+    api.plant_bomb(s, 5, 7, 1, True, 9)          # B: chained by A's +y ray, its -y ray runs back over A's cells
+    api.step(s, m)
+    api.require(is_flame(s["board"][0, 5, 6]))
+    api.require(is_flame(s["board"][0, 7, 5]))
+    api.require(s["bombs_count"][0] == 1)
+    api.step(s, m)
+    api.require(s["bombs_count"][0] == 0)
+    api.several_steps(4, s, m)
+    api.require(s["board"][0, 5, 4] == Item.EXTRABOMB)   # the wood's flag survived its one flame
+    api.require(s["board"][0, 5, 6] == Item.PASSAGE)     # the power-up item did not
+    api.require(s["board"][0, 3, 5] == Item.PASSAGE)     # a flag inside a flame does not survive the next flame
+    api.require(s["flames_count"][0] == 0)
+
+
+def q5_ray_order_and_second_bomb_on_origin(api):
+    """Q5: rays run +x, -x, +y, -y (the flame queue records the order of the chained bombs); wood stops a ray after burning,
+    rigid before; agents on the way die and the ray goes on; the blast kills the agent standing on its origin but does not set
+    off a second bomb queued on the same cell — that one goes off a step later, in loop B (bboard.cpp:198-263)."""
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 0, 0, 0)
+    api.put_agent(s, 10, 10, 1)
+    s["agents"][0, 0]["maxBombCount"] = 5
+    s["agents"][0, 0]["bombStrength"] = 3
+    s["agents"][0, 1]["maxBombCount"] = 5
+    api.plant_bomb(s, 5, 5, 0, True, 1)          # A, strength 3
+    api.plant_bomb(s, 5, 5, 1, True, 9)          # a second bomb on A's cell
+    api.plant_bomb(s, 4, 5, 1, True, 9)          # on the -x ray
+    api.plant_bomb(s, 6, 5, 1, True, 9)          # on the +x ray: chained first
+    api.put_agent(s, 5, 5, 2)                    # stands on the two bombs
+    api.put_agent(s, 5, 3, 3)                    # on the -y ray, two cells out: dies, the ray goes on to (5,2)
+    api.put_item(s, 2, 5, Item.RIGID)
+    api.put_item(s, 5, 7, Item.WOOD)
+    api.step(s, m)
+    api.require(s["agents"][0, 2]["dead"] == 1)
+    api.require(s["agents"][0, 3]["dead"] == 1)
+    api.require(is_flame(s["board"][0, 2, 5]))
+    api.require(is_flame(s["board"][0, 7, 5]))           # the wood burnt ...
+    api.require(s["board"][0, 8, 5] == Item.PASSAGE)     # ... and stopped the ray
+    api.require(s["bombs_count"][0] == 1)                # the second bomb on the origin is still queued
+    f0, f1, f2 = (queue_get(s[0], "flames", k) for k in range(3))
+    api.require((int(f0["x"]), int(f1["x"]), int(f2["x"])) == (5, 6, 4))   # A, then +x's bomb, then -x's
+    api.step(s, m)
+    api.require(s["bombs_count"][0] == 0)                # it sat in a flame cell: loop B set it off
+    api.several_steps(5, s, m)
+
+
+def q6_flame_timing(api):
+    """Q6: timeLeft 4 at spawn, decremented at the start of every Step and popped at 0: a flame kills movers during the three
+    Steps after it was spawned and is gone for the fourth; TickFlames only ever tests the head (step_utility.cpp:208-222)."""
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 5, 9, 0)
+    api.put_agent(s, 8, 5, 1)
+    api.kill(s, 2, 3)
+    api.spawn_flame(s, 5, 5, 2)
+    m[0] = Move.UP
+    api.step(s, m)
+    api.require_agent(s, 0, 5, 8)
+    api.spawn_flame(s, 2, 2, 1)                  # one Step younger
+    m[0] = IDLE
+    api.step(s, m)
+    m[0] = Move.UP
+    api.step(s, m)                               # third Step after the spawn: (5,7) still burns
+    api.require(s["agents"][0, 0]["dead"] == 1)
+    m[0], m[1] = IDLE, Move.LEFT
+    api.step(s, m)                               # fourth: popped before the agents move
+    api.require_agent(s, 1, 7, 5)
+    api.require(is_flame(s["board"][0, 2, 2]))
+    api.require(s["flames_count"][0] == 1)
+    m[1] = IDLE
+    api.step(s, m)
+    api.require(s["board"][0, 2, 2] == Item.PASSAGE)
+    api.require(s["flames_count"][0] == 0)
+
+
+def q8_several_bombs_on_one_cell(api):
+    """Q8: planting neither puts Item::BOMB on the board (the agent's item stays) nor looks for a bomb already there; every
+    position lookup answers with the FIRST queue match: a kick moves only the first of two bombs on a cell
+    (step.cpp:54, bboard.cpp:265-311)."""
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 3, 3, 0)
+    api.put_agent(s, 3, 5, 1)
+    api.kill(s, 2, 3)
+    s["agents"][0, 0]["maxBombCount"] = 3
+    s["agents"][0, 1]["canKick"] = 1
+    m[0] = Move.BOMB
+    api.step(s, m)
+    api.step(s, m)
+    api.require(s["bombs_count"][0] == 2)
+    api.require(s["board"][0, 3, 3] == Item.AGENT0)
+    m[0], m[1] = Move.RIGHT, Move.UP
+    api.step(s, m)
+    api.require(s["board"][0, 3, 3] == Item.BOMB)
+    api.step(s, m)                               # agent 1 kicks: only the first bomb leaves ...
+    api.require(bomb_y(queue_get(s[0], "bombs", 0)) == 2)
+    api.require(bomb_y(queue_get(s[0], "bombs", 1)) == 3)
+    api.require_agent(s, 1, 3, 4)                # ... and the second, resting under him now, bounces him back in loop A
+    api.require(s["board"][0, 3, 3] == Item.BOMB)
+    m[0], m[1] = IDLE, IDLE
+    api.several_steps(9, s, m)                   # both go off
+
+
+def q11_dying_mover_vacates(api):
+    """Q11: a mover that walks into a flame dies; the cell it leaves becomes BOMB if a bomb is queued there, else PASSAGE, and
+    only if it still shows the mover's own item; the dead agent keeps its stale position (step.cpp:84-99,125-136)."""
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 3, 3, 0)
+    api.put_agent(s, 6, 4, 1)
+    api.put_agent(s, 5, 5, 2)
+    api.put_agent(s, 10, 10, 3)
+    api.put_item(s, 5, 5, Item.WOOD)             # agent 2's cell shows something else
+    m[0] = Move.BOMB
+    api.step(s, m)
+    api.spawn_flame(s, 5, 3, 1)
+    m[0], m[1], m[2] = Move.RIGHT, Move.UP, Move.UP
+    api.step(s, m)
+    for a in (0, 1, 2):
+        api.require(s["agents"][0, a]["dead"] == 1)
+    api.require(s["aliveAgents"][0] == 1)
+    api.require(s["board"][0, 3, 3] == Item.BOMB)
+    api.require(s["board"][0, 4, 6] == Item.PASSAGE)
+    api.require(s["board"][0, 5, 5] == Item.WOOD)
+    api.require((int(s["agents"][0, 0]["x"]), int(s["agents"][0, 0]["y"])) == (3, 3))
+    m[0], m[1], m[2] = IDLE, IDLE, IDLE
+    api.several_steps(2, s, m)
+
+
+def q12_kick_bounce_collision(api):
+    """Q12: anybody may step onto a BOMB cell; loop A bounces a non-kicker back (the resting bomb's target, its own cell, now
+    holds an agent), a kicker gives the bomb his direction and it moves in the same Step; two bombs that want the same cell
+    both stop, and ResolveBombCollision bounces the kicker back — but only if his bomb comes FIRST in the queue: the tests only
+    look at queue indices >= the current one; they compare bomb VALUES, so two identical words never collide with each other
+    (step.cpp:147-184,195-278, step_utility.cpp:62-128,279-329)."""
+    s = api.make()
+    m = idle()
+    api.put_agent(s, 2, 2, 0)
+    api.put_agent(s, 2, 6, 1)
+    api.put_agent(s, 4, 8, 2)
+    api.put_agent(s, 4, 10, 3)
+    for a in (1, 2, 3):
+        s["agents"][0, a]["canKick"] = 1
+    s["agents"][0, 0]["maxBombCount"] = 9
+    api.plant_bomb(s, 3, 2, 0, True)             # 0: a non-kicker steps onto it
+    api.plant_bomb(s, 3, 6, 0, True)             # 1: kicked RIGHT
+    api.plant_bomb(s, 5, 8, 0, True)             # 2: kicked RIGHT, towards (6,8) ...
+    api.plant_bomb(s, 7, 8, 0, True)             # 3: ... where this one is heading: the kicker is bounced
+    api.set_bomb_direction(s, 3, Direction.LEFT)
+    api.plant_bomb(s, 7, 10, 0, True)            # 4: heading for (6,10) ...
+    api.set_bomb_direction(s, 4, Direction.LEFT)
+    api.plant_bomb(s, 5, 10, 0, True)            # 5: ... as is this one once kicked: later in the queue, its kicker stays
+    api.plant_bomb(s, 8, 3, 0, True)             # 6 and 7: identical words on one cell
+    api.plant_bomb(s, 8, 3, 0, True)
+    m[0], m[1], m[2], m[3] = Move.RIGHT, Move.RIGHT, Move.RIGHT, Move.RIGHT
+    api.step(s, m)
+    api.require_agent(s, 0, 2, 2)                # bounced back
+    api.require(s["board"][0, 2, 3] == Item.BOMB)
+    api.require_agent(s, 1, 3, 6)                # stands where the bomb was
+    api.require(bomb_x(queue_get(s[0], "bombs", 1)) == 4)
+    api.require_agent(s, 2, 4, 8)                # his kick collided: bounced back by ResolveBombCollision
+    api.require(bomb_x(queue_get(s[0], "bombs", 2)) == 5)
+    api.require(bomb_x(queue_get(s[0], "bombs", 3)) == 7)
+    api.require_agent(s, 3, 5, 10)               # his did too, but the collision was found at the other bomb's turn
+    api.require(bomb_x(queue_get(s[0], "bombs", 4)) == 7)
+    api.require(bomb_x(queue_get(s[0], "bombs", 5)) == 5)
+    m[0], m[1], m[2], m[3] = IDLE, IDLE, IDLE, IDLE
+    api.several_steps(3, s, m)
+
+
 EXTRA_CASES = {
     "q1_stale_slot_direction_inherited": q1_stale_slot_direction_inherited,
     "q2_stale_index_after_nested_chain": q2_stale_index_after_nested_chain,
+    "q3_current_vs_stored_strength": q3_current_vs_stored_strength,
+    "q4_flame_overwrite_and_pop_rules": q4_flame_overwrite_and_pop_rules,
+    "q5_ray_order_and_second_bomb_on_origin": q5_ray_order_and_second_bomb_on_origin,
+    "q6_flame_timing": q6_flame_timing,
     "q7_out_of_order_timer_underflow": q7_out_of_order_timer_underflow,
+    "q8_several_bombs_on_one_cell": q8_several_bombs_on_one_cell,
     "q9_dead_agent_cancels_move": q9_dead_agent_cancels_move,
     "q10_three_cycle_plus_one": q10_three_cycle_plus_one,
+    "q11_dying_mover_vacates": q11_dying_mover_vacates,
+    "q12_kick_bounce_collision": q12_kick_bounce_collision,
     "q13_resting_bomb_on_item_cells": q13_resting_bomb_on_item_cells,
     "q14_agent_chain_with_planting": q14_agent_chain_with_planting,
     "q15_long_blast_chain": q15_long_blast_chain,

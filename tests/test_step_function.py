@@ -27,6 +27,10 @@ def _run(name, stepper, oracle):
 
 def test_suite_is_complete():
     assert len(CASES) == 32  # 10 TEST_CASEs, 32 leaf runs
+    # one directed vector per quirk of SURVEY.md §9 (Q1 .. Q12), recorded from the compiled reference like the suite itself
+    quirks = {name.split("_")[0] for name in ALL_CASES if name.startswith("q")}
+    assert {f"q{k}" for k in range(1, 13)} <= quirks, sorted(quirks)
+    assert all(f"{name}__after" in GOLDEN.files for name in ALL_CASES)
 
 
 @pytest.mark.parametrize("name", list(ALL_CASES))
