@@ -16,14 +16,16 @@ the region (weak scaling: per-GPU batch fixed).  The reference fans out the same
 (unit_test/bboard/performance_test.cpp:40-50,71-94).
 
 The JSON line carries
-  roofline     — `achieved` / `frac`: SURVEY §8(d)'s contract bytes (2024 B per env-step: the reference's 1004-B State read
-                 and written + Move[4]) over the SAME clock as `value` (ms_per_step), against the 8 TB/s HBM3E peak;
-                 `hbm_achieved` / `hbm_frac`: the bytes the kernel really moves (`traffic`: rocprofv3 PMC FETCH_SIZE /
-                 WRITE_SIZE of this workload, measured by the default run itself in two child runs under rocprofv3 — or the
-                 figure committed under profiles/ where the profiler is missing; `traffic_source` says which; the packed
-                 record's footprint 2 x 448 B per env otherwise) over the same clock; `launch`: one launch's bytes and mean duration
-                 from HIP events on the launch stream (what rocprofv3's kernel trace reports as AverageNs);
-                 `limiter`: what actually bounds the kernel (profiles/).
+  roofline     — `achieved` / `frac`: the bytes the kernel REALLY moves per step (`traffic`: rocprofv3 PMC FETCH_SIZE x 2 +
+                 WRITE_SIZE of this workload — the figure committed under profiles/, or measured by this very run with
+                 --measure-traffic; `traffic_source` / `traffic_measured_in_run` say which; the packed record's footprint
+                 2 x 448 B per env for workloads without a PMC figure) over the SAME clock as `value` (ms_per_step), against
+                 the 8 TB/s HBM3E peak: a physical utilisation, never above 1;
+                 `contract_achieved` / `contract_frac`: SURVEY §8(d)'s contract bytes (2024 B per env-step: the reference's
+                 1004-B State read and written + Move[4]) over the same clock — bytes the kernel does not move (the device
+                 record is packed to 448 B), kept for comparison with rounds 1-2, not a utilisation;
+                 `launch`: one launch's bytes and mean duration from HIP events attached to the dispatch (what rocprofv3's
+                 kernel trace reports as AverageNs); `limited_by`: what actually bounds the kernel (profiles/).
   cpu_baseline — the unmodified reference bboard::Step (oracle/_ref, built where /root/reference lies) or the restatement,
                  timed on this host's cores on a bounded sample of the same workload (rank 0, N=1 only); `config1`: BASELINE's
                  config 1 (one env, HarmlessAgent moves, one thread).
@@ -48,7 +50,8 @@ if ROOT not in sys.path:
 ALGO_BYTES_PER_STEP = 2024  # 1004 B State read + 1004 B State write + 16 B Move[4]  (SURVEY.md §8d): the contract figure
 PACKED_BYTES_PER_STEP = 2 * 448  # what the device record moves per env-step: 112 dwords read + written (pom_packed.h)
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_JSON = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r03_traffic.json")
+ENVS_SINGLE_GPU, ENVS_PER_GPU_SHARDED = 65536, 32768  # BASELINE: 64k envs at one GPU; config 4 = 262,144 envs = 8 x 32,768
 
 
 def shard_plan(rank: int, world: int, envs_per_gpu: int) -> dict:
@@ -81,6 +84,19 @@ def reduce_max(value: float, device, dist_mod=None) -> float:
     if dist_mod is not None and dist_mod.is_initialized() and dist_mod.get_world_size() > 1:
         _all_reduce(t, dist_mod.ReduceOp.MAX, dist_mod)
     return float(t.item())
+
+
+def timed_region(run_steps, steps: int, barrier, in_region_reduce=None) -> float:
+    """The timed region: exactly `steps` steps between two barriers (each = dist.barrier + torch.cuda.synchronize()).  With
+    several ranks `in_region_reduce` — the path's one collective, the all-reduce of the step counters — is issued INSIDE it,
+    behind the last step.  Returns this rank's wall time."""
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(steps)
+    if in_region_reduce is not None:
+        in_region_reduce()
+    barrier()
+    return time.perf_counter() - t0
 
 
 # ---- the launcher behind `--gpus N` ---------------------------------------------------------------------------------
@@ -227,7 +243,7 @@ def cpu_baseline(start: np.ndarray, seed: int, dist_id: int, max_steps: int, bud
 
 
 def measure_traffic(args) -> dict | None:
-    """HBM bytes per step of THIS build on THIS workload, from the PMC counters: two child runs of this script under rocprofv3
+    """--measure-traffic: HBM bytes per step of THIS build on THIS workload, from the PMC counters: two child runs of this script under rocprofv3
     (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: separate passes, counters only, no tracing), one launch per step so that no
     concurrent dispatch shares the counters.  gfx950: FETCH_SIZE reports half of a coalesced streaming read (MI355X guide;
     calibrated in round 1 on a zero-tick launch of this kernel: 0.513), both counters are in KB.  None if the profiler is not
@@ -238,10 +254,10 @@ def measure_traffic(args) -> dict | None:
     import tempfile
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
-        return None
+        return {"failed": "rocprofv3 not found"}
     child = [sys.executable, os.path.abspath(__file__), "--traffic-probe", "--streams", "1", "--steps", "60", "--warmup", "10",
              "--envs", str(args.envs), "--kind", args.kind, "--dist", args.dist, "--seed", str(args.seed), "--max-steps", str(args.max_steps),
-             "--burn-in", str(args.burn_in), "--no-cpu-baseline", "--no-config3"]
+             "--burn-in", str(args.burn_in), "--no-cpu-baseline", "--no-config3"]  # (direct launches: 60 steps = 3 graph chunks would also do)
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -258,11 +274,13 @@ def measure_traffic(args) -> dict | None:
                         if "pom_step_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
                             vals.append(float(row["Counter_Value"]))
                 if len(vals) < 40:
-                    return None
+                    return {"failed": f"{counter} pass: only {len(vals)} dispatches of pom_step_kernel in the counter csv"}
                 vals = vals[len(vals) // 2:]  # the steady second half: past the burn-in
                 out[counter] = sum(vals) / len(vals)
-    except Exception:
-        return None
+    except Exception as exc:
+        return {"failed": f"{type(exc).__name__}: {str(exc)[:200]}"}
+    # FETCH_SIZE x 2: /opt/skills/guides/MI355X_MICROARCH.md ("on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced
+    # streaming read"); calibrated on a zero-tick launch of this kernel in round 1 (0.513, profiles/r01_traffic.json)
     bytes_per_step = (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
     return {"hbm_bytes_per_step": int(round(bytes_per_step)), "fetch_size_kb_raw": out["FETCH_SIZE"], "write_size_kb_raw": out["WRITE_SIZE"],
             "fetch_correction": 2.0}
@@ -273,7 +291,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=0,
+                    help="envs per GPU (default: 65,536 on one GPU — the headline; 32,768 per GPU with --gpus N > 1, i.e. BASELINE "
+                         "config 4's 262,144 envs at 8 GPUs)")
     ap.add_argument("--kind", default="ffa", choices=["ffa", "stress"])
     ap.add_argument("--dist", default="random", choices=["harmless", "random", "stress"])
     ap.add_argument("--ticks-per-launch", type=int, default=1)
@@ -291,11 +311,18 @@ def parse_args(argv=None):
     ap.add_argument("--fresh-boards", action="store_true",
                     help="boards drawn on the device (pom_batch_generate) and a new one per episode instead of the snapshot replay "
                          "BASELINE's configs prescribe (SURVEY §8 f3)")
-    ap.add_argument("--no-traffic", action="store_true", help="do not measure HBM traffic with rocprofv3 child runs (use the committed figure)")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="measure roofline.traffic in this run (two rocprofv3 --pmc child runs of this script, +10-20 s); default: the "
+                         "figure committed under profiles/ for this workload")
+    ap.add_argument("--no-traffic", action="store_true", help=argparse.SUPPRESS)  # accepted for older scripts: the default now
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)  # the child of measure_traffic(): steps only, no JSON extras
     ap.add_argument("--envs-per-wave", type=int, default=0)
     ap.add_argument("--lanes-per-env", type=int, default=0)
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.envs <= 0:
+        world = int(os.environ.get("WORLD_SIZE", "0")) or args.gpus
+        args.envs = ENVS_SINGLE_GPU if world <= 1 else ENVS_PER_GPU_SHARDED
+    return args
 
 
 def worker(args) -> None:
@@ -409,18 +436,27 @@ def worker(args) -> None:
     reduce_counters(counters, dist)  # warm the RCCL communicator outside the timed region
     env.reset_counters()
 
+    # The timed region: exactly K steps between two (barrier + torch.cuda.synchronize()) pairs.  With several ranks it also holds
+    # the path's one collective, where north_star puts it: the end-of-region reduction of the step / episode counters — the
+    # per-wavefront counters summed on the device behind the last step (on the launch stream), then ONE 32-byte all-reduce
+    # (RCCL over xGMI) on a side stream.  Envs shard with no exchange on the data path, so this is all the ranks ever say to
+    # each other.  On one GPU there is no collective; the counters are read after the region.
+    side = torch.cuda.Stream(device=device) if world > 1 else None
+    reduce_in_region = world > 1
+
+    def counters_allreduce() -> None:
+        env.counters_into(counters.data_ptr())  # joins the sub-batches, one reduction kernel, on the launch stream
+        side.wait_stream(stream)
+        with torch.cuda.stream(side):
+            reduce_counters(counters, dist)
+
     env.fork()  # the sub-streams are ordered behind the setup above now, not inside the timed region
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()  # torch.cuda.synchronize() waits for every stream of the device, the sub-batches' included
-    elapsed = time.perf_counter() - t0
+    # (the closing barrier's torch.cuda.synchronize() waits for every stream of the device: the sub-batches' and the side stream too)
+    elapsed = timed_region(run_steps, args.steps, barrier, counters_allreduce if reduce_in_region else None)
     elapsed = reduce_max(elapsed, device, dist)
-    # bookkeeping, after the region: what the K steps did (per-wavefront counters summed on the device; the one collective:
-    # step / episode totals over all ranks).  Envs shard with no exchange on the path, so nothing of this belongs to a step.
-    env.counters_into(counters.data_ptr())
-    reduce_counters(counters, dist)
-    torch.cuda.synchronize()
+    if not reduce_in_region:  # one GPU: bookkeeping after the region (what the K steps did)
+        env.counters_into(counters.data_ptr())
+        torch.cuda.synchronize()
     total_steps = int(counters[CNT_STEPS].item())
     episodes_finished = int(counters[1].item())
     # the same number of steps again between two HIP events on the launch stream (untimed: the events and the join they need
@@ -508,6 +544,42 @@ def worker(args) -> None:
         e3.sync()
         ms_x = ev6.elapsed_time(ev7) / n_x
         e3.close()
+        # Throughput mode: ticks_per_launch = T > 1 keeps the record in LDS for T ticks (synthetic move stream only) —
+        # NOT the canonical roofline run (a step there is one HBM round trip per tick); reported on its own, per tick
+        for name, n_o, t_o in (("throughput_T4_65536_envs", 65536, 4), ("throughput_T16_65536_envs", 65536, 16),
+                               ("throughput_T16_4096_envs", 4096, 16)):
+            e4 = BatchEnvironment(n_o, device=local_rank, mode=MODE_ENV, auto_reset=True, max_steps=args.max_steps, stream=stream.cuda_stream)
+            e4.make_game(pa.make_boards(n_o, seed=args.seed * 1000003, kind="ffa"))
+            launches = 40
+            e4.step_random(args.seed, 1, ticks=320, ticks_per_launch=t_o)
+            e4.sync()
+            ev8, ev9 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev8.record(stream)
+            e4.step_random(args.seed, 1, ticks=launches * t_o, ticks_per_launch=t_o)
+            e4.flush()
+            ev9.record(stream)
+            e4.sync()
+            ms_t = ev8.elapsed_time(ev9) / (launches * t_o)
+            other[name] = {"value": n_o / (ms_t * 1e-3), "unit": "env-steps/s", "ms_per_tick": ms_t, "ticks_per_launch": t_o,
+                           "ticks": launches * t_o,
+                           "note": "ticks_per_launch > 1: the tile stays in LDS between ticks; not the canonical one-round-trip-per-tick step"}
+            e4.close()
+        # the literal drop-in, one env at a time: pom_step (= bboard::Step(State*, Move*) behind the C-ABI: upload, one launch,
+        # download, all blocking).  Latency, not throughput: compare with cpu_baseline.config1.
+        from pomcpp_amd.batch import step_one
+        one = np.ascontiguousarray(start[:1]).copy()
+        mv1 = np.zeros(4, dtype=np.int32)
+        for _ in range(20):
+            step_one(one, mv1)
+        t_l = time.perf_counter()
+        n_l = 200
+        for k in range(n_l):
+            mv1[:] = (k % 5, (k + 1) % 5, (k + 2) % 5, (k + 3) % 5)  # HarmlessAgent's range: no bombs
+            step_one(one, mv1)
+        us_l = (time.perf_counter() - t_l) / n_l * 1e6
+        other["single_env_pom_step"] = {"value": 1e6 / us_l, "unit": "env-steps/s", "us_per_call": us_l, "calls": n_l,
+                                        "note": "pom_step(State*, Move[4]) on ONE env: host State up, one launch, State down, blocking; "
+                                                "the batch API is the product, this is the literal bboard::Step replacement"}
         other["explicit_moves_device_65536_envs"] = {
             "value": plan["n_envs"] / (ms_x * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_x, "steps": n_x,
             "note": "pom_batch_step_device with auto_reset = POM_RESET_AT_END: Move[4] from device memory, one launch per tick on the caller's stream"}
@@ -520,34 +592,39 @@ def worker(args) -> None:
         algo_bytes = ALGO_BYTES_PER_STEP * plan["n_envs"] * tpl
         footprint = PACKED_BYTES_PER_STEP * plan["n_envs"]  # per launch group: the record is read and written once whatever tpl
         contract = algo_bytes / (ms_per_step * 1e-3) / 1e9  # same clock as `value`
-        # PMC-derived HBM bytes per step come from a committed rocprofv3 pass over this very workload (separate --pmc runs cannot
-        # share a process with the timed run); anything else is priced with the packed record's footprint
-        traffic, traffic_source = None, None
+        # PMC-derived HBM bytes per step: the committed rocprofv3 passes over this very workload (profiles/, taken with
+        # scripts/profile_configs.sh), or --measure-traffic: the same two passes as child runs of this script.  Workloads without a
+        # PMC figure are priced with the packed record's footprint (the kernel reads and writes each 448-B record once).
+        traffic, traffic_source, measured_in_run, traffic_failure = None, None, False, None
         tj = os.path.join(ROOT, TRAFFIC_JSON)
-        headline = (args.envs == 65536 and tpl == 1 and args.kind == "ffa" and args.dist == "random" and args.policy == "random"
-                    and not args.fresh_boards)
-        live = None
-        if world == 1 and tpl == 1 and args.policy == "random" and not args.fresh_boards and not args.no_traffic \
-                and not args.no_config3 and not args.traffic_probe:
-            live = measure_traffic(args)  # the default run measures it itself, on this build (two rocprofv3 child runs)
-        if live:
-            traffic = live["hbm_bytes_per_step"]
-            traffic_source = (f"measured by this run: rocprofv3 --pmc FETCH_SIZE ({live['fetch_size_kb_raw']:.1f} KB raw per step, x 2: the gfx950 "
-                              f"correction) and --pmc WRITE_SIZE ({live['write_size_kb_raw']:.1f} KB) in two separate child runs of this script "
-                              "with one launch per step")
-        elif os.path.exists(tj) and headline:
-            traffic = json.load(open(tj))["hbm_bytes_per_step"]  # all launches of one step
-            traffic_source = TRAFFIC_JSON + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections applied; " \
-                                            "measured on this workload earlier, not in this run)"
+        headline_shape = (tpl == 1 and args.kind == "ffa" and args.dist == "random" and args.policy == "random" and not args.fresh_boards)
+        if args.measure_traffic and world == 1 and tpl == 1 and not args.traffic_probe:
+            live = measure_traffic(args)
+            if live and "failed" not in live:
+                traffic, measured_in_run = live["hbm_bytes_per_step"], True
+                traffic_source = (f"measured by this run: rocprofv3 --pmc FETCH_SIZE ({live['fetch_size_kb_raw']:.1f} KB raw per step, x 2: the gfx950 "
+                                  f"correction) and --pmc WRITE_SIZE ({live['write_size_kb_raw']:.1f} KB) in two separate child runs of this script "
+                                  "with one launch per step")
+            else:
+                traffic_failure = (live or {}).get("failed", "unknown")
+                print(f"bench.py: --measure-traffic FAILED ({traffic_failure}); falling back to the committed figure", file=sys.stderr)
+        if traffic is None and os.path.exists(tj) and headline_shape:
+            tjd = json.load(open(tj))
+            # per env: the committed passes ran 65,536 envs; the kernel's traffic per env does not depend on how many ranks share the job
+            traffic = int(round(tjd["hbm_bytes_per_step"] * plan["n_envs"] / tjd["envs"]))
+            traffic_source = TRAFFIC_JSON + " (rocprofv3 --pmc FETCH_SIZE x 2 / WRITE_SIZE in separate passes, one launch per step, " \
+                                            f"{tjd['envs']} envs, scaled to this rank's {plan['n_envs']}; committed, not measured in this run)"
         moved = traffic if traffic is not None else footprint
         hbm = moved / (ms_per_step * 1e-3) / 1e9
+        c4 = world > 1 and plan["global_envs"] == 262144
         line = {
             "metric": "env_steps_per_sec", "value": total_steps / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, not a measurement)" if rehearsal else ""),
             "config": {
-                "workload": f"{args.envs} concurrent 11x11 FFA envs per GPU, {args.kind} boards, "
+                "workload": (f"BASELINE config 4: {plan['global_envs']} concurrent 11x11 FFA envs sharded over {world} GPUs, " if c4 else "")
+                            + f"{args.envs} concurrent 11x11 FFA envs per GPU, {args.kind} boards, "
                             + (f"uniform-{args.dist} Move[4] (RandomAgent distribution)" if args.policy == "random"
                                else "4x SimpleAgent policy on the device (act x4 + Step per env-step, as Environment::Step)")
                             + (", auto-reset onto a fresh device-generated board" if args.fresh_boards else ", auto-reset")
@@ -558,33 +635,36 @@ def worker(args) -> None:
                 "burn_in_ticks": args.burn_in, "launches_per_step_tuning_ms": tuned, "untimed_tuning_steps": tuning_steps,
                 "parallelism": f"env-shard x{world}", "ranks": world, "collective_backend": backend,
                 "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                "collective_in_timed_region": ("one 32-byte all-reduce(SUM) of the step / episode counters behind the last step, on a side stream"
+                                               if reduce_in_region else None),
+                "per_gpu_batch_note": (f"{ENVS_SINGLE_GPU} envs on one GPU (the headline), {ENVS_PER_GPU_SHARDED} per GPU with several "
+                                       "(config 4 = 262,144 envs at 8 GPUs): compare N > 1 lines with `--gpus 1 --envs 32768`"),
                 "episodes_finished": episodes_finished,
             },
             "roofline": {
                 "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
-                # SURVEY §8(d)'s contract figure: 2024 B per env-step (the reference's 1004-B State read and written + Move[4]) over
-                # the clock `value` uses.  It prices bytes the kernel does not move — the device record is packed to 448 B — so it
-                # is no physical utilisation and can pass 1.0; `hbm_frac` below is the physical figure.
-                "achieved": contract, "frac": contract / HBM_PEAK_GBPS,
-                "frac_note": "contract bytes (reference layout, 2024 B per env-step), not bytes moved: the packed record moves 0.44-0.47 of them; "
-                             "hbm_achieved / hbm_frac are the physical figures",
-                "algorithmic_bytes_per_step": algo_bytes,
-                # the physical figure: bytes really moved per step over the same clock
-                "traffic": traffic, "traffic_source": traffic_source,
-                "hbm_achieved": hbm, "hbm_frac": hbm / HBM_PEAK_GBPS,
+                # physical: bytes really moved per step over the clock `value` uses
+                "achieved": hbm, "frac": hbm / HBM_PEAK_GBPS,
+                "traffic": traffic, "traffic_source": traffic_source, "traffic_measured_in_run": measured_in_run,
+                "traffic_fallback": bool(args.measure_traffic and not measured_in_run), "traffic_failure": traffic_failure,
                 "hbm_bytes_per_step": moved, "hbm_bytes_kind": "pmc" if traffic is not None else "packed footprint (2 x 448 B per env)",
                 "footprint_bytes_per_step": footprint, "traffic_over_footprint": (traffic / footprint) if traffic else None,
-                "limiter": "instruction issue + one wavefront's dependent chain, not HBM (DESIGN.md §4; SQ counters in profiles/)",
+                # SURVEY §8(d)'s contract figure: 2024 B per env-step (the reference's 1004-B State read and written + Move[4]) over the
+                # same clock.  Bytes the kernel does not move — the device record is packed to 448 B — so not a utilisation (it can
+                # pass 1.0); kept because rounds 1-2 reported it as `frac`.
+                "contract_achieved": contract, "contract_frac": contract / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": algo_bytes,
+                "limited_by": "instruction issue and the slowest wavefront of a launch (one round of 4 wavefronts per SIMD), not HBM: "
+                              "DESIGN.md §4, SQ / I-cache counters in profiles/",
                 # <envs per wavefront, lanes per env, fresh boards, fused policy, reset at end, one tick per launch>, as rocprofv3 names it
                 "kernel": f"pom_step_kernel<{epw}, {lpe}, {'true' if args.fresh_boards else 'false'}, {'true' if args.policy == 'simple' else 'false'}, false, "
                           f"{'true' if (tpl == 1 and lpe == 4) else 'false'}>",
                 "step_ms_hip_events": step_ms, "ms_per_step": ms_per_step,
                 # one step = `launches_per_step` concurrent launches; per launch: bytes / mean duration (matches rocprofv3's AverageNs)
                 "launches_per_step": parts,
-                "launch": {"envs": plan["n_envs"] // parts, "algorithmic_bytes": algo_bytes // parts, "packed_bytes": footprint // parts,
-                           "ms": launch_ms, "timed_launches": n_launch,
-                           "achieved": (algo_bytes / parts) / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else None,
-                           "packed_achieved": (footprint / parts) / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else None},
+                "launch": {"envs": plan["n_envs"] // parts, "hbm_bytes": moved // parts, "algorithmic_bytes": algo_bytes // parts,
+                           "packed_bytes": footprint // parts, "ms": launch_ms, "timed_launches": n_launch,
+                           "achieved": (moved / parts) / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else None,
+                           "contract_achieved": (algo_bytes / parts) / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else None},
             },
         }
         if config3:

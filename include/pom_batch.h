@@ -72,7 +72,21 @@ typedef struct PomBatchOptions {
                               board_seed, env_offset + env, games played) instead of replaying its snapshot; drawn on the
                               device inside the tick, the host is not involved */
     uint64_t board_seed;   /* seed of those boards; pom_batch_generate replaces it */
+    int32_t issue_mode;    /* how the launches of a several-tick call (pom_batch_step_random / _step_simple) are issued — POM_ISSUE_*;
+                              results do not depend on it.  0 = POM_ISSUE_THREADS where a step is several launches */
+    int32_t reserved_;
 } PomBatchOptions;
+
+/* PomBatchOptions.issue_mode (environment POM_ISSUE = direct | threads | graph overrides it).  Measured per step at 65,536
+ * envs, 20-tick call from an idle device / 500-tick call: THREADS 18.0 / 15.5 us; DIRECT 17.2 .. 26.4 (host-dependent) /
+ * 15.6 - 16.0 us; GRAPH 21.4 .. 23.5 / 16.1 us (pomcpp_amd/csrc/pom_runtime.h, profiles/r03_issue_modes.txt) */
+enum {
+    POM_ISSUE_AUTO = 0,
+    POM_ISSUE_DIRECT = 1,  /* the calling thread issues every launch; the library owns no thread */
+    POM_ISSUE_THREADS = 2, /* one helper thread per internal sub-stream issues that stream's launches (created on first use, joined by
+                              pom_batch_destroy; a helper that cannot be started falls back to DIRECT for its part) */
+    POM_ISSUE_GRAPH = 3    /* chunks of 20 ticks replayed as HIP graphs, one per sub-stream; no library-owned thread */
+};
 
 enum { POM_RESET_OFF = 0, POM_RESET_AT_START = 1, POM_RESET_AT_END = 2 };
 

@@ -6,6 +6,8 @@
  * to generate the golden vectors under tests/golden/ (tests/golden/gen_golden.py).
  * /root/reference does not exist on the GPU box; nothing there needs this file.
  */
+#include <csetjmp>
+#include <csignal>
 #include <cstring>
 #include <new>
 
@@ -52,6 +54,30 @@ void ref_spawn_flame(void* s, int x, int y, int strength) { static_cast<State*>(
 void ref_set_bomb_direction(void* s, int queueOffset, int dir)
 {
     SetBombDirection(static_cast<State*>(s)->bombs[queueOffset], Direction(dir));
+}
+
+/* InitBoardItems (bboard.cpp:346-382) on a fresh State.  It reads one queue slot past the woods it collected (idxSample draws from
+ * [0, count], bboard.cpp:367-372) — an uninitialised stack word: callers run this in a child process (tests/golden/gen_boardgen_stats.py) */
+static sigjmp_buf g_fault_jmp;
+static void on_fault(int) { siglongjmp(g_fault_jmp, 1); }
+/* returns 1 if the call faulted (SIGSEGV / SIGBUS inside the flag pass): the cell kinds, drawn before that pass, are in the
+ * State then, the flags are not to be trusted; the caller should not reuse the process */
+int ref_init_board_items(void* p, int seed)
+{
+    std::memset(p, 0, sizeof(State));
+    new (p) State();
+    struct sigaction sa, old_segv, old_bus;
+    std::memset(&sa, 0, sizeof sa);
+    sa.sa_handler = on_fault;
+    sigemptyset(&sa.sa_mask);
+    sigaction(SIGSEGV, &sa, &old_segv);
+    sigaction(SIGBUS, &sa, &old_bus);
+    int faulted = 0;
+    if (sigsetjmp(g_fault_jmp, 1) == 0) InitBoardItems(*static_cast<State*>(p), seed);
+    else faulted = 1;
+    sigaction(SIGSEGV, &old_segv, nullptr);
+    sigaction(SIGBUS, &old_bus, nullptr);
+    return faulted;
 }
 
 /* step utilities pinned by unit_test/bboard/step_utility_test.cpp */

@@ -29,6 +29,7 @@ MODE_RAW, MODE_ENV = 0, 1
 RESET_OFF, RESET_AT_START, RESET_AT_END = 0, 1, 2  # PomBatchOptions.auto_reset (True = RESET_AT_START)
 DIST_HARMLESS, DIST_RANDOM, DIST_STRESS = 0, 1, 2
 CNT_STEPS, CNT_EPISODES, CNT_RESETS, CNT_UB_TICKS = 0, 1, 2, 3
+ISSUE_AUTO, ISSUE_DIRECT, ISSUE_THREADS, ISSUE_GRAPH = 0, 1, 2, 3  # PomBatchOptions.issue_mode
 UB_LOST_AGENT, UB_NULL_BOMB, UB_QUEUE_OVERFLOW, UB_REVERT_LOOP, UB_BAD_INDEX = 1, 2, 4, 8, 16
 
 
@@ -44,6 +45,7 @@ class _Options(C.Structure):
         ("mode", C.c_int32), ("auto_reset", C.c_int32), ("max_steps", C.c_int32),
         ("env_offset", C.c_int64), ("envs_per_wave", C.c_int32), ("streams", C.c_int32),
         ("lanes_per_env", C.c_int32), ("fresh_boards", C.c_int32), ("board_seed", C.c_uint64),
+        ("issue_mode", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -135,14 +137,15 @@ def step_one(state: np.ndarray, moves) -> None:
 class BatchEnvironment:
     def __init__(self, n_envs: int, device: int = 0, mode: int = MODE_ENV, auto_reset: bool = False,
                  max_steps: int = 0, env_offset: int = 0, stream: Optional[int] = None, envs_per_wave: int = 0,
-                 streams: int = 0, lanes_per_env: int = 0, fresh_boards: bool = False, board_seed: int = 0):
+                 streams: int = 0, lanes_per_env: int = 0, fresh_boards: bool = False, board_seed: int = 0,
+                 issue_mode: int = ISSUE_AUTO):
         self._lib = load_library()
         self._h = C.c_void_p()
         self._views = []  # weak references to tensors that alias the handle's device memory (moves_tensor)
         self.n = int(n_envs)
         self.device = int(device)
         o = _Options(C.sizeof(_Options), device, stream, mode, int(auto_reset), max_steps, env_offset, envs_per_wave, streams,
-                     lanes_per_env, int(fresh_boards), board_seed)
+                     lanes_per_env, int(fresh_boards), board_seed, issue_mode, 0)
         _check(self._lib, self._lib.pom_batch_create(C.byref(self._h), self.n, C.byref(o)))
 
     def close(self) -> None:

@@ -2,7 +2,7 @@
  * pom_boardgen_body.h — the pieces of the start-board specification (include/pom_boardgen.h) the device generator is made
  * of, each a pure function so that the identical source also runs on the host in tests/emul.  SURVEY.md §8 row f3.
  *
- * On gfx950 (pom_boardgen_wave in pom_kernels.hip) a whole wavefront draws one env's board: lane l takes cells l and l+64
+ * On gfx950 (pom_boardgen_wave in pom_kernels.h) a whole wavefront draws one env's board: lane l takes cells l and l+64
  * (pom_board_cell_kind), two ballots of "is wood" ARE the 121-bit wood set; every lane also computes its cells' selection
  * thresholds and flags (pom_board_threshold / pom_board_flag_code, two hashes each), so that the sequential part of the flag
  * pass — selection sampling over ~17 woods — is a countdown over ready-made numbers; lanes 0..50 write the other 51 dwords of

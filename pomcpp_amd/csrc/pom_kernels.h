@@ -1,27 +1,22 @@
 /*
- * pom_kernels.hip — gfx950 kernels and the C-ABI (include/pom_batch.h) of the batched
- * Pommerman stepper.  Written for MI355X only: 64-lane wavefronts, one wavefront per
- * workgroup, each lane owning one env whose board / bomb queue / flame queue sit in a
- * column of the workgroup's LDS tile ([row][lane], so every per-lane dynamic index is
- * bank-conflict-free: bank = lane mod 32 for all rows).
+ * pom_kernels.h — the gfx950 kernels of the batched Pommerman stepper (device side only; the host runtime that launches
+ * them is pom_runtime.h, the C-ABI of include/pom_batch.h is pom_batch.hip).  Written for MI355X only: 64-lane wavefronts,
+ * one wavefront per workgroup, each env's board / bomb queue / flame queue in a column of the wavefront's LDS tile
+ * ([row][lane]: every per-lane dynamic index is an LDS address, no shuffles, no scratch).
  *
  * The tick itself is pom_step_body.h; this file is the data movement around it:
  *   HBM (SoA records, pom_packed.h) -> LDS tile + VGPRs -> tick(s) -> HBM,
- * the AoS<->SoA pack / unpack at the boundary, status extraction and counters.
+ * the SimpleAgent policy kernel, the observation export, the board generator, the AoS<->SoA pack / unpack at the boundary,
+ * status extraction and counters.
  */
+#ifndef POM_KERNELS_H_
+#define POM_KERNELS_H_
+
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <climits>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
-#include <mutex>
-#include <new>
-#include <thread>
+#include <cstdint>
 
 #include "pom_batch.h"
 #include "pom_boardgen_body.h"
@@ -112,7 +107,8 @@ struct StepParams {
     int64_t* wave_counters;
     int64_t n, n_pad, env_offset;
     uint64_t seed;
-    uint32_t tick0;
+    uint32_t tick0;            /* the launch's first tick is tick0 + *tick_base */
+    const uint32_t* tick_base; /* a device word: 0 for a launch of its own, the chunk's first tick for a node of a replayed graph (pom_runtime.h) */
     int32_t dist, ticks, mode, auto_reset, max_steps;
     int64_t block0, block_end; /* this launch covers tiles block0 .. block_end - 1 (sub-batch of a split step) */
     uint32_t* terminal;  /* auto_reset == POM_RESET_AT_END: the last finished episode's final record per env, array of structs */
@@ -378,6 +374,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         m0 = p.agent_mem[tile_id * 64 + lane];
         m1 = p.agent_mem[4 * np + tile_id * 64 + lane];
     }
+    const uint32_t tick0 = p.tick0 + *p.tick_base; /* a scalar load, in flight with the record */
     /* the first tick's moves do not depend on the record: hash / fetch them while the record is on its way */
     uint64_t draw0 = 0;
     int4 moves0 = make_int4(0, 0, 0, 0);
@@ -385,7 +382,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         if (p.moves) {
             if (valid) moves0 = reinterpret_cast<const int4*>(p.moves)[e];
         } else {
-            draw0 = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick0);
+            draw0 = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), tick0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the DMA rows have landed (one wavefront per workgroup: no barrier) */
@@ -480,7 +477,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
             if (active && !ag_dead(sel4(member, L.a0))) { /* act() is only asked of live agents, environment.cpp:139-146 */
                 const PomPolicyEnv E{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {L.a1[0], L.a1[1], L.a1[2], L.a1[3]}, L.bIdx, L.bCnt};
                 PomSimplePolicy<PolicyStore> pol(st, E, member, m0, m1);
-                const uint64_t r = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick0 + (uint32_t)tk);
+                const uint64_t r = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), tick0 + (uint32_t)tk);
                 mv_own = pol.act((int)((((uint32_t)(r >> (16 * member)) & 0xFFFFu) * 5u) >> 16));
                 m0 = pol.m0;
                 m1 = pol.m1;
@@ -499,7 +496,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                     const int lo = (member & 1) ? moves0.y : moves0.x, hi = (member & 1) ? moves0.w : moves0.z;
                     mine = (member & 2) ? hi : lo;
                 } else {
-                    const uint64_t r = tk == 0 ? draw0 : pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick0 + (uint32_t)tk);
+                    const uint64_t r = tk == 0 ? draw0 : pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), tick0 + (uint32_t)tk);
                     mine = pom_rng_pick((uint32_t)(r >> (16 * member)) & 0xFFFFu, p.dist);
                 }
                 mvp = stepper.pack_moves_quad(mine);
@@ -508,7 +505,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                 if (p.moves) {
                     mv[0] = moves0.x; mv[1] = moves0.y; mv[2] = moves0.z; mv[3] = moves0.w;
                 } else {
-                    const uint64_t r = tk == 0 ? draw0 : pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick0 + (uint32_t)tk);
+                    const uint64_t r = tk == 0 ? draw0 : pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), tick0 + (uint32_t)tk);
 #pragma unroll
                     for (int i = 0; i < 4; i++) mv[i] = pom_rng_pick((uint32_t)(r >> (16 * i)) & 0xFFFFu, p.dist);
                 }
@@ -1121,1131 +1118,4 @@ __global__ __launch_bounds__(1024) void pom_reduce_counters_kernel(const int64_t
     }
 }
 
-/* ---- host side: the C-ABI --------------------------------------------------------------------- */
-static thread_local char g_err[256] = "";
-static void set_err(const char* what, hipError_t e)
-{
-    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
-}
-#define HIPCHK(call)                      \
-    do {                                  \
-        hipError_t e_ = (call);           \
-        if (e_ != hipSuccess) {           \
-            set_err(#call, e_);           \
-            return POM_E_HIP;             \
-        }                                 \
-    } while (0)
-
-struct PomBatch {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int64_t n = 0, n_pad = 0, n_waves = 0, env_offset = 0; /* n_waves: counter slots, sized for the smallest EPW */
-    int epw = 64;
-    bool quad = false; /* EPW 16 with four lanes per env (pom_step_kernel<16, 4>) */
-    int mode = POM_MODE_ENV, auto_reset = 0, max_steps = 0;
-    uint32_t* state = nullptr;
-    uint32_t* snap = nullptr;       /* restart snapshot, array of structs */
-    uint32_t* terminal = nullptr;   /* POM_RESET_AT_END: final record of each env's last finished episode, array of structs */
-    int32_t* moves_dev = nullptr;   /* n_pad x 4 */
-    uint32_t* agent_mem = nullptr;  /* SimpleAgent memory, [2][4 * n_pad], allocated on first use */
-    uint32_t* episode = nullptr;    /* games started per env (fresh boards) */
-    uint64_t board_seed = 0;
-    int fresh = 0;
-    int32_t* staging = nullptr;     /* staging_envs x 251 dwords (AoS), also status scratch */
-    int64_t staging_envs = 0;
-    int64_t* wave_counters = nullptr;
-    int64_t* totals_dev = nullptr;
-    int* first_bad = nullptr;
-    uint64_t tick = 0;
-    /* A step is issued as `parts` kernels over contiguous tile ranges on internal streams: the launches are
-     * independent (envs never interact), so one part's HBM load / store phases overlap the others' compute
-     * instead of all wavefronts of the chip loading and storing in lock-step.  The caller's stream is forked
-     * into the sub-streams lazily and joined again before anything else touches the batch. */
-    enum { MAX_PARTS = 8, PROF_RING = 256 };
-    int parts = 1;
-    hipStream_t sub[MAX_PARTS] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS] = {};
-    bool forked = false;
-    int main_part = 1; /* part 0 of a split step runs on the caller's stream itself, parts 1.. on sub-streams: one stream
-                          fewer for the same overlap (3 parts: 21.2 -> 20.6 us per step at 65,536 envs); POM_MAIN_PART=0: all
-                          parts on sub-streams */
-    struct PomIssuer* issuers[MAX_PARTS] = {}; /* helper threads that issue the sub-stream parts of multi-tick calls (launch_many) */
-    bool fuse_policy = true; /* pom_batch_step_simple: policy and tick in one kernel (quad shape); POM_FUSE=0 keeps them apart */
-    /* optional per-launch timing (pom_batch_profile) */
-    bool profiling = false;
-    hipEvent_t prof_ev[2 * PROF_RING] = {};
-    int prof_n = 0;
-#if defined(POM_DIAG)
-    long long* diag = nullptr;
-    long long* diag_pol = nullptr;
-#endif
-};
-
-struct PomIssuer;
-static void stop_issuers(PomBatch* h);
-static int fork_parts(PomBatch* h);
-static int join_parts(PomBatch* h);
-static int ensure_sub_streams(PomBatch* h, int parts);
-
-extern "C" {
-
-const char* pom_last_error(void) { return g_err; }
-
-int pom_device_count(void)
-{
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
-
-int pom_batch_destroy(PomBatch* h)
-{
-    if (!h) return POM_E_ARG;
-    stop_issuers(h);
-    (void)hipSetDevice(h->device);
-    for (int k = 0; k < PomBatch::MAX_PARTS; k++)
-        if (h->sub[k]) (void)hipStreamSynchronize(h->sub[k]);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (int k = 0; k < PomBatch::MAX_PARTS; k++) {
-        if (h->sub[k]) (void)hipStreamDestroy(h->sub[k]);
-        if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
-    }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    for (int k = 0; k < 2 * PomBatch::PROF_RING; k++)
-        if (h->prof_ev[k]) (void)hipEventDestroy(h->prof_ev[k]);
-    (void)hipFree(h->state);
-    (void)hipFree(h->snap);
-    (void)hipFree(h->terminal);
-    (void)hipFree(h->moves_dev);
-    (void)hipFree(h->agent_mem);
-    (void)hipFree(h->episode);
-    (void)hipFree(h->staging);
-    (void)hipFree(h->wave_counters);
-    (void)hipFree(h->totals_dev);
-    (void)hipFree(h->first_bad);
-    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
-    delete h;
-    return POM_OK;
-}
-
-int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts)
-{
-    if (!out || n_envs <= 0 || n_envs > (int64_t)1 << 30) {
-        snprintf(g_err, sizeof g_err, "pom_batch_create: bad arguments");
-        return POM_E_ARG;
-    }
-    *out = nullptr;
-    PomBatchOptions o;
-    memset(&o, 0, sizeof o);
-    o.mode = POM_MODE_ENV;
-    if (opts) {
-        if (opts->struct_size <= 0 || opts->struct_size > (int)sizeof o) {
-            snprintf(g_err, sizeof g_err, "pom_batch_create: options struct_size %d not understood", opts->struct_size);
-            return POM_E_ARG;
-        }
-        memcpy(&o, opts, (size_t)opts->struct_size);
-    }
-    if (o.mode != POM_MODE_RAW && o.mode != POM_MODE_ENV) {
-        snprintf(g_err, sizeof g_err, "pom_batch_create: bad mode %d", o.mode);
-        return POM_E_ARG;
-    }
-    if (o.auto_reset < POM_RESET_OFF || o.auto_reset > POM_RESET_AT_END) {
-        snprintf(g_err, sizeof g_err, "pom_batch_create: auto_reset must be 0 (off), 1 (at the start of the next tick) or 2 (at the end of the tick)");
-        return POM_E_ARG;
-    }
-    int ndev = 0;
-    HIPCHK(hipGetDeviceCount(&ndev));
-    if (o.device < 0 || o.device >= ndev) {
-        snprintf(g_err, sizeof g_err, "pom_batch_create: device %d of %d", o.device, ndev);
-        return POM_E_HIP;
-    }
-    HIPCHK(hipSetDevice(o.device));
-    PomBatch* h = new (std::nothrow) PomBatch();
-    if (!h) return POM_E_NOMEM;
-    h->device = o.device;
-    h->n = n_envs;
-    h->n_pad = (n_envs + 63) / 64 * 64;
-    h->n_waves = h->n_pad / 16;
-    /* Kernel shape.  Default: the quad kernel (16 envs per wavefront, 4 adjacent lanes per env) — fastest at every batch
-     * size measured (profiles/r01_quad.txt).  The one-lane-per-env variants (64 / 32 / 16 envs per wavefront) stay
-     * selectable; all produce identical results. */
-    h->epw = 16;
-    h->quad = true;
-    if (o.lanes_per_env != 0 && o.lanes_per_env != 1 && o.lanes_per_env != 4) {
-        snprintf(g_err, sizeof g_err, "pom_batch_create: lanes_per_env must be 0, 1 or 4");
-        delete h;
-        return POM_E_ARG;
-    }
-    if (o.envs_per_wave != 0 && o.envs_per_wave != 16 && o.envs_per_wave != 32 && o.envs_per_wave != 64) {
-        snprintf(g_err, sizeof g_err, "pom_batch_create: envs_per_wave must be 0, 16, 32 or 64");
-        delete h;
-        return POM_E_ARG;
-    }
-    if (o.envs_per_wave != 0) {
-        h->epw = o.envs_per_wave;
-        h->quad = h->epw == 16 && o.lanes_per_env != 1;
-    } else if (o.lanes_per_env == 1) {
-        h->quad = false;
-        h->epw = h->n_pad <= 8192 ? 16 : 32;
-    }
-    if (o.lanes_per_env == 4 && !h->quad) {
-        snprintf(g_err, sizeof g_err, "pom_batch_create: lanes_per_env 4 needs envs_per_wave 16 (or 0)");
-        delete h;
-        return POM_E_ARG;
-    }
-    if (const char* ev = getenv("POM_EPW")) { /* tuning overrides for sweeps */
-        const int v = atoi(ev);
-        if (v == 16 || v == 32 || v == 64) {
-            h->epw = v;
-            h->quad = false;
-        }
-    }
-    if (const char* ev = getenv("POM_QUAD")) h->quad = atoi(ev) != 0 && h->epw == 16;
-    /* sub-batches per step: part 0 on the caller's stream, the others on internal streams.  Measured on MI355X at 65,536
-     * envs: one launch 26.4 us, two parts 22.3, three 20.4; FOUR concurrent streams of one process serialize on this stack
-     * (36 us; profiles/r01_streams.txt), and other streams of the process (RCCL) count against that budget, so the default
-     * stays at three only for batches where it matters and a caller can measure (pom_batch_set_streams, as bench.py does). */
-    h->parts = h->n_pad >= 49152 ? 3 : h->n_pad >= 8192 ? 2 : 1;
-    if (o.streams >= 1 && o.streams <= PomBatch::MAX_PARTS) h->parts = o.streams;
-    else if (o.streams != 0) {
-        snprintf(g_err, sizeof g_err, "pom_batch_create: streams must be 0..%d", (int)PomBatch::MAX_PARTS);
-        delete h;
-        return POM_E_ARG;
-    }
-    /* measured (MI355X, profiles/r01_fuse.txt): the fused kernel is 4-9 % faster up to 131,072 envs and 3 % slower at 262,144
-     * (it is capped at 128 VGPRs to keep 4 wavefronts per SIMD and parks ~25 long-lived values in scratch) */
-    h->fuse_policy = h->n_pad < 262144;
-    if (const char* ev = getenv("POM_FUSE")) h->fuse_policy = atoi(ev) != 0;
-    if (const char* ev = getenv("POM_MAIN_PART")) h->main_part = atoi(ev) != 0;
-    if (const char* ev = getenv("POM_STREAMS")) {
-        const int v = atoi(ev);
-        if (v >= 1 && v <= PomBatch::MAX_PARTS) h->parts = v;
-    }
-    if ((int64_t)h->parts > h->n_pad / h->epw) h->parts = (int)(h->n_pad / h->epw);
-    if (o.auto_reset == POM_RESET_AT_END && !h->quad) {
-        snprintf(g_err, sizeof g_err, "pom_batch_create: auto_reset = POM_RESET_AT_END is built for the default kernel shape "
-                 "(envs_per_wave 16, lanes_per_env 4) only");
-        delete h;
-        return POM_E_ARG;
-    }
-    h->mode = o.mode;
-    h->auto_reset = o.auto_reset;
-    h->max_steps = o.max_steps;
-    h->env_offset = o.env_offset;
-    h->fresh = o.fresh_boards != 0;
-    h->board_seed = o.board_seed;
-    h->staging_envs = h->n_pad < 16384 ? h->n_pad : 16384;
-#define ALLOC(ptr, bytes)                                              \
-    do {                                                               \
-        hipError_t e_ = hipMalloc((void**)&(ptr), (size_t)(bytes));    \
-        if (e_ != hipSuccess) {                                        \
-            set_err("hipMalloc", e_);                                  \
-            pom_batch_destroy(h);                                      \
-            return e_ == hipErrorOutOfMemory ? POM_E_NOMEM : POM_E_HIP; \
-        }                                                              \
-    } while (0)
-    if (o.stream) {
-        h->stream = (hipStream_t)o.stream;
-    } else {
-        hipError_t e_ = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-        if (e_ != hipSuccess) {
-            set_err("hipStreamCreate", e_);
-            delete h;
-            return POM_E_HIP;
-        }
-        h->own_stream = true;
-    }
-    if (ensure_sub_streams(h, h->parts) != POM_OK) {
-        pom_batch_destroy(h);
-        return POM_E_HIP;
-    }
-    const size_t rec_bytes = (size_t)POM_REC_DWORDS * 4 * (size_t)h->n_pad;
-    ALLOC(h->state, rec_bytes);
-    ALLOC(h->snap, rec_bytes);
-    ALLOC(h->moves_dev, (size_t)h->n_pad * 16);
-    ALLOC(h->staging, (size_t)h->staging_envs * POM_STATE_BYTES);
-    ALLOC(h->wave_counters, (size_t)h->n_waves * POM_CNT_N * 8);
-    ALLOC(h->totals_dev, POM_CNT_N * 8);
-    ALLOC(h->first_bad, sizeof(int));
-    ALLOC(h->episode, (size_t)h->n_pad * 4);
-    if (h->auto_reset == POM_RESET_AT_END) ALLOC(h->terminal, rec_bytes);
-#undef ALLOC
-    /* all-zero records are inert blank boards; padded envs are marked finished */
-    hipError_t e1 = hipMemsetAsync(h->state, 0, rec_bytes, h->stream);
-    hipError_t e2 = hipMemsetAsync(h->snap, 0, rec_bytes, h->stream);
-    hipError_t e3 = hipMemsetAsync(h->moves_dev, 0, (size_t)h->n_pad * 16, h->stream);
-    hipError_t e4 = hipMemsetAsync(h->wave_counters, 0, (size_t)h->n_waves * POM_CNT_N * 8, h->stream);
-    if (e4 == hipSuccess) e4 = hipMemsetAsync(h->episode, 0, (size_t)h->n_pad * 4, h->stream);
-    if (e4 == hipSuccess && h->terminal) e4 = hipMemsetAsync(h->terminal, 0, rec_bytes, h->stream);
-    hipError_t e5 = hipStreamSynchronize(h->stream);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
-        set_err("initial memset", e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4 != hipSuccess ? e4 : e5);
-        pom_batch_destroy(h);
-        return POM_E_HIP;
-    }
-    *out = h;
-    return POM_OK;
-}
-
-int64_t pom_batch_size(const PomBatch* h) { return h ? h->n : -1; }
-
-static int check_range(const PomBatch* h, int64_t first, int64_t count)
-{
-    if (!h || first < 0 || count < 0 || first + count > h->n) {
-        snprintf(g_err, sizeof g_err, "range [%lld, %lld) outside batch", (long long)first, (long long)(first + count));
-        return POM_E_ARG;
-    }
-    return POM_OK;
-}
-
-int pom_batch_upload(PomBatch* h, const void* states, int64_t first, int64_t count)
-{
-    int rc = check_range(h, first, count);
-    if (rc || !states) return rc ? rc : POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    const int big = INT_MAX;
-    HIPCHK(hipMemcpyAsync(h->first_bad, &big, sizeof big, hipMemcpyHostToDevice, h->stream));
-    int64_t bad_env = -1;
-    for (int64_t off = 0; off < count; off += h->staging_envs) {
-        const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
-        HIPCHK(hipMemcpyAsync(h->staging, (const char*)states + off * POM_STATE_BYTES, (size_t)c * POM_STATE_BYTES,
-                              hipMemcpyHostToDevice, h->stream));
-        pom_pack_kernel<<<dim3((unsigned)((c + 63) / 64)), dim3(64), 0, h->stream>>>(h->staging, first + off, c, h->state, h->snap,
-                                                                                     h->n_pad, h->first_bad);
-        HIPCHK(hipGetLastError());
-        int fb = 0;
-        HIPCHK(hipMemcpyAsync(&fb, h->first_bad, sizeof fb, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream)); /* staging is reused by the next chunk */
-        if (fb != big && bad_env < 0) {
-            bad_env = first + off + fb;
-            HIPCHK(hipMemcpyAsync(h->first_bad, &big, sizeof big, hipMemcpyHostToDevice, h->stream));
-        }
-    }
-    HIPCHK(hipMemsetAsync(h->episode + first, 0, (size_t)count * 4, h->stream)); /* an uploaded state is episode 0 of its env */
-    if (h->terminal) HIPCHK(hipMemsetAsync(h->terminal + first * POM_REC_DWORDS, 0, (size_t)count * POM_REC_DWORDS * 4, h->stream));
-    if (h->agent_mem) { /* uploaded envs start new games: fresh agents */
-        HIPCHK(hipMemsetAsync(h->agent_mem + first * 4, 0, (size_t)count * 16, h->stream));
-        HIPCHK(hipMemsetAsync(h->agent_mem + 4 * h->n_pad + first * 4, 0, (size_t)count * 16, h->stream));
-    }
-    if (bad_env >= 0) {
-        snprintf(g_err, sizeof g_err, "pom_batch_upload: env %lld holds a value outside the representable game states "
-                 "(it was replaced by a finished blank board)", (long long)bad_env);
-        return POM_E_UNREPRESENTABLE;
-    }
-    return POM_OK;
-}
-
-int pom_batch_download(PomBatch* h, void* states, int64_t first, int64_t count)
-{
-    int rc = check_range(h, first, count);
-    if (rc || !states) return rc ? rc : POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    for (int64_t off = 0; off < count; off += h->staging_envs) {
-        const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
-        HIPCHK(hipMemsetAsync(h->staging, 0, (size_t)c * POM_STATE_BYTES, h->stream));
-        pom_unpack_kernel<<<dim3((unsigned)((c + 63) / 64)), dim3(64), 0, h->stream>>>(h->state, first + off, c, h->n_pad, h->staging);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync((char*)states + off * POM_STATE_BYTES, h->staging, (size_t)c * POM_STATE_BYTES, hipMemcpyDeviceToHost,
-                              h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    return POM_OK;
-}
-
-int pom_batch_snapshot(PomBatch* h)
-{
-    if (!h) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    pom_snapshot_kernel<<<dim3((unsigned)((h->n_pad + 255) / 256)), dim3(256), 0, h->stream>>>(h->state, h->snap, h->n_pad);
-    HIPCHK(hipGetLastError());
-    return POM_OK;
-}
-
-static int ensure_sub_streams(PomBatch* h, int parts)
-{
-    if (parts <= 1) return POM_OK;
-    if (!h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    for (int k = 0; k < parts; k++) {
-        if (!h->sub[k]) HIPCHK(hipStreamCreateWithFlags(&h->sub[k], hipStreamNonBlocking));
-        if (!h->ev_join[k]) HIPCHK(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
-    }
-    return POM_OK;
-}
-
-/* caller's stream -> sub-streams: everything already queued on the caller's stream happens before the parts */
-static int fork_parts(PomBatch* h)
-{
-    if (h->parts == 1 || h->forked) return POM_OK;
-    HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-    for (int k = h->main_part; k < h->parts; k++) HIPCHK(hipStreamWaitEvent(h->sub[k], h->ev_fork, 0));
-    h->forked = true;
-    return POM_OK;
-}
-/* sub-streams -> caller's stream: whatever is queued on the caller's stream next sees all parts finished */
-static int join_parts(PomBatch* h)
-{
-    if (h->parts == 1 || !h->forked) return POM_OK;
-    for (int k = h->main_part; k < h->parts; k++) {
-        HIPCHK(hipEventRecord(h->ev_join[k], h->sub[k]));
-        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join[k], 0));
-    }
-    h->forked = false;
-    return POM_OK;
-}
-
-static int ensure_agent_mem(PomBatch* h)
-{
-    if (!h->agent_mem) {
-        if (int jr = join_parts(h)) return jr; /* the next launch forks the sub-streams again, after this memset */
-        HIPCHK(hipMalloc((void**)&h->agent_mem, (size_t)h->n_pad * 32));
-        HIPCHK(hipMemsetAsync(h->agent_mem, 0, (size_t)h->n_pad * 32, h->stream));
-    }
-    return POM_OK;
-}
-
-static int fill_params(PomBatch* h, StepParams& p, const int32_t* moves_dev, uint64_t seed, int dist, int ticks)
-{
-    p.agent_mem = h->agent_mem;
-    p.state = h->state;
-    p.snap = h->snap;
-    p.terminal = h->terminal;
-    p.moves = moves_dev;
-    p.wave_counters = h->wave_counters;
-#if defined(POM_TRUNC)
-    p.trunc = getenv("POM_TRUNC_AT") ? atoi(getenv("POM_TRUNC_AT")) : 990;
-#endif
-    p.n = h->n;
-    p.n_pad = h->n_pad;
-    p.env_offset = h->env_offset;
-    p.seed = seed;
-    p.tick0 = (uint32_t)h->tick;
-    p.dist = dist;
-    p.ticks = ticks;
-    p.mode = h->mode;
-    p.auto_reset = h->auto_reset;
-    p.max_steps = h->max_steps;
-    p.episode = h->episode;
-    p.board_seed = h->board_seed;
-    p.fresh = h->fresh;
-    p.block0 = p.block_end = 0;
-#if defined(POM_DIAG)
-    if (!h->diag) {
-        HIPCHK(hipMalloc((void**)&h->diag, (size_t)h->n_waves * POM_PH_N * 8));
-        HIPCHK(hipMemsetAsync(h->diag, 0, (size_t)h->n_waves * POM_PH_N * 8, h->stream));
-    }
-    p.diag = h->diag;
-#endif
-    return POM_OK;
-}
-
-/* one dispatch of the step kernel the handle is configured for, over tiles [p.block0, p.block_end) */
-static hipError_t dispatch_step(const PomBatch* h, const StepParams& p, hipStream_t st, bool policy, hipEvent_t ev0, hipEvent_t ev1)
-{
-    const dim3 grid((unsigned)((p.block_end - p.block0 + POM_WPB - 1) / POM_WPB));
-    const bool fresh = h->fresh && h->mode == POM_MODE_ENV && h->auto_reset;
-#define POM_LAUNCH(E, G) \
-    (fresh ? hipExtLaunchKernelGGL((pom_step_kernel<E, G, true>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p) \
-           : hipExtLaunchKernelGGL((pom_step_kernel<E, G, false>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p))
-#define POM_LAUNCH_Q(F, P, A)                                                                                                          \
-    (p.ticks == 1 ? hipExtLaunchKernelGGL((pom_step_kernel<16, 4, F, P, A, true>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p) \
-                  : hipExtLaunchKernelGGL((pom_step_kernel<16, 4, F, P, A, false>), grid, dim3(64 * POM_WPB), 0, st, ev0, ev1, 0, p))
-    const bool at_end = h->auto_reset == POM_RESET_AT_END && h->mode == POM_MODE_ENV; /* quad shape only: checked at creation */
-    if (at_end) {
-        if (policy) fresh ? POM_LAUNCH_Q(true, true, true) : POM_LAUNCH_Q(false, true, true);
-        else fresh ? POM_LAUNCH_Q(true, false, true) : POM_LAUNCH_Q(false, false, true);
-    } else if (policy) { /* the caller checked h->quad */
-        fresh ? POM_LAUNCH_Q(true, true, false) : POM_LAUNCH_Q(false, true, false);
-    } else if (h->epw == 64) POM_LAUNCH(64, 1);
-    else if (h->epw == 32) POM_LAUNCH(32, 1);
-    else if (h->quad) fresh ? POM_LAUNCH_Q(true, false, false) : POM_LAUNCH_Q(false, false, false);
-    else POM_LAUNCH(16, 1);
-#undef POM_LAUNCH_Q
-#undef POM_LAUNCH
-    return hipGetLastError();
-}
-
-/* `one_launch`: the whole batch in ONE launch on the caller's stream.  For steps that have to be joined with the caller's stream
- * every tick (explicit moves): forking into sub-streams and joining them again costs more than the overlap gains
- * (65,536 envs, MI355X: 23.3 us per step as one launch, 43.8 as two, 60.2 as three; profiles/r02a_explicit_streams.txt). */
-static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int dist, int ticks, bool policy = false, bool one_launch = false)
-{
-    StepParams p;
-    if (int rc = fill_params(h, p, moves_dev, seed, dist, ticks)) return rc;
-    const int64_t tiles = h->n_pad / h->epw;
-    const int parts = one_launch ? 1 : h->parts;
-    int rc = one_launch ? join_parts(h) : fork_parts(h);
-    if (rc) return rc;
-    for (int k = 0; k < parts; k++) {
-        const int64_t b0 = tiles * k / parts, b1 = tiles * (k + 1) / parts;
-        if (b1 <= b0) continue;
-        hipStream_t st = (parts == 1 || k < h->main_part) ? h->stream : h->sub[k];
-        p.block0 = b0;
-        p.block_end = b1;
-        /* per-launch timing (pom_batch_profile): start / stop events attached to the dispatch itself, i.e. the kernel's own
-         * duration as a profiler reports it, not the stream's period (events recorded around a launch also time the gap) */
-        const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
-        hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
-        HIPCHK(dispatch_step(h, p, st, policy, ev0, ev1));
-        if (prof) h->prof_n++;
-    }
-    return POM_OK;
-}
-
-/* ---- several ticks in one call: one issuing thread per part ---------------------------------------------------------------
- * A step of `parts` launches every ~18 us leaves the host ~6 us per launch; one thread that also pays the API's own overhead
- * does not always keep that up, and a short run then measures the host (20-step bursts: 24-36 us per step on a busy box
- * against 18 in a long run, where the queues have time to fill).  The parts are independent — each has its own stream and
- * its launches depend only on that stream's order — so part k's launches of ALL the ticks of the call are issued by a
- * helper thread of its own (created once per handle), part 0's by the caller; the call returns when everything is queued.
- * Results cannot depend on this: the same kernels with the same arguments go to the same streams in the same per-stream order. */
-struct PomIssuer {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    bool has_job = false, quit = false, busy = false;
-    std::atomic<int> posted{0}; /* bumped with every job and by pom_batch_fork: a thread that has just worked (or was told that work
-                                   is coming) polls this for up to a millisecond before it goes to sleep on the condition variable
-                                   — a futex wake-up costs 10-30 us, a tenth of a 20-step burst */
-    /* the job */
-    StepParams p;
-    hipStream_t st = nullptr;
-    int launches = 0, ticks_per_launch = 1, last_ticks = 1;
-    bool policy = false;
-    hipError_t err = hipSuccess;
-};
-
-static void issuer_main(PomBatch* h, PomIssuer* w)
-{
-    (void)hipSetDevice(h->device);
-    std::unique_lock<std::mutex> lk(w->mu);
-    int seen = w->posted.load();
-    for (;;) {
-        if (!w->has_job && !w->quit) { /* poll briefly, then sleep */
-            lk.unlock();
-            const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(1);
-            while (w->posted.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() < until) {
-            }
-            lk.lock();
-        }
-        if (!w->has_job && !w->quit && w->posted.load() != seen) { /* woken by pom_batch_fork: a job is on its way */
-            seen = w->posted.load();
-            continue;
-        }
-        w->cv.wait(lk, [w, seen] { return w->has_job || w->quit || w->posted.load() != seen; });
-        seen = w->posted.load();
-        if (w->quit) return;
-        if (!w->has_job) continue;
-        w->has_job = false;
-        StepParams p = w->p;
-        hipError_t err = hipSuccess;
-        for (int i = 0; i < w->launches && err == hipSuccess; i++) {
-            p.ticks = i + 1 == w->launches ? w->last_ticks : w->ticks_per_launch;
-            err = dispatch_step(h, p, w->st, w->policy, nullptr, nullptr);
-            p.tick0 += (uint32_t)w->ticks_per_launch;
-        }
-        w->err = err;
-        w->busy = false;
-        w->cv.notify_all();
-    }
-}
-
-static void stop_issuers(PomBatch* h)
-{
-    for (int k = 0; k < PomBatch::MAX_PARTS; k++) {
-        PomIssuer* w = h->issuers[k];
-        if (!w) continue;
-        {
-            std::lock_guard<std::mutex> g(w->mu);
-            w->quit = true;
-        }
-        w->cv.notify_all();
-        if (w->th.joinable()) w->th.join();
-        delete w;
-        h->issuers[k] = nullptr;
-    }
-}
-
-/* `launches` dispatches per part (ticks_per_launch ticks each, the last one `last_ticks`), tick counter advanced by the caller */
-static int launch_many(PomBatch* h, uint64_t seed, int dist, int launches, int ticks_per_launch, int last_ticks, bool policy)
-{
-    StepParams p;
-    if (int rc = fill_params(h, p, nullptr, seed, dist, ticks_per_launch)) return rc;
-    const int64_t tiles = h->n_pad / h->epw;
-    const int parts = h->parts;
-    if (int rc = fork_parts(h)) return rc;
-    int started[PomBatch::MAX_PARTS] = {};
-    hipError_t err = hipSuccess;
-    /* The first launch of EVERY part is issued right here, the caller's own part(s) first: a helper thread takes 10-25 us to
-     * pick its job up (profiles/r02_region_trace.txt), and a part that starts a step late finishes a step late — alone on the
-     * device.  The helpers get the remaining launches of their parts and have one step's time to wake up. */
-    const int head = 1; /* 2 and 3 measured the same (20-step regions, scripts/ab_env.sh) */
-    for (int i = 0; i < head; i++) {
-        const int tk = i + 1 == launches ? last_ticks : ticks_per_launch;
-        for (int pass = 0; pass < 2; pass++) {
-            for (int k = 0; k < parts && err == hipSuccess; k++) {
-                const bool own = parts == 1 || k < h->main_part;
-                if (own != (pass == 0)) continue;
-                const int64_t b0 = tiles * k / parts, b1 = tiles * (k + 1) / parts;
-                if (b1 <= b0) continue;
-                StepParams q = p;
-                q.block0 = b0;
-                q.block_end = b1;
-                q.ticks = tk;
-                err = dispatch_step(h, q, own ? h->stream : h->sub[k], policy, nullptr, nullptr);
-            }
-        }
-        p.tick0 += (uint32_t)ticks_per_launch;
-    }
-    const int rest = launches - head;
-    for (int k = h->main_part; k < parts && rest > 0 && err == hipSuccess; k++) { /* the sub-stream parts: hand them to their threads */
-        const int64_t b0 = tiles * k / parts, b1 = tiles * (k + 1) / parts;
-        if (b1 <= b0) continue;
-        if (!h->issuers[k]) {
-            h->issuers[k] = new (std::nothrow) PomIssuer();
-            if (!h->issuers[k]) return POM_E_NOMEM;
-            h->issuers[k]->th = std::thread(issuer_main, h, h->issuers[k]);
-        }
-        PomIssuer* w = h->issuers[k];
-        {
-            std::lock_guard<std::mutex> g(w->mu);
-            w->p = p;
-            w->p.block0 = b0;
-            w->p.block_end = b1;
-            w->st = h->sub[k];
-            w->launches = rest;
-            w->ticks_per_launch = ticks_per_launch;
-            w->last_ticks = last_ticks;
-            w->policy = policy;
-            w->err = hipSuccess;
-            w->busy = true;
-            w->has_job = true;
-            w->posted.fetch_add(1, std::memory_order_release);
-        }
-        w->cv.notify_all();
-        started[k] = 1;
-    }
-    for (int k = 0; k < (parts == 1 ? 1 : h->main_part); k++) { /* the rest of the caller's own part(s) */
-        const int64_t b0 = tiles * k / parts, b1 = tiles * (k + 1) / parts;
-        if (b1 <= b0) continue;
-        StepParams q = p;
-        q.block0 = b0;
-        q.block_end = b1;
-        for (int i = 0; i < rest && err == hipSuccess; i++) {
-            q.ticks = i + 1 == rest ? last_ticks : ticks_per_launch;
-            err = dispatch_step(h, q, h->stream, policy, nullptr, nullptr);
-            q.tick0 += (uint32_t)ticks_per_launch;
-        }
-    }
-    for (int k = 0; k < parts; k++) { /* everything is queued when the call returns */
-        if (!started[k]) continue;
-        PomIssuer* w = h->issuers[k];
-        std::unique_lock<std::mutex> lk(w->mu);
-        w->cv.wait(lk, [w] { return !w->busy; });
-        if (w->err != hipSuccess && err == hipSuccess) err = w->err;
-    }
-    if (err != hipSuccess) {
-        set_err("pom_step_kernel launch", err);
-        return POM_E_HIP;
-    }
-    return POM_OK;
-}
-
-int pom_batch_step_device(PomBatch* h, const int32_t* moves_dev)
-{
-    if (!h || !moves_dev) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    /* the moves were produced on the caller's stream and may be overwritten there right after this call */
-    return launch_step(h, moves_dev, 0, 0, 1, false, true);
-}
-
-int pom_batch_step(PomBatch* h, const int32_t* moves_host)
-{
-    if (!h || !moves_host) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    int rc = join_parts(h); /* the previous step's parts still read moves_dev */
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(h->moves_dev, moves_host, (size_t)h->n * 16, hipMemcpyHostToDevice, h->stream));
-    return launch_step(h, h->moves_dev, 0, 0, 1, false, true);
-}
-
-int pom_batch_step_random(PomBatch* h, uint64_t seed, int32_t dist, int32_t ticks, int32_t ticks_per_launch)
-{
-    if (!h || ticks < 0 || ticks_per_launch < 1 || dist < POM_DIST_HARMLESS || dist > POM_DIST_STRESS) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    const int32_t launches = (ticks + ticks_per_launch - 1) / ticks_per_launch;
-    if (launches >= 2 && h->parts > 1 && !h->profiling) { /* several launches per part: one issuing thread per part */
-        const int32_t last = ticks - (launches - 1) * ticks_per_launch;
-        int rc = launch_many(h, seed, dist, launches, ticks_per_launch, last, false);
-        if (rc) return rc;
-        h->tick += (uint64_t)ticks;
-        return POM_OK;
-    }
-    for (int32_t done = 0; done < ticks;) {
-        const int32_t t = ticks - done < ticks_per_launch ? ticks - done : ticks_per_launch;
-        int rc = launch_step(h, nullptr, seed, dist, t);
-        if (rc) return rc;
-        h->tick += (uint64_t)t;
-        done += t;
-    }
-    return POM_OK;
-}
-
-int pom_batch_set_tick(PomBatch* h, int64_t tick)
-{
-    if (!h || tick < 0) return POM_E_ARG;
-    h->tick = (uint64_t)tick;
-    return POM_OK;
-}
-
-int pom_batch_status(PomBatch* h, int64_t first, int64_t count, int32_t* done, int32_t* winner, int32_t* draw, int32_t* alive,
-                     int32_t* time_step, uint32_t* ubflags)
-{
-    int rc = check_range(h, first, count);
-    if (rc) return rc;
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    void* outs[6] = {done, winner, draw, alive, time_step, ubflags};
-    /* the AoS staging buffer doubles as scratch: 6 ints per env << 251 */
-    for (int64_t off = 0; off < count; off += h->staging_envs) {
-        const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
-        pom_status_kernel<<<dim3((unsigned)((c + 255) / 256)), dim3(256), 0, h->stream>>>(h->state, first + off, c, h->n_pad, h->staging);
-        HIPCHK(hipGetLastError());
-        for (int k = 0; k < 6; k++)
-            if (outs[k])
-                HIPCHK(hipMemcpyAsync((int32_t*)outs[k] + off, h->staging + (int64_t)k * c, (size_t)c * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    return POM_OK;
-}
-
-int pom_batch_last_results(PomBatch* h, int64_t first, int64_t count, int32_t* finished, int32_t* winner, int32_t* draw,
-                           int32_t* length, int32_t* alive)
-{
-    int rc = check_range(h, first, count);
-    if (rc) return rc;
-    if (!h->terminal) {
-        snprintf(g_err, sizeof g_err, "pom_batch_last_results: the batch was not created with auto_reset = POM_RESET_AT_END");
-        return POM_E_ARG;
-    }
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    void* outs[5] = {finished, winner, draw, length, alive};
-    for (int64_t off = 0; off < count; off += h->staging_envs) {
-        const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
-        pom_results_kernel<<<dim3((unsigned)((c + 255) / 256)), dim3(256), 0, h->stream>>>(h->state, h->terminal, first + off, c, h->n_pad,
-                                                                                            h->staging);
-        HIPCHK(hipGetLastError());
-        for (int k = 0; k < 5; k++)
-            if (outs[k])
-                HIPCHK(hipMemcpyAsync((int32_t*)outs[k] + off, h->staging + (int64_t)k * c, (size_t)c * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    return POM_OK;
-}
-
-int pom_batch_download_terminal(PomBatch* h, void* states, int64_t first, int64_t count)
-{
-    int rc = check_range(h, first, count);
-    if (rc || !states) return rc ? rc : POM_E_ARG;
-    if (!h->terminal) {
-        snprintf(g_err, sizeof g_err, "pom_batch_download_terminal: the batch was not created with auto_reset = POM_RESET_AT_END");
-        return POM_E_ARG;
-    }
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    for (int64_t off = 0; off < count; off += h->staging_envs) {
-        const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
-        HIPCHK(hipMemsetAsync(h->staging, 0, (size_t)c * POM_STATE_BYTES, h->stream));
-        pom_unpack_aos_kernel<<<dim3((unsigned)((c + 63) / 64)), dim3(64), 0, h->stream>>>(h->terminal, first + off, c, h->staging);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync((char*)states + off * POM_STATE_BYTES, h->staging, (size_t)c * POM_STATE_BYTES, hipMemcpyDeviceToHost,
-                              h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    return POM_OK;
-}
-
-int pom_batch_counters_device(PomBatch* h, void* dev_int64x4)
-{
-    if (!h || !dev_int64x4) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    pom_reduce_counters_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(h->wave_counters, h->n_waves, (int64_t*)dev_int64x4);
-    HIPCHK(hipGetLastError());
-    return POM_OK;
-}
-
-int pom_batch_counters(PomBatch* h, int64_t out[POM_CNT_N])
-{
-    if (!h || !out) return POM_E_ARG;
-    int rc = pom_batch_counters_device(h, h->totals_dev);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(out, h->totals_dev, POM_CNT_N * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return POM_OK;
-}
-
-int pom_batch_reset_counters(PomBatch* h)
-{
-    if (!h) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    HIPCHK(hipMemsetAsync(h->wave_counters, 0, (size_t)h->n_waves * POM_CNT_N * 8, h->stream));
-    return POM_OK;
-}
-
-int pom_batch_sync(PomBatch* h)
-{
-    if (!h) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return POM_OK;
-}
-
-int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_agent, int32_t* agent_attrs_dev,
-                      int32_t* env_attrs_dev)
-{
-    if (!h || !planes_dev || dtype < POM_OBS_U8 || dtype > POM_OBS_F32) return POM_E_ARG;
-    const int64_t esz = dtype == POM_OBS_U8 ? 1 : dtype == POM_OBS_F16 ? 2 : 4;
-    if (((uintptr_t)planes_dev & (4 * esz - 1)) || ((uintptr_t)agent_attrs_dev & 15) || ((uintptr_t)env_attrs_dev & 15) ||
-        (dtype == POM_OBS_U8 && !per_agent && ((uintptr_t)planes_dev & 15)))
-    {
-        snprintf(g_err, sizeof g_err, "pom_batch_observe: output pointers must be 16-byte aligned");
-        return POM_E_ARG;
-    }
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    ObserveParams p;
-    p.state = h->state;
-    p.n = h->n;
-    p.n_pad = h->n_pad;
-    p.block0 = 0;
-    p.planes = planes_dev;
-    p.agent_attrs = agent_attrs_dev;
-    p.env_attrs = env_attrs_dev;
-    p.dtype = dtype;
-    p.per_agent = per_agent ? 1 : 0;
-    pom_observe_kernel<<<dim3((unsigned)((h->n + 15) / 16)), dim3(64), 0, h->stream>>>(p);
-    HIPCHK(hipGetLastError());
-    return POM_OK;
-}
-
-int pom_batch_generate(PomBatch* h, uint64_t board_seed)
-{
-    if (!h) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    h->board_seed = board_seed;
-    pom_generate_kernel<<<dim3((unsigned)((h->n + 15) / 16)), dim3(64), 0, h->stream>>>(h->state, h->snap, h->episode, h->n, h->n_pad,
-                                                                                         h->env_offset, board_seed);
-    HIPCHK(hipGetLastError());
-    if (h->agent_mem) HIPCHK(hipMemsetAsync(h->agent_mem, 0, (size_t)h->n_pad * 32, h->stream)); /* new games: fresh agents */
-    if (h->terminal) HIPCHK(hipMemsetAsync(h->terminal, 0, (size_t)h->n_pad * POM_REC_DWORDS * 4, h->stream));
-    return POM_OK;
-}
-
-int pom_batch_episodes(PomBatch* h, int64_t first, int64_t count, uint32_t* out)
-{
-    int rc = check_range(h, first, count);
-    if (rc || !out) return rc ? rc : POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    HIPCHK(hipMemcpyAsync(out, h->episode + first, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return POM_OK;
-}
-
-int pom_batch_moves_device(PomBatch* h, int32_t** moves_dev)
-{
-    if (!h || !moves_dev) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr; /* what the caller queues on the handle's stream next sees the policy's moves */
-    *moves_dev = h->moves_dev;
-    return POM_OK;
-}
-
-int pom_batch_stream(PomBatch* h, void** stream)
-{
-    if (!h || !stream) return POM_E_ARG;
-    *stream = (void*)h->stream;
-    return POM_OK;
-}
-
-int pom_batch_device_view(PomBatch* h, void** base, int64_t* n_pad, int32_t* rec_dwords)
-{
-    if (!h) return POM_E_ARG;
-    if (base) *base = h->state;
-    if (n_pad) *n_pad = h->n_pad;
-    if (rec_dwords) *rec_dwords = POM_REC_DWORDS;
-    return POM_OK;
-}
-
-#if defined(POM_DIAG)
-/* diagnostic build only: the step kernel with zero ticks = HBM -> LDS -> HBM round trip of every record */
-int pom_diag_copy_only(PomBatch* h)
-{
-    return launch_step(h, nullptr, 0, 0, 0);
-}
-/* diagnostic build only: read and clear the per-phase cycle sums (summed over wavefronts) */
-int pom_diag_read(PomBatch* h, long long out[POM_PH_N])
-{
-    if (!h || !h->diag) return POM_E_ARG;
-    long long* tmp = new long long[(size_t)h->n_waves * POM_PH_N];
-    HIPCHK(hipMemcpyAsync(tmp, h->diag, (size_t)h->n_waves * POM_PH_N * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemsetAsync(h->diag, 0, (size_t)h->n_waves * POM_PH_N * 8, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    for (int k = 0; k < POM_PH_N; k++) out[k] = 0;
-    for (int64_t w = 0; w < h->n_waves; w++)
-        for (int k = 0; k < POM_PH_N; k++) out[k] += tmp[w * POM_PH_N + k];
-    delete[] tmp;
-    return POM_OK;
-}
-#endif
-
-#if defined(POM_DIAG)
-/* diagnostic build only: the per-wavefront accumulators as they are (n_waves x POM_PH_N), then cleared */
-extern "C" int pom_diag_read_raw(PomBatch* h, long long* out, long long max_waves)
-{
-    if (!h || !h->diag || max_waves < h->n_waves) return POM_E_ARG;
-    if (int jr = join_parts(h)) return jr;
-    HIPCHK(hipMemcpyAsync(out, h->diag, (size_t)h->n_waves * POM_PH_N * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemsetAsync(h->diag, 0, (size_t)h->n_waves * POM_PH_N * 8, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return POM_OK;
-}
-#endif
-
-#if defined(POM_DIAG)
-extern "C" int pom_diag_policy_read(PomBatch* h, long long out[POM_PP_N])
-{
-    if (!h || !h->diag_pol) return POM_E_ARG;
-    const size_t nw = (size_t)(h->n_pad / 16);
-    if (int jr = join_parts(h)) return jr;
-    long long* tmp = new long long[nw * POM_PP_N];
-    HIPCHK(hipMemcpyAsync(tmp, h->diag_pol, nw * POM_PP_N * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemsetAsync(h->diag_pol, 0, nw * POM_PP_N * 8, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    for (int k = 0; k < POM_PP_N; k++) out[k] = 0;
-    for (size_t w = 0; w < nw; w++)
-        for (int k = 0; k < POM_PP_N; k++) out[k] += tmp[w * POM_PP_N + k];
-    delete[] tmp;
-    return POM_OK;
-}
-#endif
-
-int pom_batch_set_streams(PomBatch* h, int32_t streams)
-{
-    if (!h || streams < 1 || streams > PomBatch::MAX_PARTS) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    const int64_t tiles = h->n_pad / h->epw;
-    const int want = (int64_t)streams > tiles ? (int)tiles : streams;
-    if (int er = ensure_sub_streams(h, want)) return er;
-    h->parts = want;
-    return POM_OK;
-}
-
-static int launch_policy(PomBatch* h, uint64_t seed)
-{
-    if (int rc = ensure_agent_mem(h)) return rc;
-    PolicyParams p;
-    p.state = h->state;
-    p.snap = h->snap;
-    p.agent_mem = h->agent_mem;
-    p.moves = h->moves_dev;
-    p.n = h->n;
-    p.n_pad = h->n_pad;
-    p.env_offset = h->env_offset;
-    p.seed = seed;
-    p.tick = (uint32_t)h->tick;
-    p.mode = h->mode;
-    p.auto_reset = h->auto_reset;
-    p.episode = h->episode;
-    p.board_seed = h->board_seed;
-    p.fresh = h->fresh;
-#if defined(POM_DIAG)
-    if (!h->diag_pol) {
-        HIPCHK(hipMalloc((void**)&h->diag_pol, (size_t)(h->n_pad / 16) * POM_PP_N * 8));
-        HIPCHK(hipMemsetAsync(h->diag_pol, 0, (size_t)(h->n_pad / 16) * POM_PP_N * 8, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    p.diag = h->diag_pol;
-#endif
-    /* same split and the same streams as the tick, so that part k's policy -> tick -> policy chain pipelines */
-    const int64_t tiles = h->n_pad / 16, step_tiles = h->n_pad / h->epw;
-    int rc = fork_parts(h);
-    if (rc) return rc;
-    for (int k = 0; k < h->parts; k++) {
-        /* the tick's part k covers envs [step_tiles*k/parts, ...) * epw: use the same env boundaries */
-        const int64_t e0 = step_tiles * k / h->parts * h->epw, e1 = step_tiles * (k + 1) / h->parts * h->epw;
-        const int64_t b0 = e0 / 16, b1 = e1 / 16;
-        if (b1 <= b0) continue;
-        (void)tiles;
-        p.block0 = b0;
-        hipStream_t st = (h->parts == 1 || k < h->main_part) ? h->stream : h->sub[k];
-        pom_policy_kernel<<<dim3((unsigned)(b1 - b0)), dim3(64), 0, st>>>(p);
-        HIPCHK(hipGetLastError());
-    }
-    return POM_OK;
-}
-
-int pom_batch_policy_simple(PomBatch* h, uint64_t seed, int32_t* moves_out_host)
-{
-    if (!h) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    int rc = launch_policy(h, seed);
-    if (rc) return rc;
-    if (moves_out_host) {
-        if (int jr = join_parts(h)) return jr;
-        HIPCHK(hipMemcpyAsync(moves_out_host, h->moves_dev, (size_t)h->n * 16, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    return POM_OK;
-}
-
-int pom_batch_step_policy(PomBatch* h)
-{
-    if (!h) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    int rc = launch_step(h, h->moves_dev, 0, 0, 1);
-    if (rc) return rc;
-    h->tick += 1;
-    return POM_OK;
-}
-
-int pom_batch_step_simple(PomBatch* h, uint64_t seed, int32_t ticks)
-{
-    if (!h || ticks < 0) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    if (h->quad && h->fuse_policy) { /* the fused kernel: policy and tick on one load of the record */
-        if (int rc = ensure_agent_mem(h)) return rc;
-        if (ticks >= 2 && h->parts > 1 && !h->profiling) {
-            int rc = launch_many(h, seed, 0, ticks, 1, 1, true);
-            if (rc) return rc;
-            h->tick += (uint64_t)ticks;
-            return POM_OK;
-        }
-        for (int32_t t = 0; t < ticks; t++) {
-            if (int rc = launch_step(h, nullptr, seed, 0, 1, true)) return rc;
-            h->tick += 1;
-        }
-        return POM_OK;
-    }
-    for (int32_t t = 0; t < ticks; t++) {
-        int rc = launch_policy(h, seed);
-        if (!rc) rc = launch_step(h, h->moves_dev, 0, 0, 1);
-        if (rc) return rc;
-        h->tick += 1;
-    }
-    return POM_OK;
-}
-
-int pom_batch_policy_memory(PomBatch* h, int64_t first, int64_t count, int32_t* out16)
-{
-    int rc = check_range(h, first, count);
-    if (rc || !out16) return rc ? rc : POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    if (!h->agent_mem) {
-        memset(out16, 0, (size_t)count * 4 * 16 * sizeof(int32_t));
-        return POM_OK;
-    }
-    uint32_t* tmp = new (std::nothrow) uint32_t[(size_t)count * 8];
-    if (!tmp) return POM_E_NOMEM;
-    hipError_t e1 = hipMemcpyAsync(tmp, h->agent_mem + first * 4, (size_t)count * 16, hipMemcpyDeviceToHost, h->stream);
-    hipError_t e2 = hipMemcpyAsync(tmp + count * 4, h->agent_mem + 4 * h->n_pad + first * 4, (size_t)count * 16, hipMemcpyDeviceToHost, h->stream);
-    hipError_t e3 = hipStreamSynchronize(h->stream);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-        delete[] tmp;
-        set_err("policy memory download", e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3);
-        return POM_E_HIP;
-    }
-    for (int64_t k = 0; k < count * 4; k++) pom_policy_mem_unpack(tmp[k], tmp[count * 4 + k], out16 + 16 * k);
-    delete[] tmp;
-    return POM_OK;
-}
-
-int pom_batch_fork(PomBatch* h)
-{
-    if (!h) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    for (int k = 0; k < PomBatch::MAX_PARTS; k++) /* the issuing threads of multi-tick calls: work is coming, stay awake for it */
-        if (h->issuers[k]) {
-            h->issuers[k]->posted.fetch_add(1, std::memory_order_release);
-            h->issuers[k]->cv.notify_all();
-        }
-    return fork_parts(h);
-}
-
-int pom_batch_flush(PomBatch* h)
-{
-    if (!h) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    return join_parts(h);
-}
-
-int pom_batch_profile(PomBatch* h, int enable)
-{
-    if (!h) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    if (enable && !h->prof_ev[0])
-        for (int k = 0; k < 2 * PomBatch::PROF_RING; k++) HIPCHK(hipEventCreate(&h->prof_ev[k]));
-    h->profiling = enable != 0;
-    h->prof_n = 0;
-    return POM_OK;
-}
-
-int pom_batch_profile_read(PomBatch* h, double* mean_ms, int64_t* launches)
-{
-    if (!h) return POM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    double sum = 0;
-    for (int k = 0; k < h->prof_n; k++) {
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, h->prof_ev[2 * k], h->prof_ev[2 * k + 1]));
-        sum += ms;
-    }
-    if (mean_ms) *mean_ms = h->prof_n ? sum / h->prof_n : 0.0;
-    if (launches) *launches = h->prof_n;
-    h->prof_n = 0;
-    return POM_OK;
-}
-
-int pom_batch_launch_shape(PomBatch* h, int32_t* envs_per_wave, int32_t* lanes_per_env, int32_t* launches_per_step)
-{
-    if (!h) return POM_E_ARG;
-    if (envs_per_wave) *envs_per_wave = h->epw;
-    if (lanes_per_env) *lanes_per_env = h->quad ? 4 : 1;
-    if (launches_per_step) *launches_per_step = h->parts;
-    return POM_OK;
-}
-
-int pom_step(void* state_1004, const int32_t moves[4])
-{
-    static std::mutex mu;
-    static PomBatch* one = nullptr;
-    if (!state_1004 || !moves) return POM_E_ARG;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!one) {
-        PomBatchOptions o;
-        memset(&o, 0, sizeof o);
-        o.struct_size = sizeof o;
-        o.mode = POM_MODE_RAW;
-        int rc = pom_batch_create(&one, 1, &o);
-        if (rc) return rc;
-    }
-    int rc = pom_batch_upload(one, state_1004, 0, 1);
-    if (rc) return rc;
-    rc = pom_batch_step(one, moves);
-    if (rc) return rc;
-    return pom_batch_download(one, state_1004, 0, 1);
-}
-
-} /* extern "C" */
+#endif /* POM_KERNELS_H_ */

@@ -1,6 +1,6 @@
 /*
  * pom_policy_body.h — the reference's heuristic policy `agents::SimpleAgent` for ONE agent, written against an abstract
- * per-lane store so the identical source runs on gfx950 (pom_policy_kernel in pom_kernels.hip, lane = agent) and, in
+ * per-lane store so the identical source runs on gfx950 (pom_policy_kernel in pom_kernels.h, lane = agent) and, in
  * tests/emul only, on the host for fuzzing against the oracle.  SURVEY.md §8 row f1; config 3 of BASELINE.json.
  *
  * Semantics = SimpleAgent::act (/root/reference/src/agents/simple_agent.cpp:51-137) with the strategy helpers of

@@ -1,0 +1,630 @@
+/*
+ * pom_runtime.h — host runtime of the batched stepper: the batch handle, its streams, and how a step becomes launches of
+ * pom_step_kernel (pom_kernels.h).  The C-ABI functions of include/pom_batch.h (pom_batch.hip) are thin wrappers over this.
+ */
+#ifndef POM_RUNTIME_H_
+#define POM_RUNTIME_H_
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <thread>
+
+#include "pom_kernels.h"
+
+static thread_local char g_err[256] = "";
+static void set_err(const char* what, hipError_t e)
+{
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+}
+#define HIPCHK(call)                      \
+    do {                                  \
+        hipError_t e_ = (call);           \
+        if (e_ != hipSuccess) {           \
+            set_err(#call, e_);           \
+            return POM_E_HIP;             \
+        }                                 \
+    } while (0)
+
+struct PomBatch {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n = 0, n_pad = 0, n_waves = 0, env_offset = 0; /* n_waves: counter slots, sized for the smallest EPW */
+    int epw = 64;
+    bool quad = false; /* EPW 16 with four lanes per env (pom_step_kernel<16, 4>) */
+    int mode = POM_MODE_ENV, auto_reset = 0, max_steps = 0;
+    uint32_t* state = nullptr;
+    uint32_t* snap = nullptr;       /* restart snapshot, array of structs */
+    uint32_t* terminal = nullptr;   /* POM_RESET_AT_END: final record of each env's last finished episode, array of structs */
+    int32_t* moves_dev = nullptr;   /* n_pad x 4 */
+    uint32_t* agent_mem = nullptr;  /* SimpleAgent memory, [2][4 * n_pad], allocated on first use */
+    uint32_t* episode = nullptr;    /* games started per env (fresh boards) */
+    uint64_t board_seed = 0;
+    int fresh = 0;
+    int32_t* staging = nullptr;     /* staging_envs x 251 dwords (AoS), also status scratch */
+    int64_t staging_envs = 0;
+    int64_t* wave_counters = nullptr;
+    int64_t* totals_dev = nullptr;
+    int* first_bad = nullptr;
+    uint64_t tick = 0;
+    /* A step is issued as `parts` kernels over contiguous tile ranges on internal streams: the launches are
+     * independent (envs never interact), so one part's HBM load / store phases overlap the others' compute
+     * instead of all wavefronts of the chip loading and storing in lock-step.  The caller's stream is forked
+     * into the sub-streams lazily and joined again before anything else touches the batch. */
+    enum { MAX_PARTS = 8, PROF_RING = 256 };
+    int parts = 1;
+    hipStream_t sub[MAX_PARTS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS] = {};
+    bool forked = false;
+    int main_part = 1; /* part 0 of a split step runs on the caller's stream itself, parts 1.. on sub-streams: one stream
+                          fewer for the same overlap (3 parts: 21.2 -> 20.6 us per step at 65,536 envs); POM_MAIN_PART=0: all
+                          parts on sub-streams */
+    /* how the launches of a several-tick call are issued (launch_many; PomBatchOptions.issue_mode) */
+    int issue_mode = POM_ISSUE_THREADS;
+    struct PomIssuer* issuers[MAX_PARTS] = {}; /* POM_ISSUE_THREADS: one helper thread per sub-stream part, created on first use */
+    bool issuers_failed = false;               /* a helper thread could not be started: the calling thread issues everything */
+    /* POM_ISSUE_GRAPH: multi-tick calls replay a captured chunk of launches (launch_many): POM_GRAPH_TICKS launches of every part as one HIP
+     * graph per part.  tick_words[k] is the tick part k's replay starts at, read by the graph's kernels (StepParams.tick_base;
+     * set by a one-lane kernel on the part's stream in front of each replay); tick_words[MAX_PARTS] stays 0 and is what every
+     * launch outside a graph points at. */
+    enum { MAX_GRAPHS = 4 };
+    struct PomStepGraph* graphs[MAX_GRAPHS] = {};
+    uint64_t graph_clock = 0;
+    uint32_t* tick_words = nullptr;
+    bool fuse_policy = true; /* pom_batch_step_simple: policy and tick in one kernel (quad shape); POM_FUSE=0 keeps them apart */
+    /* optional per-launch timing (pom_batch_profile) */
+    bool profiling = false;
+    hipEvent_t prof_ev[2 * PROF_RING] = {};
+    int prof_n = 0;
+#if defined(POM_DIAG)
+    long long* diag = nullptr;
+    long long* diag_pol = nullptr;
+#endif
+};
+
+static void drop_graphs(PomBatch* h);
+static void stop_issuers(PomBatch* h);
+static int fork_parts(PomBatch* h);
+static int join_parts(PomBatch* h);
+static int ensure_sub_streams(PomBatch* h, int parts);
+
+static int check_range(const PomBatch* h, int64_t first, int64_t count)
+{
+    if (!h || first < 0 || count < 0 || first + count > h->n) {
+        snprintf(g_err, sizeof g_err, "range [%lld, %lld) outside batch", (long long)first, (long long)(first + count));
+        return POM_E_ARG;
+    }
+    return POM_OK;
+}
+
+static int ensure_sub_streams(PomBatch* h, int parts)
+{
+    if (parts <= 1) return POM_OK;
+    if (!h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int k = 0; k < parts; k++) {
+        if (!h->sub[k]) HIPCHK(hipStreamCreateWithFlags(&h->sub[k], hipStreamNonBlocking));
+        if (!h->ev_join[k]) HIPCHK(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
+    }
+    return POM_OK;
+}
+
+/* caller's stream -> sub-streams: everything already queued on the caller's stream happens before the parts */
+static int fork_parts(PomBatch* h)
+{
+    if (h->parts == 1 || h->forked) return POM_OK;
+    HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+    for (int k = h->main_part; k < h->parts; k++) HIPCHK(hipStreamWaitEvent(h->sub[k], h->ev_fork, 0));
+    h->forked = true;
+    return POM_OK;
+}
+/* sub-streams -> caller's stream: whatever is queued on the caller's stream next sees all parts finished */
+static int join_parts(PomBatch* h)
+{
+    if (h->parts == 1 || !h->forked) return POM_OK;
+    for (int k = h->main_part; k < h->parts; k++) {
+        HIPCHK(hipEventRecord(h->ev_join[k], h->sub[k]));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join[k], 0));
+    }
+    h->forked = false;
+    return POM_OK;
+}
+
+static int ensure_agent_mem(PomBatch* h)
+{
+    if (!h->agent_mem) {
+        if (int jr = join_parts(h)) return jr; /* the next launch forks the sub-streams again, after this memset */
+        HIPCHK(hipMalloc((void**)&h->agent_mem, (size_t)h->n_pad * 32));
+        HIPCHK(hipMemsetAsync(h->agent_mem, 0, (size_t)h->n_pad * 32, h->stream));
+    }
+    return POM_OK;
+}
+
+static int fill_params(PomBatch* h, StepParams& p, const int32_t* moves_dev, uint64_t seed, int dist, int ticks)
+{
+    p.agent_mem = h->agent_mem;
+    p.state = h->state;
+    p.snap = h->snap;
+    p.terminal = h->terminal;
+    p.moves = moves_dev;
+    p.wave_counters = h->wave_counters;
+#if defined(POM_TRUNC)
+    p.trunc = getenv("POM_TRUNC_AT") ? atoi(getenv("POM_TRUNC_AT")) : 990;
+#endif
+    p.n = h->n;
+    p.n_pad = h->n_pad;
+    p.env_offset = h->env_offset;
+    p.seed = seed;
+    p.tick0 = (uint32_t)h->tick;
+    p.tick_base = h->tick_words + PomBatch::MAX_PARTS; /* the word that stays 0: outside a graph tick0 is the tick itself */
+    p.dist = dist;
+    p.ticks = ticks;
+    p.mode = h->mode;
+    p.auto_reset = h->auto_reset;
+    p.max_steps = h->max_steps;
+    p.episode = h->episode;
+    p.board_seed = h->board_seed;
+    p.fresh = h->fresh;
+    p.block0 = p.block_end = 0;
+#if defined(POM_DIAG)
+    if (!h->diag) {
+        HIPCHK(hipMalloc((void**)&h->diag, (size_t)h->n_waves * POM_PH_N * 8));
+        HIPCHK(hipMemsetAsync(h->diag, 0, (size_t)h->n_waves * POM_PH_N * 8, h->stream));
+    }
+    p.diag = h->diag;
+#endif
+    return POM_OK;
+}
+
+/* Which instantiation of pom_step_kernel the handle runs.  Quad shape (the default): one instantiation per combination of
+ * fresh boards / fused policy / reset at the end for launches of ONE tick, and the plain replay kernel for launches of
+ * several ticks — the other several-tick combinations would need more than the 128 VGPRs that keep four wavefronts on a SIMD
+ * (12-116 B of scratch each, round 2), so those modes always run one tick per launch (max_ticks_per_launch). */
+typedef void (*PomStepKernel)(StepParams);
+static bool runs_fresh(const PomBatch* h) { return h->fresh && h->mode == POM_MODE_ENV && h->auto_reset; }
+static bool runs_at_end(const PomBatch* h) { return h->auto_reset == POM_RESET_AT_END && h->mode == POM_MODE_ENV; }
+static int max_ticks_per_launch(const PomBatch* h, bool policy)
+{
+    return (!h->quad || (!policy && !runs_fresh(h) && !runs_at_end(h))) ? INT_MAX : 1;
+}
+static const void* step_kernel_for(const PomBatch* h, bool policy, bool one_tick)
+{
+    const bool fresh = runs_fresh(h), at_end = runs_at_end(h); /* at_end, policy: quad shape only, checked by the callers */
+    PomStepKernel k;
+    if (h->quad) {
+        static const PomStepKernel single[8] = {
+            pom_step_kernel<16, 4, false, false, false, true>, pom_step_kernel<16, 4, false, false, true, true>,
+            pom_step_kernel<16, 4, false, true, false, true>,  pom_step_kernel<16, 4, false, true, true, true>,
+            pom_step_kernel<16, 4, true, false, false, true>,  pom_step_kernel<16, 4, true, false, true, true>,
+            pom_step_kernel<16, 4, true, true, false, true>,   pom_step_kernel<16, 4, true, true, true, true>};
+        k = one_tick ? single[(fresh ? 4 : 0) | (policy ? 2 : 0) | (at_end ? 1 : 0)] : pom_step_kernel<16, 4, false, false, false, false>;
+    } else if (h->epw == 64) {
+        k = fresh ? pom_step_kernel<64, 1, true> : pom_step_kernel<64, 1, false>;
+    } else if (h->epw == 32) {
+        k = fresh ? pom_step_kernel<32, 1, true> : pom_step_kernel<32, 1, false>;
+    } else {
+        k = fresh ? pom_step_kernel<16, 1, true> : pom_step_kernel<16, 1, false>;
+    }
+    return reinterpret_cast<const void*>(k);
+}
+
+/* one dispatch of the step kernel the handle is configured for, over tiles [p.block0, p.block_end) */
+static hipError_t dispatch_step(const PomBatch* h, const StepParams& p, hipStream_t st, bool policy, hipEvent_t ev0, hipEvent_t ev1)
+{
+    const dim3 grid((unsigned)((p.block_end - p.block0 + POM_WPB - 1) / POM_WPB));
+    StepParams q = p;
+    void* args[1] = {&q};
+    return hipExtLaunchKernel(step_kernel_for(h, policy, p.ticks == 1), grid, dim3(64 * POM_WPB), args, 0, st, ev0, ev1, 0);
+}
+
+/* `one_launch`: the whole batch in ONE launch on the caller's stream.  For steps that have to be joined with the caller's stream
+ * every tick (explicit moves): forking into sub-streams and joining them again costs more than the overlap gains
+ * (65,536 envs, MI355X: 23.3 us per step as one launch, 43.8 as two, 60.2 as three; profiles/r02a_explicit_streams.txt). */
+static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int dist, int ticks, bool policy = false, bool one_launch = false)
+{
+    StepParams p;
+    if (int rc = fill_params(h, p, moves_dev, seed, dist, ticks)) return rc;
+    const int64_t tiles = h->n_pad / h->epw;
+    const int parts = one_launch ? 1 : h->parts;
+    int rc = one_launch ? join_parts(h) : fork_parts(h);
+    if (rc) return rc;
+    for (int k = 0; k < parts; k++) {
+        const int64_t b0 = tiles * k / parts, b1 = tiles * (k + 1) / parts;
+        if (b1 <= b0) continue;
+        hipStream_t st = (parts == 1 || k < h->main_part) ? h->stream : h->sub[k];
+        p.block0 = b0;
+        p.block_end = b1;
+        /* per-launch timing (pom_batch_profile): start / stop events attached to the dispatch itself, i.e. the kernel's own
+         * duration as a profiler reports it, not the stream's period (events recorded around a launch also time the gap) */
+        const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
+        hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
+        HIPCHK(dispatch_step(h, p, st, policy, ev0, ev1));
+        if (prof) h->prof_n++;
+    }
+    return POM_OK;
+}
+
+/* ---- several ticks in one call ---------------------------------------------------------------------------------------------
+ * A step is `parts` launches (one per sub-batch, on parallel streams) every ~16 us at 65,536 envs: the host has ~5 us per
+ * launch, and a call of K ticks is judged by how soon all parts' first launches are out and whether the queues stay fed.
+ * Three ways to issue them (PomBatchOptions.issue_mode; results cannot depend on the choice: the same kernels with the same
+ * arguments go to the same streams in the same per-stream order).  Measured on MI355X, 65,536 envs, 3 parts, per step
+ * (profiles/r03_issue_modes.txt):
+ *                                   20-tick call from an idle device (the bench driver's shape)      500-tick call
+ *   POM_ISSUE_THREADS (default)     18.0 us, run to run the same                                      15.5 us
+ *   POM_ISSUE_DIRECT                17.2 .. 26.4 us: one thread issues all 60 launches (2.8 us each   15.6 - 16.0 us
+ *                                   on a quiet host, then it is ahead of the device; on a busy one it is not)
+ *   POM_ISSUE_GRAPH                 21.4 .. 23.5 us: queued in 48 us, but the replayed nodes run with   16.1 - 16.2 us
+ *                                   wider gaps than plain launches
+ * THREADS: part k's launches of ALL the ticks of the call are issued by a helper thread of its own (created on first use, one
+ * per sub-stream part; the caller issues every part's first launch and the rest of its own part), the call returns when
+ * everything is queued.  A helper that cannot be started is not an error: the calling thread issues its launches.
+ * DIRECT: the calling thread issues everything, tick by tick; no library-owned threads.
+ * GRAPH: part k's launches of POM_GRAPH_TICKS consecutive ticks are a HIP graph — a plain chain of kernel nodes, built once —
+ * replayed on part k's stream with one hipGraphLaunch per part and chunk; no library-owned threads either.  The nodes'
+ * arguments never change: a node carries its offset inside the chunk, and the tick the chunk starts at is a device word per
+ * part (StepParams.tick_base) that a one-lane kernel sets on the part's stream in front of each replay.  (One graph holding
+ * all parts as parallel branches was measured first: this runtime plays the branches one after the other — 18.5 us per step
+ * in a 500-tick call.)  Ticks that do not fill a chunk are launched directly. */
+struct PomIssuer {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool has_job = false, quit = false, busy = false;
+    std::atomic<int> posted{0}; /* bumped with every job and by pom_batch_fork: a thread that has just worked (or was told that work
+                                   is coming) polls this for up to a millisecond before it goes to sleep on the condition variable
+                                   — a futex wake-up costs 10-30 us, a tenth of a 20-step burst */
+    /* the job */
+    StepParams p;
+    hipStream_t st = nullptr;
+    int launches = 0, ticks_per_launch = 1, last_ticks = 1;
+    bool policy = false;
+    hipError_t err = hipSuccess;
+};
+
+static void issuer_main(PomBatch* h, PomIssuer* w)
+{
+    (void)hipSetDevice(h->device);
+    std::unique_lock<std::mutex> lk(w->mu);
+    int seen = w->posted.load();
+    for (;;) {
+        if (!w->has_job && !w->quit) { /* poll briefly, then sleep */
+            lk.unlock();
+            const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(1);
+            while (w->posted.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() < until) {
+            }
+            lk.lock();
+        }
+        if (!w->has_job && !w->quit && w->posted.load() != seen) { /* woken by pom_batch_fork: a job is on its way */
+            seen = w->posted.load();
+            continue;
+        }
+        w->cv.wait(lk, [w, seen] { return w->has_job || w->quit || w->posted.load() != seen; });
+        seen = w->posted.load();
+        if (w->quit) return;
+        if (!w->has_job) continue;
+        w->has_job = false;
+        StepParams p = w->p;
+        hipError_t err = hipSuccess;
+        for (int i = 0; i < w->launches && err == hipSuccess; i++) {
+            p.ticks = i + 1 == w->launches ? w->last_ticks : w->ticks_per_launch;
+            err = dispatch_step(h, p, w->st, w->policy, nullptr, nullptr);
+            p.tick0 += (uint32_t)w->ticks_per_launch;
+        }
+        w->err = err;
+        w->busy = false;
+        w->cv.notify_all();
+    }
+}
+
+static void stop_issuers(PomBatch* h)
+{
+    for (int k = 0; k < PomBatch::MAX_PARTS; k++) {
+        PomIssuer* w = h->issuers[k];
+        if (!w) continue;
+        {
+            std::lock_guard<std::mutex> g(w->mu);
+            w->quit = true;
+        }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+        delete w;
+        h->issuers[k] = nullptr;
+    }
+}
+
+
+#ifndef POM_GRAPH_TICKS
+#define POM_GRAPH_TICKS 20
+#endif
+
+__global__ void pom_set_word_kernel(uint32_t* dst, uint32_t v) { *dst = v; }
+
+struct PomStepGraph {
+    hipGraph_t graph[PomBatch::MAX_PARTS] = {};
+    hipGraphExec_t exec[PomBatch::MAX_PARTS] = {};
+    StepParams key;      /* everything the nodes were built with (tick0 / tick_base / blocks zeroed) */
+    int launches = 0, parts = 0, ticks_per_launch = 0;
+    bool policy = false;
+    uint64_t used = 0;
+};
+
+static void free_graph(PomStepGraph* g)
+{
+    if (!g) return;
+    for (int k = 0; k < PomBatch::MAX_PARTS; k++) {
+        if (g->exec[k]) (void)hipGraphExecDestroy(g->exec[k]);
+        if (g->graph[k]) (void)hipGraphDestroy(g->graph[k]);
+    }
+    delete g;
+}
+
+static void drop_graphs(PomBatch* h)
+{
+    for (int k = 0; k < PomBatch::MAX_GRAPHS; k++) {
+        free_graph(h->graphs[k]);
+        h->graphs[k] = nullptr;
+    }
+}
+
+/* the graphs of `launches` launches per part for these parameters: from the cache, or built now (nullptr + *rc on failure) */
+static PomStepGraph* step_graph(PomBatch* h, const StepParams& p, int launches, int ticks_per_launch, bool policy, int* rc)
+{
+    *rc = POM_OK;
+    for (int k = 0; k < PomBatch::MAX_GRAPHS; k++) {
+        PomStepGraph* g = h->graphs[k];
+        if (g && g->launches == launches && g->parts == h->parts && g->ticks_per_launch == ticks_per_launch && g->policy == policy &&
+            memcmp(&g->key, &p, sizeof p) == 0) {
+            g->used = ++h->graph_clock;
+            return g;
+        }
+    }
+    PomStepGraph* g = new (std::nothrow) PomStepGraph();
+    if (!g) {
+        *rc = POM_E_NOMEM;
+        return nullptr;
+    }
+    memcpy(&g->key, &p, sizeof p);
+    g->launches = launches;
+    g->parts = h->parts;
+    g->ticks_per_launch = ticks_per_launch;
+    g->policy = policy;
+    hipError_t err = hipSuccess;
+    const int64_t tiles = h->n_pad / h->epw;
+    const void* fn = step_kernel_for(h, policy, ticks_per_launch == 1);
+    for (int k = 0; k < h->parts && err == hipSuccess; k++) {
+        const int64_t b0 = tiles * k / h->parts, b1 = tiles * (k + 1) / h->parts;
+        if (b1 <= b0) continue;
+        err = hipGraphCreate(&g->graph[k], 0);
+        hipGraphNode_t prev = nullptr;
+        for (int i = 0; i < launches && err == hipSuccess; i++) {
+            StepParams q = p;
+            q.block0 = b0;
+            q.block_end = b1;
+            q.ticks = ticks_per_launch;
+            q.tick0 = (uint32_t)(i * ticks_per_launch); /* relative to *tick_base */
+            q.tick_base = h->tick_words + k;
+            void* args[1] = {&q};
+            hipKernelNodeParams np;
+            memset(&np, 0, sizeof np);
+            np.func = const_cast<void*>(fn);
+            np.gridDim = dim3((unsigned)((b1 - b0 + POM_WPB - 1) / POM_WPB));
+            np.blockDim = dim3(64 * POM_WPB);
+            np.kernelParams = args;
+            hipGraphNode_t node = nullptr;
+            err = hipGraphAddKernelNode(&node, g->graph[k], prev ? &prev : nullptr, prev ? 1 : 0, &np);
+            prev = node;
+        }
+        if (err == hipSuccess) err = hipGraphInstantiate(&g->exec[k], g->graph[k], nullptr, nullptr, 0);
+    }
+    if (err != hipSuccess) {
+        set_err("building the step graph", err);
+        free_graph(g);
+        *rc = POM_E_HIP;
+        return nullptr;
+    }
+    int slot = 0; /* a free slot, or the least recently used one */
+    for (int k = 0; k < PomBatch::MAX_GRAPHS; k++) {
+        if (!h->graphs[k]) {
+            slot = k;
+            break;
+        }
+        if (h->graphs[k]->used < h->graphs[slot]->used) slot = k;
+    }
+    free_graph(h->graphs[slot]);
+    g->used = ++h->graph_clock;
+    h->graphs[slot] = g;
+    return g;
+}
+
+/* POM_ISSUE_THREADS: the helper of part k, started on first use; nullptr if it cannot be had (the caller then issues that part) */
+static PomIssuer* issuer_for(PomBatch* h, int k)
+{
+    if (h->issuers[k] || h->issuers_failed) return h->issuers[k];
+    PomIssuer* w = new (std::nothrow) PomIssuer();
+    if (w) {
+        try {
+            w->th = std::thread(issuer_main, h, w);
+        } catch (...) { /* std::system_error: no thread to be had — nothing may cross the C boundary */
+            delete w;
+            w = nullptr;
+        }
+    }
+    if (!w) h->issuers_failed = true;
+    h->issuers[k] = w;
+    return w;
+}
+
+/* THREADS / DIRECT: `launches` dispatches per part; the caller advances the tick */
+static int launch_many_streams(PomBatch* h, const StepParams& p0, int launches, int ticks_per_launch, bool policy, bool threads)
+{
+    StepParams p = p0;
+    const int64_t tiles = h->n_pad / h->epw;
+    const int parts = h->parts;
+    if (int rc = fork_parts(h)) return rc;
+    hipError_t err = hipSuccess;
+    auto part_launch = [&](int k, const StepParams& base, int count) { /* `count` launches of part k from this thread */
+        const int64_t b0 = tiles * k / parts, b1 = tiles * (k + 1) / parts;
+        if (b1 <= b0) return;
+        StepParams q = base;
+        q.block0 = b0;
+        q.block_end = b1;
+        q.ticks = ticks_per_launch;
+        const bool own = parts == 1 || k < h->main_part;
+        for (int i = 0; i < count && err == hipSuccess; i++) {
+            err = dispatch_step(h, q, own ? h->stream : h->sub[k], policy, nullptr, nullptr);
+            q.tick0 += (uint32_t)ticks_per_launch;
+        }
+    };
+    if (!threads) { /* tick by tick, the caller's own part first */
+        for (int i = 0; i < launches && err == hipSuccess; i++) {
+            for (int k = 0; k < parts; k++) part_launch(k, p, 1);
+            p.tick0 += (uint32_t)ticks_per_launch;
+        }
+    } else {
+        /* The first launch of EVERY part is issued right here, the caller's own part(s) first: a helper thread takes 10-25 us to
+         * pick its job up (profiles/r02_region_trace.txt), and a part that starts a step late finishes a step late — alone on
+         * the device.  The helpers get the remaining launches of their parts and have one step's time to wake up. */
+        for (int pass = 0; pass < 2; pass++)
+            for (int k = 0; k < parts; k++)
+                if ((parts == 1 || k < h->main_part) == (pass == 0)) part_launch(k, p, 1);
+        p.tick0 += (uint32_t)ticks_per_launch;
+        const int rest = launches - 1;
+        PomIssuer* started[PomBatch::MAX_PARTS] = {};
+        for (int k = h->main_part; k < parts && rest > 0 && err == hipSuccess; k++) { /* the sub-stream parts: hand them to their threads */
+            const int64_t b0 = tiles * k / parts, b1 = tiles * (k + 1) / parts;
+            if (b1 <= b0) continue;
+            PomIssuer* w = issuer_for(h, k);
+            if (!w) { /* no helper: this thread does it */
+                part_launch(k, p, rest);
+                continue;
+            }
+            {
+                std::lock_guard<std::mutex> g(w->mu);
+                w->p = p;
+                w->p.block0 = b0;
+                w->p.block_end = b1;
+                w->st = h->sub[k];
+                w->launches = rest;
+                w->ticks_per_launch = ticks_per_launch;
+                w->last_ticks = ticks_per_launch;
+                w->policy = policy;
+                w->err = hipSuccess;
+                w->busy = true;
+                w->has_job = true;
+                w->posted.fetch_add(1, std::memory_order_release);
+            }
+            w->cv.notify_all();
+            started[k] = w;
+        }
+        for (int k = 0; k < (parts == 1 ? 1 : h->main_part) && rest > 0; k++) part_launch(k, p, rest); /* the rest of the caller's own part(s) */
+        for (int k = 0; k < parts; k++) { /* everything is queued when the call returns */
+            PomIssuer* w = started[k];
+            if (!w) continue;
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [w] { return !w->busy; });
+            if (w->err != hipSuccess && err == hipSuccess) err = w->err;
+        }
+    }
+    if (err != hipSuccess) { /* some launches may be queued, others not: the handle's tick no longer describes its state */
+        set_err("pom_step_kernel launch (the batch is in an undefined state: upload again or destroy it)", err);
+        return POM_E_HIP;
+    }
+    return POM_OK;
+}
+
+/* `launches` dispatches per part, ticks_per_launch ticks each; advances h->tick by what was queued */
+static int launch_many(PomBatch* h, uint64_t seed, int dist, int launches, int ticks_per_launch, bool policy)
+{
+    static const int chunk = getenv("POM_GRAPH_TICKS") ? atoi(getenv("POM_GRAPH_TICKS")) : POM_GRAPH_TICKS;
+    int done = 0;
+    if (h->issue_mode == POM_ISSUE_GRAPH && chunk >= 2 && launches >= chunk && !h->profiling) {
+        StepParams p;
+        memset(&p, 0, sizeof p); /* the cache compares the bytes */
+        if (int rc = fill_params(h, p, nullptr, seed, dist, ticks_per_launch)) return rc;
+        p.tick0 = 0;
+        p.tick_base = nullptr;
+        int rc = POM_OK;
+        PomStepGraph* g = step_graph(h, p, chunk, ticks_per_launch, policy, &rc);
+        if (!g) return rc;
+        if (int fr = fork_parts(h)) return fr;
+        for (; launches - done >= chunk; done += chunk) {
+            for (int pass = 0; pass < 2; pass++) { /* the caller's own stream first: its part starts without a wait on the fork event */
+                for (int k = 0; k < h->parts; k++) {
+                    const bool own = h->parts == 1 || k < h->main_part;
+                    if (own != (pass == 0) || !g->exec[k]) continue;
+                    hipStream_t st = own ? h->stream : h->sub[k];
+                    pom_set_word_kernel<<<dim3(1), dim3(1), 0, st>>>(h->tick_words + k, (uint32_t)h->tick);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipGraphLaunch(g->exec[k], st));
+                }
+            }
+            h->tick += (uint64_t)chunk * (uint64_t)ticks_per_launch;
+        }
+    }
+    if (done == launches) return POM_OK;
+    if (h->profiling) { /* per-launch events: launch_step attaches them */
+        for (; done < launches; done++) {
+            if (int rc = launch_step(h, nullptr, seed, dist, ticks_per_launch, policy)) return rc;
+            h->tick += (uint64_t)ticks_per_launch;
+        }
+        return POM_OK;
+    }
+    StepParams p;
+    if (int rc = fill_params(h, p, nullptr, seed, dist, ticks_per_launch)) return rc;
+    const bool threads = h->issue_mode == POM_ISSUE_THREADS && h->parts > 1 && launches - done >= 2;
+    if (int rc = launch_many_streams(h, p, launches - done, ticks_per_launch, policy, threads)) return rc;
+    h->tick += (uint64_t)(launches - done) * (uint64_t)ticks_per_launch;
+    return POM_OK;
+}
+
+static int launch_policy(PomBatch* h, uint64_t seed)
+{
+    if (int rc = ensure_agent_mem(h)) return rc;
+    PolicyParams p;
+    p.state = h->state;
+    p.snap = h->snap;
+    p.agent_mem = h->agent_mem;
+    p.moves = h->moves_dev;
+    p.n = h->n;
+    p.n_pad = h->n_pad;
+    p.env_offset = h->env_offset;
+    p.seed = seed;
+    p.tick = (uint32_t)h->tick;
+    p.mode = h->mode;
+    p.auto_reset = h->auto_reset;
+    p.episode = h->episode;
+    p.board_seed = h->board_seed;
+    p.fresh = h->fresh;
+#if defined(POM_DIAG)
+    if (!h->diag_pol) {
+        HIPCHK(hipMalloc((void**)&h->diag_pol, (size_t)(h->n_pad / 16) * POM_PP_N * 8));
+        HIPCHK(hipMemsetAsync(h->diag_pol, 0, (size_t)(h->n_pad / 16) * POM_PP_N * 8, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    p.diag = h->diag_pol;
+#endif
+    /* same split and the same streams as the tick, so that part k's policy -> tick -> policy chain pipelines */
+    const int64_t tiles = h->n_pad / 16, step_tiles = h->n_pad / h->epw;
+    int rc = fork_parts(h);
+    if (rc) return rc;
+    for (int k = 0; k < h->parts; k++) {
+        /* the tick's part k covers envs [step_tiles*k/parts, ...) * epw: use the same env boundaries */
+        const int64_t e0 = step_tiles * k / h->parts * h->epw, e1 = step_tiles * (k + 1) / h->parts * h->epw;
+        const int64_t b0 = e0 / 16, b1 = e1 / 16;
+        if (b1 <= b0) continue;
+        (void)tiles;
+        p.block0 = b0;
+        hipStream_t st = (h->parts == 1 || k < h->main_part) ? h->stream : h->sub[k];
+        pom_policy_kernel<<<dim3((unsigned)(b1 - b0)), dim3(64), 0, st>>>(p);
+        HIPCHK(hipGetLastError());
+    }
+    return POM_OK;
+}
+
+#endif /* POM_RUNTIME_H_ */

@@ -1,7 +1,7 @@
 /*
  * pom_step_body.h — one simulation tick for ONE env, written against an
  * abstract per-lane store `A` so the identical source runs
- *   - on gfx950 with A = a column of the wavefront's LDS tile (pom_kernels.hip), and
+ *   - on gfx950 with A = a column of the wavefront's LDS tile (pom_kernels.h), and
  *   - on the host with A = a plain array, ONLY inside tests/ (tests/emul), to fuzz
  *     the kernel's logic against the oracle without a GPU.  It is never a product
  *     CPU path: the shipped library has no host stepper.

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How does the time of a 20-step burst depend on what the GPU did just before (clock / power state)?"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import pomcpp_amd as pa
 from pomcpp_amd.batch import BatchEnvironment, MODE_ENV

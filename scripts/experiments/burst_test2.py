@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One fresh process: PRE steps (one call), sync, optional idle, 5 warm-up steps, then a timed 20-step burst (bench.py's driver shape)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import pomcpp_amd as pa
 from pomcpp_amd.batch import BatchEnvironment, MODE_ENV

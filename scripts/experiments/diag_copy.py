@@ -2,11 +2,11 @@
 """Diagnostic: time pom_step_kernel with ticks=0 (pure record round trip) vs ticks=1, HIP events via torch."""
 import ctypes as C, os, subprocess, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 lib = os.path.join(ROOT, "build", "libpom_batch_diag.so")
 subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DPOM_DIAG", "-I" + ROOT + "/include",
-                "-I" + ROOT + "/pomcpp_amd/csrc", "-o", lib, ROOT + "/pomcpp_amd/csrc/pom_kernels.hip"], check=True)
+                "-I" + ROOT + "/pomcpp_amd/csrc", "-o", lib, ROOT + "/pomcpp_amd/csrc/pom_batch.hip"], check=True)
 import torch
 import pomcpp_amd.batch as B
 B.library_path = lambda: lib

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Tuning sweep: us/tick of pom_step_kernel by envs-per-wavefront (POM_EPW) and batch size; checks results agree."""
 import hashlib, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import pomcpp_amd as pa

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """explicit-moves path (pom_batch_step_device, joined with the caller's stream every tick) by sub-batches per step"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import pomcpp_amd as pa
 from pomcpp_amd.batch import BatchEnvironment, MODE_ENV

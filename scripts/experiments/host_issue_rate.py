@@ -4,7 +4,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import pomcpp_amd as pa
 from pomcpp_amd.batch import BatchEnvironment, MODE_ENV

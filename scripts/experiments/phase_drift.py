@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Step time as the batch ages: fresh games at tick 0 -> steady mix (episodes of every length up to the 800-tick cap)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import pomcpp_amd as pa

@@ -8,7 +8,7 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=150)
@@ -20,7 +20,7 @@ res = {}
 for k in names:
     lib = os.path.join(ROOT, "build", f"libpom_dup{k}.so")
     subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", f"-DPOM_POL_DUP={k}", "-I" + ROOT + "/include",
-                    "-I" + ROOT + "/pomcpp_amd/csrc", "-o", lib, ROOT + "/pomcpp_amd/csrc/pom_kernels.hip"], check=True)
+                    "-I" + ROOT + "/pomcpp_amd/csrc", "-o", lib, ROOT + "/pomcpp_amd/csrc/pom_batch.hip"], check=True)
     env = dict(os.environ, POM_LIB=lib, POM_STREAMS="2")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--policy", "simple", "--envs", str(a.envs), "--steps", str(a.steps),
                           "--warmup", str(a.warmup), "--no-cpu-baseline", "--streams", "2"], env=env, capture_output=True, text=True, check=True).stdout

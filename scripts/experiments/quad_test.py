@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Parity + speed of the quad kernel (POM_EPW=16 POM_QUAD=1) vs the default, single stream."""
 import hashlib, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import pomcpp_amd as pa
 from pomcpp_amd.batch import BatchEnvironment, MODE_ENV

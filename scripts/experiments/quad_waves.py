@@ -1,5 +1,5 @@
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for lib in sys.argv[1:] or [""]:
     env = dict(os.environ)
     if lib != "default": env["POM_LIB"] = os.path.join(ROOT, lib)

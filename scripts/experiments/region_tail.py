@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import pomcpp_amd as pa
 from pomcpp_amd.batch import BatchEnvironment, MODE_ENV

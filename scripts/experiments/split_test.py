@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Experiment: one batch vs K independent sub-batches on K streams (memory phases of one overlap compute of the others)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import pomcpp_amd as pa

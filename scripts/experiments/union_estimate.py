@@ -3,7 +3,7 @@
 real game (the others hold a lone agent: a trivial tick and a restart every time) — the wavefront then runs the union of the
 paths of `live` envs instead of 16."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import pomcpp_amd as pa
 from pomcpp_amd.batch import BatchEnvironment, MODE_ENV

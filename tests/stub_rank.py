@@ -16,7 +16,7 @@ import bench  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--gpus", type=int, default=1)
-ap.add_argument("--envs", type=int, default=32768)
+ap.add_argument("--envs", type=int, default=0)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--fail-rank", type=int, default=-1)
 a = ap.parse_args()
@@ -25,12 +25,33 @@ assert world == a.gpus and int(os.environ["LOCAL_RANK"]) == rank
 if rank == a.fail_rank:
     sys.exit(3)
 dist.init_process_group("gloo", rank=rank, world_size=world)
-plan = bench.shard_plan(rank, world, a.envs)
-counters = torch.tensor([plan["n_envs"] * a.steps, 1, 0, 0], dtype=torch.int64)
-bench.reduce_counters(counters, dist)
+envs = bench.parse_args(["--gpus", str(a.gpus)] + (["--envs", str(a.envs)] if a.envs else [])).envs  # bench.py's own default
+plan = bench.shard_plan(rank, world, envs)
+counters = torch.zeros(4, dtype=torch.int64)
+log = []
+
+
+def run_steps(k):
+    log.append("steps")
+    counters[0] += plan["n_envs"] * k
+    counters[1] += 1
+
+
+def reduce_in_region():
+    log.append("allreduce")
+    bench.reduce_counters(counters, dist)
+
+
+def barrier():
+    log.append("barrier")
+    dist.barrier()
+
+
+bench.timed_region(run_steps, a.steps, barrier, reduce_in_region if world > 1 else None)  # bench.py's own region
 slowest = bench.reduce_max(1.0 + rank, torch.device("cpu"), dist)
 if rank == 0:
     print(json.dumps({"n_gpus": world, "steps_total": int(counters[0]), "first_env": plan["first_env"], "global_envs": plan["global_envs"],
-                      "slowest": slowest, "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}), flush=True)
+                      "envs_per_gpu": envs, "slowest": slowest, "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                      "region": log}), flush=True)
 dist.barrier()
 dist.destroy_process_group()

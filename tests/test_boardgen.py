@@ -51,6 +51,72 @@ def test_oracle_boards_keep_the_reference_distribution(oracle):
     assert np.all(s["bombs_count"] == 0) and np.all(s["flames_count"] == 0) and not s["agents"]["dead"].any()
 
 
+# ---- the pin against the compiled reference: tests/golden/boardgen_stats.npz (tests/golden/gen_boardgen_stats.py) ----------------
+REFSTATS = np.load(os.path.join(ROOT, "tests", "golden", "boardgen_stats.npz"))
+INNER = np.ones(121, dtype=bool)
+INNER[CORNERS] = False
+
+
+def _chi2_two_sample(a, b, min_expected=25):
+    """Pearson statistic and degrees of freedom for 'two histograms, one distribution' (small bins merged from both ends)"""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    keep = (a + b) > 0
+    a, b = a[keep], b[keep]
+    while len(a) > 2 and min(a[0] + b[0], a[-1] + b[-1]) < 2 * min_expected:  # merge the tails inwards
+        if a[0] + b[0] <= a[-1] + b[-1]:
+            a, b = np.concatenate([[a[0] + a[1]], a[2:]]), np.concatenate([[b[0] + b[1]], b[2:]])
+        else:
+            a, b = np.concatenate([a[:-2], [a[-2] + a[-1]]]), np.concatenate([b[:-2], [b[-2] + b[-1]]])
+    na, nb = a.sum(), b.sum()
+    exp_a, exp_b = (a + b) * na / (na + nb), (a + b) * nb / (na + nb)
+    return float(((a - exp_a) ** 2 / exp_a + (b - exp_b) ** 2 / exp_b).sum()), len(a) - 1
+
+
+def check_against_reference_distribution(boards):
+    """boards: int64 [n, 121] start boards of a generator (agents in the corners).  Compared with what the compiled reference's
+    InitBoardItems produced over 20,000 seeds — on the 117 cells the agents do not cover.  The reference's own figures carry
+    ~0.1 % of dirt: its stray read past the wood list (bboard.cpp:367-372) turns a passage into 1..4 on some boards, and 14 % of
+    its runs fault inside the flag pass (their cell kinds are kept, their flags are not)."""
+    from scipy.stats import chi2
+    n = len(boards)
+    cells = boards[:, INNER]
+    wood = (cells >> 8) == 2
+    nb = int(REFSTATS["n_boards"])
+    inner2d = INNER.reshape(11, 11)
+    for mine, ref_map in (((cells == Item.RIGID).mean(), REFSTATS["rigid_per_cell"]), (wood.mean(), REFSTATS["wood_per_cell"])):
+        ref = ref_map[inner2d].sum() / (nb * 117)
+        assert abs(mine - ref) < 0.0025, (mine, ref)  # binomial sd 0.0002-0.0003 on either side + the reference's stray writes
+        assert abs(ref - 1 / 7) < 0.0025              # ... which is also how far the reference itself is from its nominal 1/7
+    # woods per board: the whole histogram
+    stat, dof = _chi2_two_sample(np.bincount(wood.sum(1), minlength=118), REFSTATS["woods_inner_hist"])
+    assert chi2.sf(stat, dof) > 1e-4, (stat, dof)
+    # neighbouring cells: the 3 x 3 table of (kind, kind of the right-hand neighbour), columns 1..9
+    k = np.where(boards == Item.RIGID, 1, np.where((boards >> 8) == 2, 2, 0)).reshape(n, 11, 11)
+    pairs = np.array([[((k[:, :, 1:9] == a) & (k[:, :, 2:10] == b)).sum() for b in range(3)] for a in range(3)])
+    stat, dof = _chi2_two_sample(pairs.reshape(-1), REFSTATS["adjacent_pairs_inner"].reshape(-1))
+    assert chi2.sf(stat, dof) > 1e-4, (stat, dof)
+    # flags: ceil(woods / 2) per board — what the reference gives on every run its stray read does not spoil
+    assert int(REFSTATS["flags_given_ok"]) == int(REFSTATS["flags_wanted_ok"])
+    assert REFSTATS["shortfall_hist"][2:].sum() == 0  # and at most one short otherwise
+    flag = np.where((boards >> 8) == 2, boards & 0xFF, 0)
+    hidden = 4  # a corner may hide a wood, flagged or not
+    assert np.all(np.abs((flag > 0).sum(1) - (((boards >> 8) == 2).sum(1) + 1) // 2) <= hidden)
+    # flag values: uniform over 1..4 in both
+    stat, dof = _chi2_two_sample(np.bincount(flag[flag > 0], minlength=5)[1:], REFSTATS["flag_value_totals"])
+    assert chi2.sf(stat, dof) > 1e-4, (stat, dof)
+    # which woods are flagged does not depend on where they are: per board row, flagged / woods as in the reference
+    f2, w2 = (flag > 0).reshape(n, 11, 11), ((boards >> 8) == 2).reshape(n, 11, 11)
+    ref_rows = REFSTATS["flagged_per_cell_ok"][:, 1:10].sum(1) / REFSTATS["wood_per_cell_ok"][:, 1:10].sum(1)
+    my_rows = f2[:, :, 1:10].sum((0, 2)) / w2[:, :, 1:10].sum((0, 2))
+    assert np.all(np.abs(my_rows - ref_rows) < 0.02), (my_rows, ref_rows)
+
+
+def test_oracle_boards_match_the_compiled_references_distribution(oracle):
+    n = 20000
+    s = oracle.boardgen(20261004, np.arange(n), np.arange(n) % 3)
+    check_against_reference_distribution(s["board"].reshape(n, 121).astype(np.int64))
+
+
 def test_oracle_boards_are_a_function_of_seed_env_episode(oracle):
     a = oracle.boardgen(5, [3, 3, 4, 3], [0, 1, 0, 0])
     assert a[0].tobytes() == a[3].tobytes()
@@ -107,6 +173,18 @@ def test_device_generator_body_matches_oracle(oracle):
 
 
 # ---- GPU, through the C-ABI --------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_device_boards_match_the_compiled_references_distribution(hip_lib):
+    """pom_batch_generate against the histograms recorded from the compiled reference's InitBoardItems (20,000 seeds)"""
+    from pomcpp_amd.batch import BatchEnvironment, MODE_ENV
+    n = 20000
+    env = BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, env_offset=31337)
+    env.generate(20261004)
+    boards = env.get_state()["board"].reshape(n, 121).astype(np.int64)
+    env.close()
+    check_against_reference_distribution(boards)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,offset", [(5000, 0), (100, 123456), (17, 7)])
 def test_generate_matches_oracle(hip_lib, oracle, n, offset):

@@ -242,3 +242,33 @@ def test_split_steps_over_streams_give_identical_results(hip_lib, oracle, stream
         assert _digest(env.get_state()) == _digest(ref)
     with pytest.raises(PomError):
         BatchEnvironment(64, streams=9)
+
+
+@pytest.mark.parametrize("mode", ["direct", "threads", "graph"])
+@pytest.mark.parametrize("streams", [1, 3])
+def test_issue_modes_give_identical_results(hip_lib, oracle, mode, streams):
+    """How the launches of a several-tick call are issued (PomBatchOptions.issue_mode: by the calling thread, by one helper thread
+    per sub-stream, as replayed HIP graphs of 20 ticks) must not show in states, counters or the tick that keys the move stream —
+    random play, ticks_per_launch 1 and 3, the fused SimpleAgent kernel, calls shorter and longer than a graph chunk."""
+    from pomcpp_amd.batch import ISSUE_DIRECT, ISSUE_GRAPH, ISSUE_THREADS
+    im = {"direct": ISSUE_DIRECT, "threads": ISSUE_THREADS, "graph": ISSUE_GRAPH}[mode]
+    n, seed = 4000, 99
+    start = pa.make_boards(n, seed=12)
+    want = start.copy()
+    oracle.run_random(want, start, 47 + 5 + 63, seed, 0, 0, DIST_RANDOM, 800)
+    with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800, streams=streams, issue_mode=im) as env:
+        env.make_game(start)
+        env.step_random(seed, DIST_RANDOM, ticks=47)                      # two chunks + 7
+        env.step_random(seed, DIST_RANDOM, ticks=5)                       # shorter than a chunk
+        env.step_random(seed, DIST_RANDOM, ticks=63, ticks_per_launch=3)  # 21 launches of 3 ticks
+        assert _digest(env.get_state()) == _digest(want)
+        assert env.counters()[CNT_STEPS] == n * (47 + 5 + 63)
+    ref, mems = start.copy(), np.zeros((n, 4, 16), dtype=np.int32)
+    oracle.run_simple(ref, start, mems, 45, seed, 0, 0, 800)
+    with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800, streams=streams, issue_mode=im) as env:
+        env.make_game(start)
+        env.step_simple(seed, 45)
+        assert _digest(env.get_state()) == _digest(ref)
+        assert np.array_equal(env.policy_memory(), mems)
+    with pytest.raises(PomError):
+        BatchEnvironment(64, issue_mode=7)
