@@ -83,6 +83,9 @@ struct LdsEnv {
         const int b = dpp_x2(v);
         return b < v ? b : v;
     }
+    /* "the other lanes' LDS writes so far are visible from here on": true at every instruction of a wavefront in lock-step, so
+     * nothing to do; the four-lane host model of tests/emul makes its lanes meet here */
+    __device__ void sync() const {}
     __device__ int cell(int c) const { return reinterpret_cast<const uint16_t*>(t)[(c >> 1) * (2 * EPW) + (c & 1)]; }
     __device__ void put_cell(int c, int v) { reinterpret_cast<uint16_t*>(t)[(c >> 1) * (2 * EPW) + (c & 1)] = (uint16_t)v; }
     __device__ int bomb(int s) const { return (int)t[(ROW_BOMBS + s) * EPW]; }

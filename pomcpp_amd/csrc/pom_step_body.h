@@ -32,7 +32,9 @@
  * read-only until a group vote has excluded the order-dependent cases, which then run replicated.
  *
  * Store interface A (all indices per lane):
- *   static constexpr int G;  int sub();  int gor(int) / gmin(int) / gadd(int)
+ *   static constexpr int G;  int sub();  int gor(int) / gmin(int) / gadd(int) / gbcast<J>(int)
+ *   void sync()   where split code goes on to READ what other lanes of the group have just written (free on the device: a
+ *                 wavefront runs in lock-step; the four-lane host model of tests/emul needs to be told)
  *   set_x(...)  write by the owner lane only (replicated code)   put_x(...)  write by the calling lane (split code)
  *   int  cell(int c) / void set_cell(int c, int code)      c = y*11+x, 16-bit codes
  *   int  bomb(int slot) / void set_bomb(int slot, int v)    physical queue slot 0..19
@@ -261,6 +263,7 @@ struct PomStepper {
             const int v = bomb_at(i);
             put_bomb_at(i - 1, v);
         }
+        a.sync(); /* whoever looks at the queue next sees all the moved slots */
         if (folded_) {
             /* The slot that falls out of the live range keeps its word (stale slots are state) — in the reference
              * the word as it was BEFORE TickBombs, which has not run yet there: take the folded decrement back out of it. */
@@ -412,6 +415,7 @@ struct PomStepper {
                     for (int i = 1; i <= len; i++)
                         a.put_cell(ray_cell(c0, r, i), POM_C_FLAME | ((c0 << 3) + (i == len ? (int)((ends >> (2 * r)) & 3u) : 0)));
                 }
+                a.sync(); /* the next blast's scan looks at cells other lanes' rays have just written */
                 if (rem == REM_TOP && top_word != -1) { /* nothing touched the queue: the head is still the word the caller saw */
                     owner_bombcount_dec(top_word);
                     L.bIdx = wrap20(L.bIdx + 1);
@@ -894,27 +898,20 @@ struct PomStepper {
             explode(pb_x(c), pb_y(c), pb_strength(c), REM_TOP, c);
         }
     }
-    /* everything between the flame pops and the top-bomb explosions; returns the head of the bomb queue after the timer
-     * decrement and the number of rounds the explosion loop may take */
-    POM_HD void step_middle(const uint32_t mvp, int& top, int& n)
+    /* FillPositions / FillDestPos (step_utility.cpp:130-152), dead agents included, and the two questions that decide what
+     * the tick has to do about them.  Positions travel as a byte per agent (x | y << 4), destinations as (x+1) | (y+1) << 4.
+     * With a quad per env lane m works out agent m's and the four are exchanged with quad broadcasts; the pairwise logic —
+     * FixSwitchMove, ResolveDependencies: prep_dependencies — only runs for the envs in which some agent's destination
+     * touches another agent's cell (`contact`; dead agents included: SURVEY Q9).  Otherwise, the usual case (the agents are
+     * far apart), FixSwitchMove changes nothing and everyone is a root in index order.  `clash`: two live agents on one cell. */
+    POM_HD void prep_positions(const uint32_t mvp, uint32_t& oldp, uint32_t& dstp, int& deadmask, int& contact, int& clash)
     {
-        top = 0;
-        n = 0;
-
-        /* FillPositions / FillDestPos / FixSwitchMove (step_utility.cpp:130-170); dead agents included.  Positions travel as a
-         * byte per agent (x | y << 4), destinations as (x+1) | (y+1) << 4.  With a quad per env lane m works out agent m's and
-         * the four are exchanged with quad broadcasts; the pairwise logic below — FixSwitchMove, ResolveDependencies — only
-         * runs for the envs in which some agent's destination touches another agent's cell (dead agents included: SURVEY
-         * Q9).  Otherwise, the usual case (the agents are far apart), FixSwitchMove changes nothing and everyone is a root in
-         * index order. */
-        uint32_t oldp = 0, dstp = 0;
-        uint32_t dep = 0xFFFF, roots = 0x3210;
-        int nroots = 4;
-        int deadmask = 0;
+        oldp = dstp = 0;
+        deadmask = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) deadmask |= ag_dead(L.a0[i]) << i;
-        int contact = 0;
-        int clash = 0; /* two live agents on one cell */
+        contact = 0;
+        clash = 0; /* two live agents on one cell */
         if (A::G == 4) {
             const int m = a.sub();
             const int av = sel4(m, L.a0);
@@ -955,53 +952,74 @@ struct PomStepper {
                     if (i != j) contact |= ((((dstp >> (8 * i)) & 0xF) - 1) & 0xF) == ((oldp >> (8 * j)) & 0xF) &&
                                            ((((dstp >> (8 * i + 4)) & 0xF) - 1) & 0xF) == ((oldp >> (8 * j + 4)) & 0xF);
         }
+    }
+    /* FixSwitchMove (step_utility.cpp:154-170) and ResolveDependencies (step_utility.cpp:172-205): destinations corrected in
+     * place; dependency / roots as nibbles, 0xF = -1 */
+    POM_HD void prep_dependencies(const uint32_t mvp, const uint32_t oldp, const int deadmask, uint32_t& dstp, uint32_t& dep, uint32_t& roots,
+                                  int& nroots)
+    {
+        int px[4], py[4], dx[4], dy[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            px[i] = (int)((oldp >> (8 * i)) & 0xF);
+            py[i] = (int)((oldp >> (8 * i + 4)) & 0xF);
+            const int mvi = (int)((mvp >> (4 * i)) & 0xF);
+            dx[i] = px[i] + mv_dx(mvi);
+            dy[i] = py[i] + mv_dy(mvi);
+        }
+        roots = 0xFFFF;
+        nroots = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int j = i; j < 4; j++) {
+                if (dx[i] == px[j] && dy[i] == py[j] && dx[j] == px[i] && dy[j] == py[i]) {
+                    dx[i] = px[i]; dy[i] = py[i];
+                    dx[j] = px[j]; dy[j] = py[j];
+                }
+            }
+        }
+        /* ResolveDependencies (step_utility.cpp:172-205); dependency / roots as nibbles, 0xF = -1 */
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int is_root = 1;
+            if (!((deadmask >> i) & 1)) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (j == i) continue;
+                    if (is_root && !((deadmask >> j) & 1) && dx[i] == px[j] && dy[i] == py[j]) {
+                        dep = (dep & ~(0xFu << (4 * j))) | ((uint32_t)i << (4 * j));
+                        is_root = 0;
+                    }
+                }
+            }
+            if (is_root) {
+                roots = (roots & ~(0xFu << (4 * nroots))) | ((uint32_t)i << (4 * nroots));
+                nroots++;
+            }
+        }
+        dstp = 0; /* FixSwitchMove may have changed them */
+#pragma unroll
+        for (int i = 0; i < 4; i++) dstp |= (uint32_t)(((dx[i] + 1) & 0xF) | (((dy[i] + 1) & 0xF) << 4)) << (8 * i);
+    }
+
+    /* everything between the flame pops and the top-bomb explosions; returns the head of the bomb queue after the timer
+     * decrement and the number of rounds the explosion loop may take */
+    POM_HD void step_middle(const uint32_t mvp, int& top, int& n)
+    {
+        top = 0;
+        n = 0;
+
+        /* FillPositions / FillDestPos / FixSwitchMove / ResolveDependencies (step_utility.cpp:130-205): prep_positions and
+         * prep_dependencies above */
+        uint32_t oldp = 0, dstp = 0;
+        uint32_t dep = 0xFFFF, roots = 0x3210;
+        int nroots = 4;
+        int deadmask = 0, contact = 0, clash = 0;
+        prep_positions(mvp, oldp, dstp, deadmask, contact, clash);
         oldp_ = oldp;
         POM_CUT(L, 24);
-        if (contact) {
-            int px[4], py[4], dx[4], dy[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                px[i] = (int)((oldp >> (8 * i)) & 0xF);
-                py[i] = (int)((oldp >> (8 * i + 4)) & 0xF);
-                const int mvi = (int)((mvp >> (4 * i)) & 0xF);
-                dx[i] = px[i] + mv_dx(mvi);
-                dy[i] = py[i] + mv_dy(mvi);
-            }
-            roots = 0xFFFF;
-            nroots = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-#pragma unroll
-                for (int j = i; j < 4; j++) {
-                    if (dx[i] == px[j] && dy[i] == py[j] && dx[j] == px[i] && dy[j] == py[i]) {
-                        dx[i] = px[i]; dy[i] = py[i];
-                        dx[j] = px[j]; dy[j] = py[j];
-                    }
-                }
-            }
-            /* ResolveDependencies (step_utility.cpp:172-205); dependency / roots as nibbles, 0xF = -1 */
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                int is_root = 1;
-                if (!((deadmask >> i) & 1)) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (j == i) continue;
-                        if (is_root && !((deadmask >> j) & 1) && dx[i] == px[j] && dy[i] == py[j]) {
-                            dep = (dep & ~(0xFu << (4 * j))) | ((uint32_t)i << (4 * j));
-                            is_root = 0;
-                        }
-                    }
-                }
-                if (is_root) {
-                    roots = (roots & ~(0xFu << (4 * nroots))) | ((uint32_t)i << (4 * nroots));
-                    nroots++;
-                }
-            }
-            dstp = 0; /* FixSwitchMove may have changed them */
-#pragma unroll
-            for (int i = 0; i < 4; i++) dstp |= (uint32_t)(((dx[i] + 1) & 0xF) | (((dy[i] + 1) & 0xF) << 4)) << (8 * i);
-        }
+        if (contact) prep_dependencies(mvp, oldp, deadmask, dstp, dep, roots, nroots);
         POM_CUT(L, 27);
         const int ouroboros = nroots == 0;
         int posb[4]; /* the agents' position bytes (x | y << 4) */

@@ -1,7 +1,8 @@
 /*
  * emul_fuzz.cpp — TEST-ONLY: random play, device tick body (host build, pom_emul.cpp) vs the
  * oracle (oracle/pom_oracle.c) on identical State + Move[4]; all 1004 bytes and the UB flags
- * must agree after every tick.  usage: emul_fuzz <scenario> <steps> <seed>
+ * must agree after every tick.  usage: emul_fuzz <scenario> <steps> <seed> [quad]
+ * quad: the four-lanes-per-env build of the body (pom_emul_quad.cpp: the shipped kernel's shape) instead of the one-lane build
  */
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +15,7 @@ extern "C" {
 #include "pom_testgen.h"
 #include "pom_rng.h"
 uint32_t pom_emul_step(void* state_1004, const int32_t* moves, int env_mode, int max_steps, uint32_t* status_io);
+uint32_t pom_emul_quad_step(void* state_1004, const int32_t* moves, int env_mode, int max_steps, uint32_t* status_io);
 }
 
 int main(int argc, char** argv)
@@ -21,6 +23,7 @@ int main(int argc, char** argv)
     int scenario = argc > 1 ? atoi(argv[1]) : 1;
     long long steps = argc > 2 ? atoll(argv[2]) : 200000;
     uint64_t seed = argc > 3 ? strtoull(argv[3], 0, 0) : 1;
+    const int quad = argc > 4 && !strcmp(argv[4], "quad");
     PomTestRng rng = {pom_splitmix64(seed) | 1};
     int dist = scenario == 0 ? POM_DIST_HARMLESS : scenario == 2 ? POM_DIST_STRESS : POM_DIST_RANDOM;
     PomState cur, a, b;
@@ -37,7 +40,7 @@ int main(int argc, char** argv)
             a = cur;
             b = cur;
             uint32_t ub_o = pom_oracle_env_step(&a, mv, &est);
-            uint32_t ub_e = pom_emul_step(&b, mv, 1, 0, &status);
+            uint32_t ub_e = quad ? pom_emul_quad_step(&b, mv, 1, 0, &status) : pom_emul_step(&b, mv, 1, 0, &status);
             done++;
             for (int i = 0; i < 4; i++) a.agents[i].pad_[0] = a.agents[i].pad_[1] = 0;
             int eq = memcmp(&a, &b, sizeof a) == 0 && ub_o == ub_e;
@@ -64,7 +67,7 @@ int main(int argc, char** argv)
             if (est.done) break;
         }
     }
-    printf("emul_fuzz scenario %d seed %llu: %lld steps, %lld episodes, %lld flagged ticks, 0 mismatches\n", scenario,
+    printf("emul_fuzz%s scenario %d seed %llu: %lld steps, %lld episodes, %lld flagged ticks, 0 mismatches\n", quad ? " (four lanes per env)" : "", scenario,
            (unsigned long long)seed, done, episodes, flagged);
     return 0;
 }

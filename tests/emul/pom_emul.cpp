@@ -19,6 +19,7 @@ struct ArrayEnv {
     int gmin(int v) const { return v; }
     int gadd(int v) const { return v; }
     template <int J> int gbcast(int v) const { return v; }
+    void sync() const {}
     void put_cell(int c, int v) { cells[c] = (uint16_t)v; }
     void put_bomb(int s, int v) { bombs[s] = v; }
     void put_flame(int s, int v) { flames[s] = v; }
@@ -36,6 +37,37 @@ struct ArrayEnv {
 };
 
 extern "C" {
+
+/* The device body's agent preparation alone (PomStepper::prep_positions / prep_dependencies: FillPositions, FillDestPos,
+ * FixSwitchMove, ResolveDependencies as the tick runs them), for the reference's [step utilities] vectors
+ * (unit_test/bboard/step_utility_test.cpp:38-173).  dest: x, y per agent after FixSwitchMove where the body applies it (only
+ * with `contact`: some destination touches another agent's cell; without it FixSwitchMove cannot change anything);
+ * dependency[j] = the agent that waits for j's cell or -1; roots in visiting order, -1 padded.  Returns the number of roots,
+ * or -1 if the state is not representable. */
+int pom_emul_prep(const void* state_1004, const int32_t* moves, int32_t* dest_xy, int32_t* dependency, int32_t* roots_out, int32_t* contact_out)
+{
+    uint32_t rec[POM_REC_DWORDS];
+    if (pom_pack_state((const int32_t*)state_1004, rec, 1)) return -1;
+    ArrayEnv env;
+    std::memset(&env, 0, sizeof env);
+    PomLane L;
+    pom_lane_load(L, rec[POM_REC_META], rec[POM_REC_META2], rec + POM_REC_AGENTS);
+    PomStepper<ArrayEnv> st(env, L);
+    const uint32_t mvp = PomStepper<ArrayEnv>::pack_moves(moves);
+    uint32_t oldp = 0, dstp = 0, dep = 0xFFFF, roots = 0x3210;
+    int nroots = 4, deadmask = 0, contact = 0, clash = 0;
+    st.prep_positions(mvp, oldp, dstp, deadmask, contact, clash);
+    if (contact) st.prep_dependencies(mvp, oldp, deadmask, dstp, dep, roots, nroots);
+    for (int i = 0; i < 4; i++) {
+        dest_xy[2 * i] = (int)((dstp >> (8 * i)) & 0xF) - 1;
+        dest_xy[2 * i + 1] = (int)((dstp >> (8 * i + 4)) & 0xF) - 1;
+        const int d = (int)((dep >> (4 * i)) & 0xF), r = (int)((roots >> (4 * i)) & 0xF);
+        dependency[i] = d == 0xF ? -1 : d;
+        roots_out[i] = (i < nroots && r != 0xF) ? r : -1;
+    }
+    if (contact_out) *contact_out = contact | (clash << 1);
+    return nroots;
+}
 
 /* one tick through pack -> device body -> unpack.  status_io: the env's status byte (ENV mode).
  * returns the POM_UB_* flags of this tick, or 0xFFFFFFFF if the state is not representable */

@@ -1,6 +1,7 @@
-"""Kernel logic without a GPU: the device tick body (pomcpp_amd/csrc/pom_step_body.h) compiled for the host
-over a plain-array store (tests/emul) and fuzzed against the oracle, plus pack/unpack round trips.  This is a
-test build only — the product library contains no host stepper."""
+"""Kernel logic without a GPU: the device tick body (pomcpp_amd/csrc/pom_step_body.h) compiled for the host — one lane per env
+over a plain-array store (tests/emul/pom_emul.cpp), and in the SHIPPED shape, four lanes per env, as four threads that meet at
+every cross-lane operation (tests/emul/pom_emul_quad.cpp) — and fuzzed against the oracle, plus pack/unpack round trips.  These
+are test builds only — the product library contains no host stepper."""
 import ctypes as C
 import os
 import subprocess
@@ -22,12 +23,14 @@ def emul_bins():
     run = lambda *a: subprocess.run(list(a), check=True, cwd=ROOT)
     run("g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-fPIC", *INC, "-c", "tests/emul/pom_emul.cpp", "-o", "build/pom_emul.o")
     run("gcc", "-O2", "-std=c11", "-fPIC", *INC, "-c", "oracle/pom_oracle.c", "-o", "build/pom_oracle.o")
-    run("g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", *INC, "tests/emul/emul_fuzz.cpp", "build/pom_emul.o", "build/pom_oracle.o",
-        "-o", "build/emul_fuzz")
-    run("g++", "-shared", "-o", "build/libpom_emul.so", "build/pom_emul.o")
+    run("g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-fPIC", "-pthread", *INC, "-c", "tests/emul/pom_emul_quad.cpp", "-o", "build/pom_emul_quad.o")
+    run("g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-pthread", *INC, "tests/emul/emul_fuzz.cpp", "build/pom_emul.o", "build/pom_emul_quad.o",
+        "build/pom_oracle.o", "-o", "build/emul_fuzz")
+    run("g++", "-shared", "-pthread", "-o", "build/libpom_emul.so", "build/pom_emul.o", "build/pom_emul_quad.o")
     lib = C.CDLL(os.path.join(BUILD, "libpom_emul.so"))
-    lib.pom_emul_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-    lib.pom_emul_step.restype = C.c_uint32
+    for fn in (lib.pom_emul_step, lib.pom_emul_quad_step):
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        fn.restype = C.c_uint32
     return lib
 
 
@@ -36,6 +39,15 @@ def test_device_tick_body_matches_oracle_under_random_play(emul_bins, scenario):
     out = subprocess.run([os.path.join(BUILD, "emul_fuzz"), str(scenario), "150000", "5"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-3000:]
     assert "0 mismatches" in out.stdout
+
+
+@pytest.mark.parametrize("scenario", [0, 1, 2, 3])
+def test_quad_tick_body_matches_oracle_under_random_play(emul_bins, scenario):
+    """the shipped shape, four lanes per env: states equal the oracle's and the lanes never break what the device assumes of them
+    (same cross-lane operation reached by all four, no conflicting writes, replicated registers identical)"""
+    out = subprocess.run([os.path.join(BUILD, "emul_fuzz"), str(scenario), "60000", "11", "quad"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert "0 mismatches" in out.stdout and "four lanes per env" in out.stdout
 
 
 def test_pack_unpack_round_trip_and_rejections(emul_bins):
@@ -88,16 +100,18 @@ def test_device_tick_body_reproduces_every_reference_step_case(emul_bins, oracle
     from tests.step_cases import ALL_CASES
     golden = np.load(os.path.join(ROOT, "tests", "golden", "step_cases.npz"))
 
-    def stepper(state, moves):
-        mv = np.ascontiguousarray(moves, dtype=np.int32)
-        buf = np.ascontiguousarray(state).reshape(1)
-        assert emul_bins.pom_emul_step(buf.ctypes.data, mv.ctypes.data, 0, 0, None) != 0xFFFFFFFF
-        state[...] = buf.reshape(state.shape)
+    for step_fn in (emul_bins.pom_emul_step, emul_bins.pom_emul_quad_step):  # one lane per env; four (the shipped shape)
+        def stepper(state, moves):
+            mv = np.ascontiguousarray(moves, dtype=np.int32)
+            buf = np.ascontiguousarray(state).reshape(1)
+            flags = step_fn(buf.ctypes.data, mv.ctypes.data, 0, 0, None)
+            assert flags != 0xFFFFFFFF and not (flags & 0x40000000)  # representable; the quad model's checks hold
+            state[...] = buf.reshape(state.shape)
 
-    for name, case in ALL_CASES.items():
-        api = HostAPI(stepper, oracle)
-        case(api)
-        after = golden[f"{name}__after"]
-        assert len(api.trace) == len(after)
-        for k, (_b, _m, a) in enumerate(api.trace):
-            assert a == after[k].tobytes(), f"{name}: state after step {k} differs from the reference's"
+        for name, case in ALL_CASES.items():
+            api = HostAPI(stepper, oracle)
+            case(api)
+            after = golden[f"{name}__after"]
+            assert len(api.trace) == len(after)
+            for k, (_b, _m, a) in enumerate(api.trace):
+                assert a == after[k].tobytes(), f"{name}: state after step {k} differs from the reference's"

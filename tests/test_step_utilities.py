@@ -1,6 +1,12 @@
-"""The reference's `[step utilities]` cases (unit_test/bboard/step_utility_test.cpp:38-173) against the
-oracle's exported helpers (the device path fuses them into the tick; there they are pinned through Step)."""
+"""The reference's `[step utilities]` cases (unit_test/bboard/step_utility_test.cpp:38-173) against the oracle's exported helpers
+and — second half of this file — against the DEVICE tick body's own preparation functions (PomStepper::prep_positions /
+prep_dependencies of pomcpp_amd/csrc/pom_step_body.h, host build of tests/emul; on the GPU they are pinned through Step)."""
+import ctypes as C
+import os
+import subprocess
+
 import numpy as np
+import pytest
 
 import pomcpp_amd.state as S
 from pomcpp_amd.state import Move
@@ -79,3 +85,92 @@ def test_dead_agents_are_roots(oracle):  # :154-172
     S.kill(s[0], 1)
     _, _, chain = _resolve(oracle, s, _dest(oracle, s, [Move.RIGHT, Move.DOWN, Move.LEFT, Move.UP]))
     assert 0 in chain.tolist() and 1 in chain.tolist()
+
+
+# ---- the same vectors through the device tick body's preparation functions (tests/emul/pom_emul.cpp: pom_emul_prep) -------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def prep():
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    so = os.path.join(ROOT, "build", "libpom_emul_prep.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+                    "-I" + os.path.join(ROOT, "pomcpp_amd/csrc"), "tests/emul/pom_emul.cpp", "-o", so], check=True, cwd=ROOT)
+    lib = C.CDLL(so)
+    lib.pom_emul_prep.argtypes = [C.c_void_p] * 6
+    lib.pom_emul_prep.restype = C.c_int
+
+    def run(s, m):
+        dest, dep, roots = np.zeros(8, dtype=np.int32), np.zeros(4, dtype=np.int32), np.zeros(4, dtype=np.int32)
+        contact = C.c_int32(0)
+        mv = np.asarray(m, dtype=np.int32)
+        n = lib.pom_emul_prep(s.ctypes.data, mv.ctypes.data, dest.ctypes.data, dep.ctypes.data, roots.ctypes.data, C.byref(contact))
+        assert n >= 0
+        return n, dest.reshape(4, 2).tolist(), dep.tolist(), roots.tolist(), contact.value
+    return run
+
+
+def _oracle_prep(oracle, s, m):
+    """FillDestPos -> FixSwitchMove -> ResolveDependencies as step.cpp:17-33 chains them"""
+    d = _dest(oracle, s, m)
+    oracle.lib.pom_oracle_fix_switch_move(s.ctypes.data, d.ctypes.data)
+    n, dep, chain = _resolve(oracle, s, d)
+    return n, d.reshape(4, 2).tolist(), dep.tolist(), chain.tolist()
+
+
+def test_device_prep_destination_position_filling(prep):  # :38-61
+    s = S.new_states(1)
+    _line(s)
+    _, dest, _, _, _ = prep(s, [Move.DOWN, Move.LEFT, Move.RIGHT, Move.UP])
+    assert dest == [[0, 1], [0, 0], [3, 0], [3, -1]]
+
+
+def test_device_prep_fix_switch_position(prep):  # :63-84
+    s = S.new_states(1)
+    _line(s)
+    _, dest, _, _, contact = prep(s, [Move.RIGHT, Move.RIGHT, Move.LEFT, Move.LEFT])
+    assert contact & 1 and dest == [[1, 0], [1, 0], [2, 0], [2, 0]]
+
+
+@pytest.mark.parametrize("pos,moves,kill,expect_roots,n_roots", [
+    ([(0, 0), (1, 0), (8, 4), (9, 8)], [Move.RIGHT] * 3 + [Move.IDLE], (), {1}, None),                      # :97-109  0 -> 1
+    ([(0, 0), (1, 0), (8, 8), (9, 8)], [Move.RIGHT] * 3 + [Move.IDLE], (), {1, 3}, None),                   # :110-122 two chains
+    ([(0, 0), (1, 0), (2, 0), (3, 0)], [Move.RIGHT] * 4, (), {3}, None),                                    # :123-135 complete chain
+    ([(0, 0), (1, 0), (1, 1), (0, 1)], [Move.RIGHT, Move.DOWN, Move.LEFT, Move.UP], (), set(), 0),          # :136-153 ouroboros
+    ([(0, 0), (1, 0), (1, 1), (0, 1)], [Move.RIGHT, Move.DOWN, Move.LEFT, Move.UP], (1,), {0, 1}, None),    # :154-172 dead agents are roots
+])
+def test_device_prep_resolve_dependencies(prep, oracle, pos, moves, kill, expect_roots, n_roots):
+    s = S.new_states(1)
+    _place(s, pos)
+    if kill:
+        S.kill(s[0], *kill)
+    n, dest, dep, roots, _ = prep(s, moves)
+    assert expect_roots <= {r for r in roots if r >= 0}
+    if n_roots is not None:
+        assert n == n_roots and roots[0] == -1
+    # and all of it equals the restatement of the reference's helpers, which tests/golden pins against the compiled reference
+    on, odest, odep, ochain = _oracle_prep(oracle, s, moves)
+    assert (n, dest, dep, roots[:n]) == (on, odest, odep, ochain[:on])
+
+
+def test_device_prep_equals_the_restated_helpers_on_random_positions(prep, oracle):
+    """agents crowded into a 3 x 3 corner so that switches, chains, cycles and dead agents in the way all occur"""
+    rng = np.random.default_rng(5)
+    seen_contact = 0
+    for _ in range(3000):
+        s = S.new_states(1)
+        _place(s, [tuple(int(v) for v in rng.integers(0, 3, size=2)) for _ in range(4)])
+        dead = [i for i in range(4) if rng.random() < 0.2]
+        if dead:
+            S.kill(s[0], *dead)
+        m = [int(v) for v in rng.integers(0, 6, size=4)]
+        n, dest, dep, roots, contact = prep(s, m)
+        on, odest, odep, ochain = _oracle_prep(oracle, s, m)
+        seen_contact += contact & 1
+        if contact & 1:
+            assert (n, dest, dep, roots[:n]) == (on, odest, odep, ochain[:on]), (s["agents"][0], m)
+        else:  # nobody's destination is anybody's cell: nothing to fix, everybody a root in index order
+            raw = _dest(oracle, s, m).reshape(4, 2).tolist()
+            assert dest == raw == odest and n == on == 4 and roots == [0, 1, 2, 3] == ochain and dep == odep == [-1] * 4
+    assert seen_contact > 1000
