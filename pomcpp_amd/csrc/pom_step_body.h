@@ -1322,7 +1322,7 @@ struct PomStepper {
                 a.put_bdest(k, key);
                 moving |= pb_dir(b) != 0;
                 const int idx = pb_y(b) * POM_N + pb_x(b);
-                const int w = idx >> 5;
+                const int w = (idx >> 5) > 3 ? 3 : idx >> 5; /* a position off the board (no live bomb has one: upload checks) counts into the last word */
                 const uint32_t m = 1u << (idx & 31);
                 const uint32_t cur = pick4(w, occ);
                 shared |= (cur & m) != 0;
