@@ -301,6 +301,200 @@ struct PolicyStore {
     __device__ int bomb(int s) const { return (int)t[(POM_REC_BOMBS + s) * 16]; }
 };
 
+/* ---------------------------------------------------------------------------------------------
+ * SimpleAgent's two searches, run for all agents of a wavefront TOGETHER (round 3).  With a lane per agent and the 121-bit sets
+ * in four registers of that lane, a wavefront pays its LONGEST flood (23.5 + 15.9 levels where the average act() runs 2.9 + 2.0,
+ * tests/emul/flood_levels.sh) at ~70 VALU per level, while 80 % (forward) / 60 % (backward) of its lanes have no flood to run.
+ * Here the wavefront's flood jobs — whoever's they are — are dealt to its 16 quads, 16 at a time: job i of a round goes to quad i,
+ * whose four lanes hold the job's sets one 32-cell word each (pom_quad_*_level, pom_policy_body.h: two DPP word exchanges and a
+ * dozen logic ops per level).  A round lasts as long as its longest job, at a third of the price per level.  No LDS memory is
+ * used for the hand-over (the fused kernel has none to spare): a job's inputs are pulled from its owner lane and its answer is
+ * pulled back by the owner with ds_bpermute; which lane owns job i comes from one ds_permute of the lanes' ranks.
+ * ------------------------------------------------------------------------------------------- */
+struct PomQuadLanes {
+    typedef uint32_t W;
+    int k;
+    uint32_t c0_, c10_, valid_, not_first_, not_last_;
+    __device__ explicit PomQuadLanes(int k_) : k(k_)
+    {
+        const uint32_t a[4] = {0x00400801u, 0x00801002u, 0x01002004u, 0x00004008u};
+        const uint32_t b[4] = {0x00200400u, 0x00400801u, 0x00801002u, 0x01002004u};
+        c0_ = pick4(k, a);
+        c10_ = pick4(k, b);
+        valid_ = k == 3 ? 0x01FFFFFFu : ~0u;
+        not_first_ = k == 0 ? 0u : ~0u;
+        not_last_ = k == 3 ? 0u : ~0u;
+    }
+    __device__ static int qor(int v)
+    {
+        v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+        return v | __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    }
+    /* quad_perm [0,0,1,2]: lane j reads lane j-1; [1,2,3,3]: lane j reads lane j+1 */
+    __device__ W prev(W w) const { return (W)__builtin_amdgcn_update_dpp(0, (int)w, 0x90, 0xF, 0xF, true) & not_first_; }
+    __device__ W next(W w) const { return (W)__builtin_amdgcn_update_dpp(0, (int)w, 0xF9, 0xF, 0xF, true) & not_last_; }
+    __device__ bool any(W w) const { return qor((int)w) != 0; }
+    __device__ W bit(int c) const { return (c >> 5) == k ? 1u << (c & 31) : 0u; }
+    __device__ W col0() const { return c0_; }
+    __device__ W col10() const { return c10_; }
+    __device__ W valid() const { return valid_; }
+    __device__ int lowest(W w) const
+    {
+        int r = w ? 32 * k + __builtin_ctz(w) : 999;
+        const int a = __builtin_amdgcn_update_dpp(0, r, 0xB1, 0xF, 0xF, true);
+        r = a < r ? a : r;
+        const int b = __builtin_amdgcn_update_dpp(0, r, 0x4E, 0xF, 0xF, true);
+        return b < r ? b : r;
+    }
+    __device__ int gates_hit(W hit, uint32_t g8) const
+    {
+        int m = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int g = (int)((g8 >> (8 * j)) & 0xFF); /* 0xFF (no gate): word 7, nobody's */
+            m |= (int)(((g >> 5) == k) & ((hit >> (g & 31)) & 1u)) << j;
+        }
+        return qor(m);
+    }
+};
+
+/* which lane owns job i (for i < the number of jobs), in lane i: every lane sends its id to a slot of its own — the job lanes to
+ * their rank, the others behind them — one ds_permute */
+__device__ __forceinline__ int pom_job_owners(uint64_t jobs, bool need, int lane, int& rank, int& njobs)
+{
+    njobs = __popcll(jobs);
+    rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(jobs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)jobs, 0u));
+    const int slot = need ? rank : njobs + (lane - rank);
+    return __builtin_amdgcn_ds_permute(slot << 2, lane);
+}
+
+/* FillRMap's reach + MoveTowardsSafePlace's choice for every lane with `need`: the lowest cell of (window & reachable & safe) or
+ * -1.  src: the agent's cell; radius: of the scan window (the danger value; the worker lanes build the window word by word,
+ * pom_window_word); sets: the wavefront's prepared cell sets, rows [word][16 envs] (0..3 walkable, 4..7 agents, 8..11 safe).
+ * Every lane of the wavefront calls this. */
+__device__ __forceinline__ int pom_coop_forward(bool need, int src, int radius, const uint32_t* sets, int lane)
+{
+    const uint64_t jobs = __ballot(need);
+    int result = -1;
+    if (jobs == 0) return result;
+    int rank, njobs;
+    const int owner_tab = pom_job_owners(jobs, need, lane, rank, njobs);
+    const int k = lane & 3, q = lane >> 2;
+    const PomQuadLanes Q(k);
+    POM_NOUNROLL
+    for (int base = 0; base < njobs; base += 16) {
+        const int j = base + q;
+        const bool has = j < njobs;
+        const int ow = __builtin_amdgcn_ds_bpermute((has ? j : lane) << 2, owner_tab);
+        const int owner = has ? ow : lane;
+        const int desc = __builtin_amdgcn_ds_bpermute(owner << 2, src | (radius << 8));
+        const int jsrc = desc & 0xFF, jrad = desc >> 8;
+        const int env = owner >> 2;
+        const uint32_t me = ~Q.bit(jsrc); /* FillRMap never re-enters its source */
+        const uint32_t walk = sets[k * 16 + env] & me, agents = sets[(4 + k) * 16 + env] & me, safe = sets[(8 + k) * 16 + env];
+        uint32_t front = has ? Q.bit(jsrc) : 0u, all = 0u;
+        bool live = has;
+        POM_NOUNROLL
+        while (__any(live)) {
+            if (live) live = pom_quad_forward_level(Q, walk, agents, front, all);
+        }
+        const int jy = div11(jsrc);
+        const int low = Q.lowest(pom_window_word(k, jsrc - jy * POM_N, jy, jrad) & all & safe);
+        const int got = __builtin_amdgcn_ds_bpermute((rank & 15) << 4, low); /* lane 0 of the quad that worked on my job */
+        if (need && (rank >> 4) == (base >> 4)) result = got == 999 ? -1 : got;
+    }
+    return result;
+}
+
+/* MoveTowardsPosition's backward flood for every lane with `need`: which of its gates (g8: a cell per byte, DOWN UP RIGHT LEFT of
+ * the agent's cell, 0xFF = none) the first level that reaches any of them reaches, as a 4-bit mask (0: the target is out of
+ * reach).  Every lane of the wavefront calls this. */
+__device__ __forceinline__ int pom_coop_backward(bool need, int src, int target, uint32_t g8, const uint32_t* sets, int lane)
+{
+    const uint64_t jobs = __ballot(need);
+    int result = 0;
+    if (jobs == 0) return result;
+    int rank, njobs;
+    const int owner_tab = pom_job_owners(jobs, need, lane, rank, njobs);
+    const int k = lane & 3, q = lane >> 2;
+    const PomQuadLanes Q(k);
+    POM_NOUNROLL
+    for (int base = 0; base < njobs; base += 16) {
+        const int j = base + q;
+        const bool has = j < njobs;
+        const int ow = __builtin_amdgcn_ds_bpermute((has ? j : lane) << 2, owner_tab);
+        const int owner = has ? ow : lane;
+        const int jsrc = __builtin_amdgcn_ds_bpermute(owner << 2, src);
+        const int jt = __builtin_amdgcn_ds_bpermute(owner << 2, target);
+        const uint32_t jg = (uint32_t)__builtin_amdgcn_ds_bpermute(owner << 2, (int)g8);
+        const int env = owner >> 2;
+        const uint32_t walk = sets[k * 16 + env] & ~Q.bit(jsrc);
+        const uint32_t gates = Q.bit((int)(jg & 0xFF)) | Q.bit((int)((jg >> 8) & 0xFF)) | Q.bit((int)((jg >> 16) & 0xFF)) | Q.bit((int)(jg >> 24));
+        uint32_t front = has ? Q.bit(jt) : 0u, seen = front;
+        int r = has ? -1 : 0;
+        POM_NOUNROLL
+        while (__any(r < 0)) {
+            if (r < 0) r = pom_quad_backward_level(Q, walk, gates, jg, front, seen);
+        }
+        const int got = __builtin_amdgcn_ds_bpermute((rank & 15) << 4, r);
+        if (need && (rank >> 4) == (base >> 4)) result = got;
+    }
+    return result;
+}
+
+/* SimpleAgent::act for the 64 agents of a wavefront (lane = agent, quad = env): the per-agent pieces of _Decide
+ * (pom_policy_body.h) with the two searches run cooperatively in between.  actor: this lane's agent is asked for a move (a live
+ * agent of an env that plays this tick).  Every lane of the wavefront calls this; returns the lane's Move (IDLE if not an actor). */
+template <class Store>
+__device__ __forceinline__ int pom_policy_wave(Store& st, const PomPolicyEnv& E, int member, uint32_t& m0, uint32_t& m1, bool actor, int draw,
+                                               const uint32_t* sets, int lane
+#if defined(POM_DIAG)
+                                               , long long& t_last, long long* t_acc
+#endif
+)
+{
+    PomSimplePolicy<Store> pol(st, E, member, m0, m1);
+#if defined(POM_DIAG)
+    pol.t_last = t_last;
+    for (int k = 0; k < POM_PP_N; k++) pol.t_acc[k] = 0;
+#endif
+    int in_danger = 0;
+    if (actor) in_danger = pol.begin();
+    int mv = POM_MOVE_IDLE;
+#if defined(POM_TRUNC)
+    if (st.trunc <= 1) return actor ? (pol.danger_ | pol.adj1_ | pol.near_ | pol.looping_ | pol.can_bomb_) & 1 : mv; /* diagnostic build: keep the predicates alive */
+#endif
+    __builtin_amdgcn_wave_barrier(); /* the sets of all 16 envs were written by their own lanes: no read of them may be scheduled earlier */
+    const int safe_cell = pom_coop_forward(actor && in_danger, pol.src_cell(), pol.danger_, sets, lane);
+    int target = -1, found = POM_MOVE_IDLE, flood = 0;
+    uint32_t g8 = 0xFFFFFFFFu;
+    if (actor) {
+        target = pol.pick_target(safe_cell);
+#if defined(POM_DIAG)
+        { const long long now_ = (long long)clock64(); pol.t_acc[POM_PP_TARGET] += now_ - pol.t_last; pol.t_last = now_; }
+#endif
+        flood = pol.path_begin(target, found, g8);
+    }
+#if defined(POM_TRUNC)
+    if (st.trunc <= 2) return target & 1;
+#endif
+    const int hit = pom_coop_backward(actor && flood, pol.src_cell(), target, g8, sets, lane);
+    if (actor) {
+        const int step = pol.path_end(target, found, hit);
+#if defined(POM_TRUNC)
+        if (st.trunc <= 3) return step;
+#endif
+        mv = pol.finish(step, draw);
+        m0 = pol.m0;
+        m1 = pol.m1;
+    }
+#if defined(POM_DIAG)
+    t_last = pol.t_last;
+    for (int k = POM_PP_PREDICATES; k <= POM_PP_TAIL; k++) t_acc[k] = pol.t_acc[k];
+#endif
+    return mv;
+}
+
 /* occupancy target of the quad kernel: 4 wavefronts per SIMD = 16 per CU = every one of 65,536 envs' wavefronts resident at
  * once.  The kernel needs 120-128 VGPRs; the target keeps the compiler from drifting past 128 (which would drop a whole
  * round's worth of wavefronts to a second round) — at the price of a spill or two if it ever has to.  History: an early
@@ -477,13 +671,16 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                 pom_policy_prepare_safe(st);
             }
 #endif
-            if (active && !ag_dead(sel4(member, L.a0))) { /* act() is only asked of live agents, environment.cpp:139-146 */
+            { /* act() is only asked of live agents (environment.cpp:139-146); the wavefront's searches run together: every lane goes in */
                 const PomPolicyEnv E{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {L.a1[0], L.a1[1], L.a1[2], L.a1[3]}, L.bIdx, L.bCnt};
-                PomSimplePolicy<PolicyStore> pol(st, E, member, m0, m1);
                 const uint64_t r = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), tick0 + (uint32_t)tk);
-                mv_own = pol.act((int)((((uint32_t)(r >> (16 * member)) & 0xFFFFu) * 5u) >> 16));
-                m0 = pol.m0;
-                m1 = pol.m1;
+                const bool actor = active && !ag_dead(sel4(member, L.a0));
+#if defined(POM_DIAG)
+                long long pt_last = 0, pt_acc[POM_PP_N];
+                mv_own = pom_policy_wave(st, E, member, m0, m1, actor, (int)((((uint32_t)(r >> (16 * member)) & 0xFFFFu) * 5u) >> 16), sets, lane, pt_last, pt_acc);
+#else
+                mv_own = pom_policy_wave(st, E, member, m0, m1, actor, (int)((((uint32_t)(r >> (16 * member)) & 0xFFFFu) * 5u) >> 16), sets, lane);
+#endif
             }
             p.agent_mem[tile_id * 64 + lane] = m0;
             p.agent_mem[4 * np + tile_id * 64 + lane] = m1;
@@ -739,33 +936,19 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
     PolicyStore st{t, danger + ec, sets + ec, id};
     POM_PSTAMP(POM_PP_LOAD);
     if (e < p.n && !frozen) { /* all four lanes of the env, dead agents' lanes included */
-#if defined(POM_POL_DUP)
-        if (POM_POL_DUP == 1) {
-            pom_policy_prepare_clear(st);
-            pom_policy_prepare_fill(st, E);
-            pom_policy_prepare_safe(st);
-            asm volatile("" ::: "memory");
-        }
-#endif
         pom_policy_prepare_clear(st);
         pom_policy_prepare_fill(st, E);
         pom_policy_prepare_safe(st);
     }
     POM_PSTAMP(POM_PP_PREPARE);
-    if (e < p.n && !frozen && !ag_dead(sel4(id, E.a0))) { /* act() is only asked of live agents, environment.cpp:139-146 */
-        PomSimplePolicy<PolicyStore> pol(st, E, id, m0, m1);
-#if defined(POM_DIAG)
-        pol.t_last = t_last;
-        for (int k = 0; k < POM_PP_N; k++) pol.t_acc[k] = 0;
-#endif
+    { /* act() is only asked of live agents (environment.cpp:139-146); the wavefront's searches run together: every lane goes in */
+        const bool actor = e < p.n && !frozen && !ag_dead(sel4(id, E.a0));
         const uint64_t r = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick);
         const int draw = (int)((((uint32_t)(r >> (16 * id)) & 0xFFFFu) * 5u) >> 16);
-        mv = pol.act(draw);
-        m0 = pol.m0;
-        m1 = pol.m1;
 #if defined(POM_DIAG)
-        t_last = pol.t_last;
-        for (int k = POM_PP_PREDICATES; k <= POM_PP_TAIL; k++) t_acc[k] = pol.t_acc[k];
+        mv = pom_policy_wave(st, E, id, m0, m1, actor, draw, sets, lane, t_last, t_acc);
+#else
+        mv = pom_policy_wave(st, E, id, m0, m1, actor, draw, sets, lane);
 #endif
     }
     p.moves[slot] = mv;

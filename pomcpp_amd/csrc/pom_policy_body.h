@@ -17,7 +17,10 @@
  * flood fills on 121-bit cell sets in registers, one dilation (4 multi-word shifts + masks) per level: (a) forwards from the
  * source until nothing grows — only the danger branch needs it; (b) backwards from the ONE target the decision is about, until
  * the flood first touches neighbours of the source — as many levels as the target is far.  No queue, no per-cell map, no LDS
- * traffic, ~90 VALU per level instead of ~100 per CELL; (b) sits at one program point for both branches that need it.
+ * traffic; (b) sits at one program point for both branches that need it.  On the device the floods of all agents of a wavefront are
+ * run TOGETHER (round 3): the wavefront's flood jobs are dealt to its 16 quads, a quad holds one job's sets one 32-cell word per
+ * lane (pom_quad_*_level below, ~25 VALU per level instead of ~70), so a wavefront pays for its longest flood at a third of the
+ * price (pom_kernels.h: pom_coop_forward / pom_coop_backward).
  *
  * Agent memory, 2 dwords: m0 = recentPositions.queue[0..3], a byte each: x:4 | y:4 two's-complement nibbles (-1 .. 11);
  *                         m1 = recentPositions.index:2 | count:3 @2 | moveQueue.queue[0..3] 3 bits each @5 | moveQueue.count:3 @17
@@ -60,19 +63,6 @@ enum { POM_PP_LOAD = 0, POM_PP_PREPARE, POM_PP_PREDICATES, POM_PP_TARGET, POM_PP
     } while (0)
 #else
 #define POM_PSTAMP(k) ((void)0)
-#endif
-/* POM_POL_DUP=k builds (scripts/policy_dup.py, never shipped) run section k twice, results unchanged: the extra time is what
- * the section costs on the real workload (the kernel is VALU-issue-bound, so elapsed-time stamps mislead) */
-#if defined(POM_POL_DUP) && defined(__HIP_DEVICE_COMPILE__)
-#define POM_DUP(k, stmt, out)                                                        \
-    do {                                                                             \
-        if (POM_POL_DUP == (k)) {                                                    \
-            stmt;                                                                    \
-            asm volatile("" : "+v"(out), "+v"(walk.w[0]), "+v"(walk.w[1]), "+v"(walk.w[2]), "+v"(walk.w[3])::"memory"); \
-        }                                                                            \
-    } while (0)
-#else
-#define POM_DUP(k, stmt, out) ((void)0)
 #endif
 /* POM_LEVEL_STATS (host analysis builds only, tests/emul/flood_levels.cpp): how many levels the two floods of an act() ran */
 #if defined(POM_LEVEL_STATS) && !defined(__HIP_DEVICE_COMPILE__)
@@ -217,14 +207,81 @@ struct PomCells {
     }
 };
 
+/* ---- a 121-bit cell set spread over the four lanes of a quad ------------------------------------------------------------------
+ * One 32-cell word per lane: lane k of the quad holds cells 32k .. 32k+31.  A dilation then costs each lane two word exchanges
+ * with its neighbours in the quad and a dozen logic ops instead of the ~50 that four words in one lane's registers take — what
+ * the wave-cooperative floods of pom_kernels.h are made of.  Q says what "one word per lane" is: on the device a uint32_t per
+ * lane with DPP quad permutes for prev / next (PomQuadLanes, pom_kernels.h); in tests/emul four words at once (PomQuadHost), so
+ * that the very same level functions are fuzzed against the four-register floods below without a GPU.
+ *   Q::W                     the word type;  & | ~ << >> work lane-wise
+ *   q.prev(w) / q.next(w)    the word of lane k-1 / k+1 (0 at the ends)
+ *   q.any(w)                 is any bit set in any of the four words (the same answer in all four lanes)
+ *   q.bit(c)                 the set {c}
+ *   q.col0() / q.col10()     the cells of column x = 0 / x = 10;  q.valid(): the 121 cells
+ *   q.lowest(w)              the smallest member or 999;  q.gates_hit(w, g8): which of the four cells packed in g8 (a byte each,
+ *                            0xFF = none) are members, as a 4-bit mask
+ */
+template <class Q>
+POM_HD typename Q::W pom_quad_neighbours(const Q& q, typename Q::W w)
+{
+    const typename Q::W p = q.prev(w), n = q.next(w);
+    return (((w << 11) | (p >> 21)) | ((w >> 11) | (n << 21)) | (((w << 1) | (p >> 31)) & ~q.col0()) | (((w >> 1) | (n << 31)) & ~q.col10())) & q.valid();
+}
+/* one level of FillRMap's reach (PomSimplePolicy::forward_reach below): returns whether anything grew */
+template <class Q>
+POM_HD bool pom_quad_forward_level(const Q& q, typename Q::W walk, typename Q::W agents, typename Q::W& front, typename Q::W& all)
+{
+    const typename Q::W nb = pom_quad_neighbours(q, front) & ~all;
+    const typename Q::W grown = nb & walk;
+    all = all | grown | (nb & agents);
+    front = grown;
+    return q.any(grown);
+}
+/* one level of MoveTowardsPosition's backward flood (PomSimplePolicy::path_local below): -1 = go on, else the flood is over and
+ * the value is the 4-bit mask of gates this level reached (0: the flood died out) */
+template <class Q>
+POM_HD int pom_quad_backward_level(const Q& q, typename Q::W walk, typename Q::W gates, uint32_t g8, typename Q::W& front, typename Q::W& seen)
+{
+    front = pom_quad_neighbours(q, front) & ~seen & walk;
+    if (!q.any(front)) return 0;
+    seen = seen | front;
+    const typename Q::W hit = front & gates;
+    if (!q.any(hit)) return -1;
+    return q.gates_hit(hit, g8);
+}
+
+/* word k (cells 32k .. 32k+31) of MoveTowardsSafePlace's scan window around (sx, sy) for `radius` (PomSimplePolicy::window below
+ * is the whole set): only the three or four board rows that overlap the word are looked at */
+POM_HD uint32_t pom_window_word(int k, int sx, int sy, int radius)
+{
+    const int lim = radius < POM_N ? radius : POM_N; /* exclusive upper bound of x and of y (sic, strategy.cpp:128-129) */
+    const int y0 = sy - radius < 0 ? 0 : sy - radius;
+    const int first = div11(32 * k);
+    uint32_t w = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int y = first + i;
+        const int dy_ = y - sy;
+        const int rem = radius - (dy_ < 0 ? -dy_ : dy_);
+        const int x0 = sx - rem < 0 ? 0 : sx - rem;
+        const int x1 = sx + rem < lim - 1 ? sx + rem : lim - 1;
+        const int ok = (int)(y >= y0) & (int)(y < lim) & (int)(rem >= 0) & (int)(x0 <= x1);
+        const int s = y * POM_N + x0 - 32 * k; /* where the run starts relative to the word: -10 .. 43 */
+        const uint32_t run = (1u << (x1 - x0 + 1 > 0 ? x1 - x0 + 1 : 0)) - 1u; /* at most 11 bits */
+        const uint32_t bits = s >= 0 ? (s < 32 ? run << s : 0u) : run >> (-s);
+        w |= ok ? bits : 0u;
+    }
+    return k == 3 ? w & 0x01FFFFFFu : w;
+}
+
 template <class P>
 struct PomSimplePolicy {
     P& p;
     const PomPolicyEnv& E;
     int id, sx, sy; /* me, and where I stand (the search's source) */
     uint32_t m0, m1;
-    PomCells walk, agents; /* the env's walkable and agent cells (prepared once per env) */
-    PomCells all;          /* the cells FillRMap reaches (GetDistance != 0); built by forward_reach() */
+    int danger_ = 0, can_bomb_ = 0, adj1_ = 0, near_ = 0, looping_ = 0; /* begin()'s answers */
+    PomCells all; /* the cells FillRMap reaches (GetDistance != 0); built by forward_reach() — the one-lane floods only */
 #if defined(POM_DIAG)
     long long t_last, t_acc[POM_PP_N];
 #endif
@@ -232,17 +289,14 @@ struct PomSimplePolicy {
         : p(p_), E(e_), id(id_), sx(0), sy(0), m0(m0_), m1(m1_)
     {
         all = PomCells::zero();
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            walk.w[k] = p.setw(k);
-            agents.w[k] = p.setw(4 + k);
-        }
         const int av = sel4(id, E.a0);
         sx = ag_x(av);
         sy = ag_y(av);
-        agents.remove(sy * POM_N + sx); /* FillRMap never re-enters its source (strategy.cpp:83-90) */
-        walk.remove(sy * POM_N + sx);
     }
+    POM_HD int src_cell() const { return sy * POM_N + sx; }
+    /* the env's walkable / agent cells as the searches see them: FillRMap never re-enters its source (strategy.cpp:83-90) */
+    POM_HD int walk_has(int c) const { return (int)((p.setw(c >> 5) >> (c & 31)) & 1u) & (int)(c != src_cell()); }
+    POM_HD int agent_has(int c) const { return (int)((p.setw(4 + (c >> 5)) >> (c & 31)) & 1u) & (int)(c != src_cell()); }
 
     /* ---- memory fields ---- */
     POM_HD static int nib2i(int v) { return v == 15 ? -1 : v; }
@@ -276,11 +330,20 @@ struct PomSimplePolicy {
     }
 
     /* (a) FillRMap, strategy.cpp:59-93: which cells get a distance.  A cell can be entered if it is walkable or holds an agent
-     * (:43-44); the search continues only through walkable cells, agents are reached but not passed (:50-53). */
+     * (:43-44); the search continues only through walkable cells, agents are reached but not passed (:50-53).  The one-lane form
+     * (host builds; the kernels run pom_quad_forward_level over the same sets, four lanes per flood). */
     POM_HD void forward_reach()
     {
+        PomCells walk, agents;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            walk.w[k] = p.setw(k);
+            agents.w[k] = p.setw(4 + k);
+        }
+        agents.remove(src_cell());
+        walk.remove(src_cell());
         PomCells front = PomCells::zero();
-        front.add(sy * POM_N + sx);
+        front.add(src_cell());
         all = PomCells::zero();
         POM_NOUNROLL
         for (int level = 0; level < POM_CELLS; level++) {
@@ -292,56 +355,11 @@ struct PomSimplePolicy {
             if (!grown.any()) break;
         }
     }
-    /* (b) MoveTowardsPosition, strategy.cpp:99-121, for target (tx, ty) != source: the Move of the first step, IDLE if the
-     * search never reached the target.  Backwards from the target through walkable cells; the first level that touches walkable
-     * neighbours of the source decides, DOWN before UP before RIGHT before LEFT (the order FillRMap tries them in). */
-    POM_HD int move_towards(int tx, int ty) const
-    {
-        const int t = ty * POM_N + tx;
-        const int nx[4] = {sx, sx, sx + 1, sx - 1}, ny[4] = {sy + 1, sy - 1, sy, sy};
-        const int mvk[4] = {POM_MOVE_DOWN, POM_MOVE_UP, POM_MOVE_RIGHT, POM_MOVE_LEFT};
-        int found = POM_MOVE_IDLE, enterable = walk.has(t) | agents.has(t);
-        PomCells gates = PomCells::zero(); /* the source's walkable neighbours */
-#pragma unroll
-        for (int k = 3; k >= 0; k--) {
-            if (oob(nx[k], ny[k])) continue;
-            const int n = ny[k] * POM_N + nx[k];
-            if (n == t && enterable) found = mvk[k]; /* the target is next to me */
-            if (walk.has(n)) gates.add(n);
-        }
-        if (found == POM_MOVE_IDLE && enterable && gates.any()) {
-            PomCells seen = PomCells::zero(), front = PomCells::zero();
-            seen.add(t);
-            front.add(t);
-            POM_NOUNROLL
-            for (int level = 0; level < POM_CELLS; level++) {
-                POM_COUNT_LEVEL(pom_stat_bwd);
-                front = front.neighbours().minus(seen) & walk;
-                if (!front.any()) break;
-                seen = seen | front;
-                const PomCells hit = front & gates;
-                if (hit.any()) {
-#pragma unroll
-                    for (int k = 3; k >= 0; k--)
-                        if (!oob(nx[k], ny[k]) && hit.has(ny[k] * POM_N + nx[k])) found = mvk[k];
-                    break;
-                }
-            }
-        }
-        if (found != POM_MOVE_IDLE) return found;
-        /* unreached target: its map entry is 0, i.e. "distance 0, predecessor cell 0".  The reference takes cell 0 for the
-         * source if the agent stands there and answers by comparing coordinates (:107-113); otherwise IDLE (:115-118) */
-        if (sx == 0 && sy == 0) {
-            if (tx > 0) return POM_MOVE_RIGHT;
-            if (ty > 0) return POM_MOVE_DOWN;
-        }
-        return POM_MOVE_IDLE;
-    }
     /* MoveTowardsSafePlace, strategy.cpp:123-140.  The reference scans y from sy-radius while y < radius, x from sx-radius while
      * x < radius (sic: the upper bounds are `radius`, not origin + radius), skips cells off the board or further than `radius`
      * in Manhattan distance, and takes the first reachable cell that passes _safe_condition.  Scan order = ascending cell index,
-     * so: window set (one run of cells per row) & reachable & safe, lowest member. */
-    POM_HD int safe_place(int radius) /* the cell MoveTowardsSafePlace heads for, -1 if none */
+     * so: window set (one run of cells per row) & reachable & safe, lowest member.  window(): the window set. */
+    POM_HD PomCells window(int radius) const
     {
         const int lim = radius < POM_N ? radius : POM_N; /* exclusive upper bound of x and of y */
         PomCells win = PomCells::zero();
@@ -355,10 +373,14 @@ struct PomSimplePolicy {
             const int x1 = sx + rem < lim - 1 ? sx + rem : lim - 1;
             if (x0 <= x1) win.add_range(y * POM_N + x0, x1 - x0 + 1);
         }
+        return win;
+    }
+    POM_HD int safe_place(int radius) /* the cell MoveTowardsSafePlace heads for, -1 if none; one-lane form, after forward_reach() */
+    {
         PomCells safe_cells;
 #pragma unroll
         for (int k = 0; k < 4; k++) safe_cells.w[k] = p.setw(8 + k);
-        return (win & all & safe_cells).lowest();
+        return (window(radius) & all & safe_cells).lowest();
     }
     POM_HD int manhattan_to(int j) const
     {
@@ -448,72 +470,139 @@ struct PomSimplePolicy {
     }
     POM_HD int one_safe_step(int draw) /* the common tail of _Decide and _MoveSafeOneSpace, simple_agent.cpp:37-48,105-121 */
     {
-        POM_DUP(5, (mq_set_count(0), safe_directions(), sort_directions()), m1);
         mq_set_count(0);
         safe_directions();
         sort_directions();
         if (mq_count() == 0) return POM_MOVE_IDLE;
         return mq_at(draw % 2);
     }
-    POM_HD int decide(int draw) /* _Decide, simple_agent.cpp:51-122 */
+
+    /* ---- _Decide (simple_agent.cpp:51-122) in the pieces between which its two searches sit.  The kernels run the searches for
+     * all agents of a wavefront together (pom_kernels.h: pom_coop_forward / pom_coop_backward); act() below strings the pieces
+     * together with the one-lane searches. ---- */
+    /* the predicates; returns whether the agent is in danger, i.e. needs FillRMap's reach and a safe place in it */
+    POM_HD int begin()
     {
         const int av = sel4(id, E.a0), a1v = sel4(id, E.a1);
-        const int danger = in_danger(sx, sy);
-        const int can_bomb = pom_sext8((uint32_t)av >> 16) < pom_sext16((uint32_t)a1v);
-        int adj1 = adjacent_enemy(1), near = adjacent_enemy(7), looping = has_rp_loop();
-        POM_DUP(6, (adj1 = adjacent_enemy(1) + 2 * adjacent_enemy(7) + 4 * has_rp_loop()), adj1);
+        danger_ = in_danger(sx, sy);
+        can_bomb_ = pom_sext8((uint32_t)av >> 16) < pom_sext16((uint32_t)a1v);
+        adj1_ = adjacent_enemy(1);
+        near_ = adjacent_enemy(7);
+        looping_ = has_rp_loop();
         POM_PSTAMP(POM_PP_PREDICATES);
-#if defined(POM_TRUNC)
-        if (p.trunc <= 1) return (adj1 | near | looping | danger | can_bomb) & 1; /* diagnostic build: keep the predicates alive */
-#endif
-        /* Which cell, if any, does this decision want a path to?  In danger: the first safe reachable cell of the scan window
-         * (needs the reachable set); else, allowed to bomb, an enemy within 7 and nothing more urgent: that enemy.  The path
-         * question itself is then asked at ONE program point for both kinds of agents of the wavefront. */
-        int target = -1;
-        const int chasing = danger == 0 && can_bomb && !adj1 && near && !looping;
-        if (danger > 0) {
-            POM_DUP(2, (forward_reach(), all.w[0] ^= all.w[1] ^ all.w[2] ^ all.w[3]), all.w[0]);
-            forward_reach();
-            POM_DUP(3, target = safe_place(danger), target);
-            target = safe_place(danger);
-        } else if (chasing) {
-            target = enemy_cell(7);
+        return danger_ > 0;
+    }
+    /* Which cell, if any, does this decision want a path to?  In danger: the first safe reachable cell of the scan window
+     * (`safe_cell`: what the forward search found, -1 if nothing); else, allowed to bomb, an enemy within 7 and nothing more
+     * urgent: that enemy. */
+    POM_HD int pick_target(int safe_cell) const
+    {
+        if (danger_ > 0) return safe_cell;
+        const int chasing = can_bomb_ && !adj1_ && near_ && !looping_;
+        return chasing ? enemy_cell(7) : -1;
+    }
+    /* (b) MoveTowardsPosition, strategy.cpp:99-121, for a target != source: the Move of the first step, IDLE if the search
+     * never reached the target.  Backwards from the target through walkable cells; the first level that touches walkable
+     * neighbours of the source ("gates") decides, DOWN before UP before RIGHT before LEFT (the order FillRMap tries them in).
+     * path_begin: what needs no search — `found` if the target is next to me; the gates, a cell index per byte of g8 in that
+     * order (0xFF = none); returns whether the flood has to run. */
+    POM_HD int path_begin(int target, int& found, uint32_t& g8) const
+    {
+        found = POM_MOVE_IDLE;
+        g8 = 0xFFFFFFFFu;
+        if (target < 0) return 0;
+        const int nx[4] = {sx, sx, sx + 1, sx - 1}, ny[4] = {sy + 1, sy - 1, sy, sy};
+        const int mvk[4] = {POM_MOVE_DOWN, POM_MOVE_UP, POM_MOVE_RIGHT, POM_MOVE_LEFT};
+        const int enterable = walk_has(target) | agent_has(target);
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            if (oob(nx[k], ny[k])) continue;
+            const int n = ny[k] * POM_N + nx[k];
+            if (n == target && enterable) found = mvk[k]; /* the target is next to me */
+            if (walk_has(n)) g8 = (g8 & ~(0xFFu << (8 * k))) | ((uint32_t)n << (8 * k));
         }
-        POM_PSTAMP(POM_PP_TARGET);
-#if defined(POM_TRUNC)
-        if (p.trunc <= 2) return target & 1;
-#endif
-        int mv = POM_MOVE_IDLE;
-        if (target >= 0) {
-            const int ty = div11(target);
-            POM_DUP(4, mv = move_towards(target - ty * POM_N, ty), mv);
-            mv = move_towards(target - ty * POM_N, ty);
+        /* The flood's first level is the target's walkable neighbours: it ends there if one of them is a gate, i.e. if the target
+         * is two steps away through a gate.  A third of all floods are that short (tests/emul/flood_levels.sh): answered here,
+         * they do not take a quad of the wavefront's cooperative floods. */
+        if (found == POM_MOVE_IDLE && enterable) {
+            const int ty = div11(target), tx = target - ty * POM_N;
+#pragma unroll
+            for (int k = 3; k >= 0; k--) {
+                const int ddx = nx[k] - tx, ddy = ny[k] - ty;
+                if (((g8 >> (8 * k)) & 0xFF) != 0xFF && (ddx < 0 ? -ddx : ddx) + (ddy < 0 ? -ddy : ddy) == 1) found = mvk[k];
+            }
         }
+        return found == POM_MOVE_IDLE && enterable && g8 != 0xFFFFFFFFu;
+    }
+    /* the flood, one-lane form: which gates the first level that reaches any of them reaches (4-bit mask, 0 = none) */
+    POM_HD int path_local(int target, uint32_t g8) const
+    {
+        PomCells walk, gates = PomCells::zero();
+#pragma unroll
+        for (int k = 0; k < 4; k++) walk.w[k] = p.setw(k);
+        walk.remove(src_cell());
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (((g8 >> (8 * k)) & 0xFF) != 0xFF) gates.add((int)((g8 >> (8 * k)) & 0xFF));
+        PomCells seen = PomCells::zero(), front = PomCells::zero();
+        seen.add(target);
+        front.add(target);
+        POM_NOUNROLL
+        for (int level = 0; level < POM_CELLS; level++) {
+            POM_COUNT_LEVEL(pom_stat_bwd);
+            front = front.neighbours().minus(seen) & walk;
+            if (!front.any()) break;
+            seen = seen | front;
+            const PomCells hit = front & gates;
+            if (hit.any()) {
+                int m = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (((g8 >> (8 * k)) & 0xFF) != 0xFF && hit.has((int)((g8 >> (8 * k)) & 0xFF))) m |= 1 << k;
+                return m;
+            }
+        }
+        return 0;
+    }
+    POM_HD int path_end(int target, int found, int hit_mask) const
+    {
+        if (target < 0) return POM_MOVE_IDLE;
+        const int mvk[4] = {POM_MOVE_DOWN, POM_MOVE_UP, POM_MOVE_RIGHT, POM_MOVE_LEFT};
+        if (found == POM_MOVE_IDLE) {
+#pragma unroll
+            for (int k = 3; k >= 0; k--)
+                if ((hit_mask >> k) & 1) found = mvk[k];
+        }
+        if (found != POM_MOVE_IDLE) return found;
+        /* unreached target: its map entry is 0, i.e. "distance 0, predecessor cell 0".  The reference takes cell 0 for the
+         * source if the agent stands there and answers by comparing coordinates (:107-113); otherwise IDLE (:115-118) */
+        if (sx == 0 && sy == 0) {
+            const int ty = div11(target), tx = target - ty * POM_N;
+            if (tx > 0) return POM_MOVE_RIGHT;
+            if (ty > 0) return POM_MOVE_DOWN;
+        }
+        return POM_MOVE_IDLE;
+    }
+    /* the rest of _Decide with the path's first step `mv` in hand, then SimpleAgent::act's bookkeeping (simple_agent.cpp:123-137) */
+    POM_HD int finish(int mv, int draw)
+    {
         POM_PSTAMP(POM_PP_PATH);
-#if defined(POM_TRUNC)
-        if (p.trunc <= 3) return mv;
-#endif
         /* the three ways out of _Decide that do not end in _MoveSafeOneSpace's tail; everything else falls through to it, at
          * one program point (three inlined copies under three lane masks would cost the wavefront three times) */
         const int px = sx + mv_dx(mv), py = sy + mv_dy(mv);
         const int step_ok = walkable_at(px, py);
         const int d_next = step_ok ? in_danger(px, py) : 0;
         int out = -1;
-        if (danger > 0) {
+        if (danger_ > 0) {
             if (step_ok && safe(d_next, 2)) out = mv;
-        } else if (can_bomb) {
-            if (adj1) out = POM_MOVE_BOMB;
-            else if (near && looping) out = draw % 4;
-            else if (near && step_ok && safe(d_next, 5)) out = mv;
+        } else if (can_bomb_) {
+            if (adj1_) out = POM_MOVE_BOMB;
+            else if (near_ && looping_) out = draw % 4;
+            else if (near_ && step_ok && safe(d_next, 5)) out = mv;
             else if (adjacent_wood()) out = POM_MOVE_BOMB;
         }
         if (out < 0) out = one_safe_step(draw);
-        return out;
-    }
-    POM_HD int act(int draw) /* SimpleAgent::act, simple_agent.cpp:123-137 */
-    {
-        const int mv = decide(draw);
-        const int key = pos_key(sx + mv_dx(mv), sy + mv_dy(mv));
+        const int key = pos_key(sx + mv_dx(out), sy + mv_dy(out));
         int idx = rp_index(), cnt = rp_count();
         if (cnt == 4) { /* RemainingCapacity() == 0: PopElem */
             idx = (idx + 1) & 3;
@@ -524,7 +613,22 @@ struct PomSimplePolicy {
         cnt++;
         m1 = (m1 & ~31u) | (uint32_t)idx | ((uint32_t)cnt << 2);
         POM_PSTAMP(POM_PP_TAIL);
-        return mv;
+        return out;
+    }
+    POM_HD int act(int draw) /* SimpleAgent::act with the one-lane searches (host builds) */
+    {
+        int safe_cell = -1;
+        if (begin()) {
+            forward_reach();
+            safe_cell = safe_place(danger_);
+        }
+        const int target = pick_target(safe_cell);
+        POM_PSTAMP(POM_PP_TARGET);
+        int found;
+        uint32_t g8;
+        int hit = 0;
+        if (path_begin(target, found, g8)) hit = path_local(target, g8);
+        return finish(path_end(target, found, hit), draw);
     }
 };
 

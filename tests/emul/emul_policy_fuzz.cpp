@@ -1,6 +1,7 @@
 /*
  * emul_policy_fuzz.cpp — TEST-ONLY: four SimpleAgents play random games; every act() is computed by the device policy body
- * (host build) and by the policy oracle on the same state, memory and draw.  usage: emul_policy_fuzz <scenario> <acts> <seed>
+ * (host build) and by the policy oracle on the same state, memory and draw.  usage: emul_policy_fuzz <scenario> <acts> <seed> [quad]
+ * quad: the searches run through the quad-word level functions the kernels' wave-cooperative floods are made of
  */
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,7 @@ extern "C" {
 #include "pom_testgen.h"
 #include "pom_rng.h"
 int pom_emul_simple_act(const void* state_1004, int id, int32_t* mem16, int draw);
+extern int pom_emul_quad_floods;
 }
 
 int main(int argc, char** argv)
@@ -19,6 +21,7 @@ int main(int argc, char** argv)
     int scenario = argc > 1 ? atoi(argv[1]) : 1;
     long long want = argc > 2 ? atoll(argv[2]) : 200000;
     uint64_t seed = argc > 3 ? strtoull(argv[3], 0, 0) : 1;
+    pom_emul_quad_floods = argc > 4 && !strcmp(argv[4], "quad");
     PomTestRng rng = {pom_splitmix64(seed) | 1};
     long long acts = 0, episodes = 0, maps = 0;
     PomState st;

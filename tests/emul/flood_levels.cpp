@@ -141,6 +141,16 @@ int main(int argc, char** argv)
     stats("forward levels per wavefront (max)", wf);
     stats("backward levels per wavefront (max)", wb);
     printf("%lld act() calls\n", acts);
+    {
+        long long hf[12] = {0}, hb[12] = {0}, nf = 0, nb = 0;
+        for (int x : af) if (x) { hf[std::min(x, 11)]++; nf++; }
+        for (int x : ab) if (x) { hb[std::min(x, 11)]++; nb++; }
+        printf("levels of the floods that run (%% of them), 1 .. 10, 11+:\n  forward ");
+        for (int k = 1; k < 12; k++) printf(" %5.1f", 100.0 * hf[k] / nf);
+        printf("\n  backward");
+        for (int k = 1; k < 12; k++) printf(" %5.1f", 100.0 * hb[k] / nb);
+        printf("\n");
+    }
     printf("\nfloods of one wavefront-tick (16 envs), estimated VALU per wavefront:\n");
     stats("now: lane = agent (50 F + 45 B)", c_now);
     stats("quad-shared, member by member", c_seq);

@@ -14,8 +14,11 @@ BUILD = os.path.join(ROOT, "build")
 INC = ["-I" + os.path.join(ROOT, p) for p in ("include", "pomcpp_amd/csrc", "oracle")]
 
 
+@pytest.mark.parametrize("floods", ["one-lane", "quad"])
 @pytest.mark.parametrize("scenario", [1, 2])
-def test_device_policy_body_matches_oracle_under_play(scenario):
+def test_device_policy_body_matches_oracle_under_play(scenario, floods):
+    """floods: the two searches of an act() as one lane runs them (four registers per cell set), or through the quad-word level
+    functions the kernels' wave-cooperative floods are made of (pom_quad_*_level, pom_window_word)"""
     os.makedirs(BUILD, exist_ok=True)
     run = lambda *a: subprocess.run(list(a), check=True, cwd=ROOT)
     run("g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", *INC, "-c", "tests/emul/pom_policy_emul.cpp", "-o", "build/pom_policy_emul.o")
@@ -23,8 +26,18 @@ def test_device_policy_body_matches_oracle_under_play(scenario):
     run("gcc", "-O2", "-std=c11", *INC, "-c", "oracle/pom_oracle.c", "-o", "build/pom_oracle_p.o")
     run("g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", *INC, "tests/emul/emul_policy_fuzz.cpp", "build/pom_policy_emul.o",
         "build/pom_policy_oracle.o", "build/pom_oracle_p.o", "-o", "build/emul_policy_fuzz")
-    out = subprocess.run([os.path.join(BUILD, "emul_policy_fuzz"), str(scenario), "100000", "3"], capture_output=True, text=True)
+    out = subprocess.run([os.path.join(BUILD, "emul_policy_fuzz"), str(scenario), "100000", "3"] + (["quad"] if floods == "quad" else []),
+                         capture_output=True, text=True)
     assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-2000:]
+
+
+def test_window_word_by_word_equals_the_window():
+    import ctypes as C
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "libpom_policy_emul.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-fPIC", "-shared", *INC, "tests/emul/pom_policy_emul.cpp", "-o", so],
+                   check=True, cwd=ROOT)
+    assert C.CDLL(so).pom_emul_window_check() == 0  # every agent cell x radius 0..15, all four words
 
 
 def test_oracle_policy_basics(oracle):
