@@ -134,9 +134,10 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
         delete h;
         return POM_E_ARG;
     }
-    /* measured (MI355X, profiles/r01_fuse.txt): the fused kernel is 4-9 % faster up to 131,072 envs and 3 % slower at 262,144
-     * (it is capped at 128 VGPRs to keep 4 wavefronts per SIMD and parks ~25 long-lived values in scratch) */
-    h->fuse_policy = h->n_pad < 262144;
+    /* policy and tick in one kernel: faster at every batch size since the wavefront-cooperative searches (round 3: 33.7 / 39.0 /
+     * 55.7 / 109.5 us per step fused against 42.2 / 47.9 / 62.8 / 112.8 as two kernels at 32,768 .. 262,144 envs).  Round 1
+     * measured the two kernels 3 % ahead at 262,144 envs (profiles/r01_fuse.txt). */
+    h->fuse_policy = true;
     if (const char* ev = getenv("POM_FUSE")) h->fuse_policy = atoi(ev) != 0;
     if (const char* ev = getenv("POM_MAIN_PART")) h->main_part = atoi(ev) != 0;
     if (o.issue_mode < POM_ISSUE_AUTO || o.issue_mode > POM_ISSUE_GRAPH) {
