@@ -146,3 +146,43 @@ def test_mixed_play_through_the_device_move_buffer(hip_lib, oracle):
             env.close()  # a view of the handle's move buffer is still alive
         del mv
         env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 1000])
+def test_gpu_policy_every_agent_of_a_wavefront_searches(hip_lib, oracle, n):
+    """The searches of all agents of a wavefront run together, 16 at a time (pom_coop_forward / pom_coop_backward): here EVERY
+    live agent of every env stands on a ticking bomb (64 forward jobs per wavefront: four rounds) and most then need a path
+    (several backward rounds) — moves, memory and the tick that follows must equal the oracle's; n = 1000 leaves the last
+    wavefront partly empty."""
+    from pomcpp_amd.batch import BatchEnvironment, MODE_ENV
+    start = pa.make_boards(n, seed=99)
+    rng = np.random.default_rng(3)
+    for e in range(n):
+        for a in range(4):
+            start[e]["agents"][a]["maxBombCount"] = 3
+            x, y = int(start[e]["agents"][a]["x"]), int(start[e]["agents"][a]["y"])
+            pa.plant_bomb(start[e], x, y, a, False, int(rng.integers(2, 9)))  # under the agent: the board keeps showing him
+        for c in rng.integers(0, 121, size=30):  # open the boards up a little: longer searches
+            yy, xx = divmod(int(c), 11)
+            if start[e]["board"][yy, xx] in (1, 2 << 8) or (int(start[e]["board"][yy, xx]) >> 8) == 2:
+                start[e]["board"][yy, xx] = 0
+    ref = start.copy()
+    mem = np.zeros((n, 4, 16), dtype=np.int32)
+    status = [dict(done=0, winner=-1, draw=0) for _ in range(n)]
+    with BatchEnvironment(n, mode=MODE_ENV, auto_reset=False) as env:
+        env.make_game(start)
+        for t in range(12):
+            done = np.array([st["done"] for st in status], dtype=np.int32)
+            want = oracle.simple_policy(ref, mem, 5, 0, t, done)
+            got = env.policy_simple(5, want_moves=True)
+            assert np.array_equal(got, want), (t, np.argwhere(got != want)[:5])
+            assert np.array_equal(env.policy_memory(), mem), t
+            if t == 0:  # the first call must really have loaded every quad: all agents are in danger and walk away
+                assert (want != 0).mean() > 0.5
+            env.step_policy()
+            for e in range(n):
+                oracle.env_step(ref[e:e + 1], want[e], status[e])
+        got_state = env.get_state()
+    ref["agents"]["pad"] = 0
+    assert got_state.tobytes() == ref.tobytes()
