@@ -179,8 +179,9 @@ int pom_batch_launch_shape(PomBatch* h, int32_t* envs_per_wave, int32_t* lanes_p
  * order its own device work against steps and observations with events instead of pom_batch_sync */
 int pom_batch_stream(PomBatch* h, void** stream);
 
-/* zero-copy view for device-side consumers (policies, observation kernels): SoA records,
- * dword d of env e at base[d * n_pad + e]; layout in pomcpp_amd/csrc/pom_packed.h */
+/* zero-copy view for device-side consumers (policies, observation kernels): packed records in tiles of 16 envs,
+ * dword d of env e at base[(e / 16) * (16 * rec_dwords) + d * 16 + e % 16]; n_pad = envs the buffer holds (a multiple of 64);
+ * layout in pomcpp_amd/csrc/pom_packed.h */
 int pom_batch_device_view(PomBatch* h, void** base, int64_t* n_pad, int32_t* rec_dwords);
 
 /*

@@ -199,7 +199,7 @@ __device__ __forceinline__ void dma_rows(const uint32_t* g, uint32_t* lds_base)
                                      (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
 }
 template <int EPW>
-__device__ __forceinline__ void load_tile(const uint32_t* col, int64_t np, uint32_t* tile, int sub)
+__device__ __forceinline__ void load_tile(const uint32_t* col, int64_t np /* row stride of a column */, uint32_t* tile, int sub)
 {
     constexpr int GR = 64 / EPW; /* rows per instruction */
     /* a rolled loop with a running pointer: fully unrolled, hipcc precomputes all per-lane 64-bit addresses first
@@ -227,7 +227,8 @@ __device__ __forceinline__ void store_tile(uint32_t* col, int64_t np, const uint
 }
 /* EPW = 16: the same movement in 16-byte pieces (gfx950's global_load_lds_dwordx4 / dwordx4 stores).  A tile row is 16 envs
  * = 64 contiguous bytes in HBM and in LDS, so lane l takes envs 4(l%4)..+3 of row r0 + l/4 and one instruction covers 16 rows:
- * 7 instead of 28 per direction.  All 16 columns come from the same buffer (`base` = &buf[tile's first env]). */
+ * 7 instead of 28 per direction.  `base` = the tile's first dword, np = the row stride: with the buffers laid out tile by tile
+ * (pom_packed.h) np = 16 and an instruction moves 1,024 contiguous bytes. */
 template <int ROWS = POM_REC_DWORDS>
 __device__ __forceinline__ void load_tile16_x4(const uint32_t* base, int64_t np, uint32_t* tile, int lane)
 {
@@ -531,9 +532,10 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     uint32_t* const sets = tile + (POM_REC_DWORDS + 32) * EPW;
     const int lane = threadIdx.x & 63;
     /* XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own
-     * L2).  With fewer than 64 envs per wavefront neighbouring tiles share 128-B lines of every record row, so they are
-     * given to workgroups of the SAME XCD: the second touch of a line is an L2 hit instead of a second HBM fetch
-     * (FETCH_SIZE per launch 21.4 MB -> footprint, profiles/).  Bijective for any grid size. */
+     * L2).  Neighbouring tiles are given to workgroups of the SAME XCD (bijective for any grid size): with the buffers laid
+     * out row-major over all envs (rounds 1-2) neighbouring tiles shared the 128-B lines of every record row and the
+     * second touch of a line became an L2 hit instead of a second HBM fetch; with a tile contiguous in memory (round 3) it
+     * keeps an XCD's traffic in one region of memory. */
     int64_t tile_local;
     {
         const int64_t b = blockIdx.x, nb = gridDim.x, q = nb / 8, r = nb % 8, x = b % 8;
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     /* data movement: lane -> (env el, row group sub) so that one DMA / store instruction covers 64/EPW rows */
     const int el = lane % EPW, sub = lane / EPW;
     const int64_t e_d = tile_id * EPW + el;
-    uint32_t* col_d = p.state + e_d;         /* buffers hold n_pad columns: in range for every lane */
+    uint32_t* col_d = p.state + pom_rec_col(e_d); /* buffers hold n_pad columns: in range for every lane */
     /* the tick: G = 1: the lanes with sub == 0 own env el; G = 4: lane -> (env lane/4, member lane%4), all lanes run */
     const int ec = G == 1 ? el : lane >> 2;
     const int member = G == 1 ? 0 : lane & 3;
@@ -564,8 +566,8 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
 #endif
     long long c_steps = 0, c_episodes = 0, c_resets = 0, c_ub = 0;
 
-    if (EPW == 16) load_tile16_x4(p.state + tile_id * EPW, np, tile, lane); /* 16-byte pieces, 7 instructions */
-    else load_tile<EPW>(col_d, np, tile, sub);
+    if (EPW == 16) load_tile16_x4(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane); /* 16-byte pieces, 7 instructions of 1 KB */
+    else load_tile<EPW>(col_d, POM_TILE_ENVS, tile, sub);
     uint32_t m0 = 0, m1 = 0; /* POLICY: this lane's agent's memory */
     if (POLICY) {
         m0 = p.agent_mem[tile_id * 64 + lane];
@@ -812,9 +814,9 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
          * see through, so that they are computed here */
         int lane_late = lane;
         asm volatile("" : "+v"(lane_late));
-        store_tile16_x4(p.state + tile_id * EPW, np, tile, lane_late);
+        store_tile16_x4(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane_late);
     } else {
-        store_tile<EPW>(col_d, np, tile, sub, el);
+        store_tile<EPW>(col_d, POM_TILE_ENVS, tile, sub, el);
     }
 
 #if defined(POM_DIAG)
@@ -892,7 +894,7 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
 #if defined(POM_DIAG)
     long long t_last = (long long)clock64(), t_acc[POM_PP_N] = {0, 0, 0, 0, 0, 0, 0};
 #endif
-    load_tile16_x4<POL_LOAD_ROWS>(p.state + tile_id * 16, np, tile, lane);
+    load_tile16_x4<POL_LOAD_ROWS>(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane);
     /* the policy: lane -> (env lane/4, agent lane%4) */
     const int ec = lane >> 2, id = lane & 3;
     const int64_t e = tile_id * 16 + ec;
@@ -1075,7 +1077,7 @@ __global__ __launch_bounds__(64) void pom_observe_kernel(ObserveParams p)
         tile_local = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
     }
     const int64_t tile_id = p.block0 + tile_local;
-    load_tile16_x4(p.state + tile_id * 16, np, tile, lane);
+    load_tile16_x4(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint8_t* stage_b = reinterpret_cast<uint8_t*>(stage);
     const uint16_t* tile_h = reinterpret_cast<const uint16_t*>(tile);
@@ -1186,7 +1188,7 @@ __global__ __launch_bounds__(64) void pom_generate_kernel(uint32_t* state, uint3
     if (tile_id * 16 + lane < n && lane < 16) episode[tile_id * 16 + lane] = 0u;
     __syncthreads();
     /* whole tiles: the buffers hold n_pad columns; columns past n are blank records here, as after creation */
-    store_tile16_x4(state + tile_id * 16, np, tile, lane);
+    store_tile16_x4(state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane);
     for (int ec = 0; ec < 16; ec++) { /* the snapshot: array of structs (restart_column); columns past n are blank like the state's */
         uint32_t* rec = snap + (tile_id * 16 + ec) * POM_REC_DWORDS;
         rec[lane] = tile[lane * 16 + ec];
@@ -1200,33 +1202,34 @@ __global__ void pom_pack_kernel(const int32_t* __restrict__ aos, int64_t first, 
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    uint32_t* col = state + first + i;
-    int bad = pom_pack_state(aos + i * (POM_STATE_BYTES / 4), col, np);
+    uint32_t* col = state + pom_rec_col(first + i);
+    const int64_t rs = POM_TILE_ENVS; /* row stride of a column */
+    int bad = pom_pack_state(aos + i * (POM_STATE_BYTES / 4), col, rs);
     /* live bombs must sit on the board and belong to a real agent: they index cells and agents */
     {
-        const uint32_t m = col[POM_REC_META * np];
+        const uint32_t m = col[POM_REC_META * rs];
         const int bIdx = (m >> 8) & 0xFF, bCnt = (m >> 16) & 0xFF;
         if (!bad) {
             for (int k = 0; k < bCnt; k++) {
-                const int b = (int)col[(POM_REC_BOMBS + (bIdx + k) % POM_Q) * np];
+                const int b = (int)col[(POM_REC_BOMBS + (bIdx + k) % POM_Q) * rs];
                 bad |= (pb_x(b) >= POM_N) | (pb_y(b) >= POM_N) | (pb_id(b) >= POM_AGENT_COUNT);
             }
         }
     }
     if (bad) {
         atomicMin(first_bad, (int)(i > INT_MAX - 1 ? INT_MAX - 1 : i));
-        for (int d = 0; d < POM_REC_DWORDS; d++) col[d * np] = 0; /* inert blank board ... */
-        col[POM_REC_META2 * np] = (uint32_t)POM_ST_DONE << 8;     /* ... that is never stepped in ENV mode */
+        for (int d = 0; d < POM_REC_DWORDS; d++) col[d * rs] = 0; /* inert blank board ... */
+        col[POM_REC_META2 * rs] = (uint32_t)POM_ST_DONE << 8;     /* ... that is never stepped in ENV mode */
     }
     uint32_t* s = snap + (first + i) * POM_REC_DWORDS; /* the snapshot is array-of-structs (restart_column) */
-    for (int d = 0; d < POM_REC_DWORDS; d++) s[d] = col[d * np];
+    for (int d = 0; d < POM_REC_DWORDS; d++) s[d] = col[d * rs];
 }
 
 __global__ void pom_unpack_kernel(const uint32_t* __restrict__ state, int64_t first, int64_t count, int64_t np, int32_t* aos)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    pom_unpack_state(state + first + i, np, aos + i * (POM_STATE_BYTES / 4));
+    pom_unpack_state(state + pom_rec_col(first + i), POM_TILE_ENVS, aos + i * (POM_STATE_BYTES / 4));
 }
 
 /* out: 6 arrays of `count` int32: done, winner, draw, alive, timeStep, ubflags */
@@ -1234,14 +1237,14 @@ __global__ void pom_status_kernel(const uint32_t* __restrict__ state, int64_t fi
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const uint32_t* col = state + first + i;
-    const uint32_t m = col[POM_REC_META * np], m2 = col[POM_REC_META2 * np];
+    const uint32_t* col = state + pom_rec_col(first + i);
+    const uint32_t m = col[POM_REC_META * POM_TILE_ENVS], m2 = col[POM_REC_META2 * POM_TILE_ENVS];
     const uint32_t st = (m2 >> 8) & 0xFF;
     out[0 * count + i] = (st & POM_ST_DONE) ? 1 : 0;
     out[1 * count + i] = (int)((st >> POM_ST_WINNER_SHIFT) & 7) - 1;
     out[2 * count + i] = (st & POM_ST_DRAW) ? 1 : 0;
     out[3 * count + i] = pom_sext8(m);
-    out[4 * count + i] = (int32_t)col[POM_REC_TIMESTEP * np];
+    out[4 * count + i] = (int32_t)col[POM_REC_TIMESTEP * POM_TILE_ENVS];
     out[5 * count + i] = (int32_t)(m2 >> 16);
 }
 
@@ -1252,7 +1255,7 @@ __global__ void pom_results_kernel(const uint32_t* __restrict__ state, const uin
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const uint32_t now = (state[POM_REC_META2 * np + first + i] >> 8) & 0xFF;
+    const uint32_t now = (state[pom_rec_col(first + i) + POM_REC_META2 * POM_TILE_ENVS] >> 8) & 0xFF;
     const uint32_t* rec = terminal + (first + i) * POM_REC_DWORDS;
     const uint32_t st = (rec[POM_REC_META2] >> 8) & 0xFF;
     out[0 * count + i] = (now & POM_ST_RESTARTED) ? 1 : 0;
@@ -1274,7 +1277,7 @@ __global__ void pom_snapshot_kernel(const uint32_t* __restrict__ state, uint32_t
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= np) return;
     for (int d = 0; d < POM_REC_DWORDS; d++) {
-        uint32_t v = state[d * np + e];
+        uint32_t v = state[pom_rec_col(e) + d * POM_TILE_ENVS];
         if (d == POM_REC_META2) v &= 0xFFu; /* a snapshot starts an episode: status and flags clear */
         snap[e * POM_REC_DWORDS + d] = v;    /* array of structs (restart_column) */
     }

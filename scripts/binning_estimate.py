@@ -53,11 +53,23 @@ base, n_pad, rec = env.device_view()
 assert n_pad == n and rec == 112
 
 
-class _Raw:
-    __cuda_array_interface__ = {"shape": (rec, n_pad), "typestr": "<i4", "data": (base, False), "version": 2}
+class _Raw:  # the device buffer: tiles of 16 envs, [tile][dword][env in tile] (pom_packed.h)
+    __cuda_array_interface__ = {"shape": (n_pad // 16, rec, 16), "typestr": "<i4", "data": (base, False), "version": 2}
 
 
-state = torch.as_tensor(_Raw(), device=dev)
+tiles = torch.as_tensor(_Raw(), device=dev)
+
+
+class _State:
+    """the buffer as [dword][env]: clone() gathers it, copy_() scatters it back"""
+    def clone(self):
+        return tiles.permute(1, 0, 2).reshape(rec, n_pad).clone()
+
+    def copy_(self, src):
+        tiles.copy_(src.reshape(rec, n_pad // 16, 16).permute(1, 0, 2))
+
+
+state = _State()
 
 
 def classes(st):
