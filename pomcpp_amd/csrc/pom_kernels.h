@@ -537,10 +537,14 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
      * second touch of a line became an L2 hit instead of a second HBM fetch; with a tile contiguous in memory (round 3) it
      * keeps an XCD's traffic in one region of memory. */
     int64_t tile_local;
+#if defined(POM_NO_XCD_REMAP)
+    tile_local = blockIdx.x;
+#else
     {
         const int64_t b = blockIdx.x, nb = gridDim.x, q = nb / 8, r = nb % 8, x = b % 8;
         tile_local = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
     }
+#endif
     if (POM_WPB > 1) {
         tile_local = tile_local * POM_WPB + (threadIdx.x >> 6);
         if (p.block0 + tile_local >= p.block_end) return; /* the last workgroup of a launch may be short of tiles */
