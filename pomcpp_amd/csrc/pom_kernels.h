@@ -5,8 +5,8 @@
  * ([row][lane]: every per-lane dynamic index is an LDS address, no shuffles, no scratch).
  *
  * The tick itself is pom_step_body.h; this file is the data movement around it:
- *   HBM (SoA records, pom_packed.h) -> LDS tile + VGPRs -> tick(s) -> HBM,
- * the SimpleAgent policy kernel, the observation export, the board generator, the AoS<->SoA pack / unpack at the boundary,
+ *   HBM (packed records in 16-env tiles, pom_packed.h) -> LDS tile + VGPRs -> tick(s) -> HBM,
+ * the SimpleAgent policy kernel, the observation export, the board generator, the pack / unpack between the boundary's 1004-byte States and the tiles,
  * status extraction and counters.
  */
 #ifndef POM_KERNELS_H_
@@ -255,7 +255,7 @@ __device__ __forceinline__ void store_tile16_x4(uint32_t* base, int64_t np, cons
 }
 /*
  * The restart snapshot is kept array-of-structs: env e's record is the 448 contiguous bytes snap[e * 112 .. e * 112 + 111].
- * A restart needs ONE env's whole record, and in the struct-of-arrays layout of the state buffer that is 112 dwords in 112
+ * A restart needs ONE env's whole record, and in the column layout of the state buffer that is 112 dwords in 112
  * different 64-byte sectors (4 useful bytes each: 18 MB of HBM fetch per step at 65,536 envs for the 3.8 % of envs that
  * restart, a fifth of the kernel's whole traffic; profiles/r02a_head1_summary.txt).  Here the whole wavefront fetches the
  * record of one restarting env — lane l takes dwords l and l + 64, seven fully used sectors — and writes it into that env's

@@ -154,7 +154,7 @@ POM_HD int ag_y(int a0) { return (a0 >> 8) & 0xFF; }
 POM_HD int ag_dead(int a0) { return (a0 >> 25) & 1; }
 POM_HD int ag_kick(int a0) { return (a0 >> 24) & 1; }
 POM_HD int ag_setpos(int a0, int x, int y) { return (a0 & ~0xFFFF) | x | (y << 8); }
-POM_HD int ag_bombcount_add(int a0, int d) { return (a0 & ~0xFF0000) | ((a0 + (d << 16)) & 0xFF0000); }
+POM_HD int ag_bombcount_add(int a0, int d) { return (a0 & ~0xFF0000) | (int)(((uint32_t)a0 + ((uint32_t)d << 16)) & 0xFF0000u); } /* d may be -1: unsigned arithmetic */
 
 POM_HD int wrap20(int p) { return p >= POM_Q ? p - POM_Q : p; } /* p < 40 */
 POM_HD uint32_t pom_zero_bytes(uint32_t x) /* 0x80 in exactly the bytes of x that are 0 */
