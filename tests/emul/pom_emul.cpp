@@ -69,6 +69,38 @@ int pom_emul_prep(const void* state_1004, const int32_t* moves, int32_t* dest_xy
     return nroots;
 }
 
+/* The device buffers' layout (pom_packed.h: tiles of 16 envs, pom_rec_col): `n` States packed into a buffer of ceil(n/16) tiles
+ * exactly as pom_pack_kernel does it, then unpacked again.  Returns 0 if every State comes back and every env's 112 dwords lie
+ * inside its own tile at the documented places, else a line number. */
+int pom_emul_tile_roundtrip(const void* states_1004, int n, void* out_1004)
+{
+    const int tiles = (n + POM_TILE_ENVS - 1) / POM_TILE_ENVS;
+    uint32_t* buf = new uint32_t[(size_t)tiles * POM_TILE_DWORDS];
+    uint8_t* owner = new uint8_t[(size_t)tiles * POM_TILE_DWORDS]; /* which env (mod 251, +1) wrote each dword */
+    std::memset(buf, 0, (size_t)tiles * POM_TILE_DWORDS * 4);
+    std::memset(owner, 0, (size_t)tiles * POM_TILE_DWORDS);
+    int rc = 0;
+    for (int e = 0; e < n && !rc; e++) {
+        const int64_t col = pom_rec_col(e);
+        if (col / POM_TILE_DWORDS != e / POM_TILE_ENVS) rc = __LINE__;
+        if (pom_pack_state((const int32_t*)states_1004 + (size_t)e * 251, buf + col, POM_TILE_ENVS)) rc = __LINE__;
+        for (int d = 0; d < POM_REC_DWORDS && !rc; d++) {
+            const int64_t at = (int64_t)(e / POM_TILE_ENVS) * POM_TILE_DWORDS + d * POM_TILE_ENVS + e % POM_TILE_ENVS; /* the documented place */
+            if (at != col + (int64_t)d * POM_TILE_ENVS || owner[at]) rc = __LINE__;
+            owner[at] = (uint8_t)(e % 251 + 1);
+        }
+    }
+    for (int e = 0; e < n && !rc; e++) {
+        int32_t st[251];
+        std::memset(st, 0, sizeof st);
+        pom_unpack_state(buf + pom_rec_col(e), POM_TILE_ENVS, st);
+        std::memcpy((char*)out_1004 + (size_t)e * POM_STATE_BYTES, st, POM_STATE_BYTES);
+    }
+    delete[] buf;
+    delete[] owner;
+    return rc;
+}
+
 /* one tick through pack -> device body -> unpack.  status_io: the env's status byte (ENV mode).
  * returns the POM_UB_* flags of this tick, or 0xFFFFFFFF if the state is not representable */
 uint32_t pom_emul_step(void* state_1004, const int32_t* moves, int env_mode, int max_steps, uint32_t* status_io)

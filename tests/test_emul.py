@@ -73,6 +73,17 @@ def test_pack_unpack_round_trip_and_rejections(emul_bins):
         assert emul_bins.pom_emul_step(s.ctypes.data, idle.ctypes.data, 0, 0, None) == 0xFFFFFFFF
 
 
+def test_tile_layout_of_the_device_buffers(emul_bins):
+    """pom_packed.h: tiles of 16 envs, struct-of-arrays inside a tile; every env's dwords at the documented places, disjoint"""
+    n = 100  # not a multiple of 16
+    s = pa.make_boards(n, seed=21, kind="stress")
+    s["agents"]["pad"] = 0
+    out = np.zeros(n, dtype=STATE_DTYPE)
+    emul_bins.pom_emul_tile_roundtrip.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    assert emul_bins.pom_emul_tile_roundtrip(s.ctypes.data, n, out.ctypes.data) == 0
+    assert out.tobytes() == s.tobytes()
+
+
 def test_env_epilogue_timeout_and_winner(emul_bins):
     s = pa.new_states(1)
     pa.put_agents_in_corners(s[0])
