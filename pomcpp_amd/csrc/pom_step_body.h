@@ -376,6 +376,7 @@ struct PomStepper {
             const int c0 = y * POM_N + x;
             const int e0 = a.cell(c0); /* the origin, read together with the rays' first cells: nothing is written before the vote */
             int chains = 0, victims = 0;
+            int chain_key = 0; /* this lane's ray stopped at a cell with a queued bomb: distance << 12 | agent there | his id << 1 */
             uint32_t lens = 0; /* reach of ray r in nibble r */
             uint32_t ends = 0; /* power-up flag of the wood a ray ends on, 2 bits per ray (only a ray's last cell can be wood) */
             POM_NOUNROLL
@@ -391,6 +392,7 @@ struct PomStepper {
                         const int cy = div11(c);
                         if (bomb_index_alone((c - cy * POM_N) | (cy << 4)) >= 0) {
                             chains = 1;
+                            chain_key = (i << 12) | pc_is_agent(e) | ((e & 3) << 1);
                             break;
                         }
                         if (pc_is_agent(e)) victims |= 1 << (e & 3); /* killed, the ray goes on (bboard.cpp:26-29) */
@@ -425,8 +427,14 @@ struct PomStepper {
                 }
                 return;
             }
+            /* a short blast that meets a queued bomb (nothing has been written yet): the look-and-commit engine; with a lane per
+             * ray the scan above IS the engine's first look — each lane hands over what it saw on its ray */
+            if (A::G == 4) {
+                const int r = a.sub();
+                explode_long(x, y, strength, rem, 1, (int)((lens >> (4 * r)) & 0xF), (int)((ends >> (2 * r)) & 3u), victims, chain_key);
+                return;
+            }
         }
-        /* a long blast, or a short one that meets a queued bomb (nothing has been written yet): the look-and-commit engine */
         explode_long(x, y, strength, rem);
     }
 
@@ -544,7 +552,8 @@ struct PomStepper {
      * "A queued bomb under the item" is answered from a set of bomb cells built once per call (bomb_cells); explosions only
      * remove bombs, so the set can only be too large, and the one cell a look settles on is checked against the queue itself
      * (which also yields the bomb's index): a cell found empty there is struck from the set and the look repeated. */
-    POM_HD void explode_long(int x, int y, int strength, int rem)
+    POM_HD void explode_long(int x, int y, int strength, int rem, int seen = 0, int seen_len = 0, int seen_ends = 0, int seen_vict = 0,
+                             int seen_chain = 0)
     {
         int s = strength < 0 ? 0 : strength > POM_N ? POM_N : strength;
         POM_STAMP(L, POM_PH_TICK_BOMBS);
@@ -594,11 +603,19 @@ struct PomStepper {
                 int chain = 0, info = 0;
                 rlen[q] = rs[q] - 1;
                 rends[q] = rwood[q] = rvict[q] = 0;
-                if (r >= dir) scan_ray(c0, r, rs[q], ray_room(x, y, s, r), occ, rlen[q], rends[q], rwood[q], rvict[q], chain, info);
+                if (seen) { /* the caller's scan of this very blast (explode): ray r of lane r from distance 1, nothing written since */
+                    rlen[q] = seen_len;
+                    rends[q] = seen_ends; /* 0 unless the ray ends on a flagged wood */
+                    rwood[q] = 1;
+                    rvict[q] = seen_vict;
+                    chain = seen_chain >> 12;
+                    info = seen_chain & 0xFFF;
+                } else if (r >= dir) scan_ray(c0, r, rs[q], ray_room(x, y, s, r), occ, rlen[q], rends[q], rwood[q], rvict[q], chain, info);
                 const int key = (r << 16) | (chain << 12) | info;
                 first = (chain != 0 && key < first) ? key : first;
             }
             first = a.gmin(first);
+            seen = 0;
             rstar = first == 0x7FFFFFFF ? 4 : first >> 16;
             if (rstar < 4) { /* the cell the look settled on: which bomb is it? */
                 const int c = ray_cell(c0, rstar, (first >> 12) & 0xF);
