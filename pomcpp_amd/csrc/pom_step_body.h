@@ -431,7 +431,7 @@ struct PomStepper {
              * ray the scan above IS the engine's first look — each lane hands over what it saw on its ray */
             if (A::G == 4) {
                 const int r = a.sub();
-                explode_long(x, y, strength, rem, 1, (int)((lens >> (4 * r)) & 0xF), (int)((ends >> (2 * r)) & 3u), victims, chain_key);
+                explode_long(x, y, strength, rem, 1, (int)((lens >> (4 * r)) & 0xF), (int)((ends >> (2 * r)) & 3u), victims, chain_key, e0);
                 return;
             }
         }
@@ -553,11 +553,12 @@ struct PomStepper {
      * remove bombs, so the set can only be too large, and the one cell a look settles on is checked against the queue itself
      * (which also yields the bomb's index): a cell found empty there is struck from the set and the look repeated. */
     POM_HD void explode_long(int x, int y, int strength, int rem, int seen = 0, int seen_len = 0, int seen_ends = 0, int seen_vict = 0,
-                             int seen_chain = 0)
+                             int seen_chain = 0, int seen_origin = 0)
     {
         int s = strength < 0 ? 0 : strength > POM_N ? POM_N : strength;
         POM_STAMP(L, POM_PH_TICK_BOMBS);
-        flame_prologue(x, y, strength);
+        if (seen) flame_prologue(x, y, strength, seen_origin); /* the caller has looked at the origin cell already */
+        else flame_prologue(x, y, strength);
         int dir = 0, i = 1, sp = 0; /* the rays before `dir` are done, ray `dir` goes on at distance i, the others start at 1 */
         constexpr int NR = 4 / A::G;
         uint32_t occ[4];
@@ -1137,9 +1138,12 @@ struct PomStepper {
                 POM_NOUNROLL
                 for (int r = 0; r < rounds; r++) {
                     const int act = goes && mydepth == r;
-                    int item = 0, collide = 0;
+                    int item = 0, collide = 0, shows_me = 0;
                     if (act) { /* what is there now: everything the earlier rounds did has been written */
                         item = a.cell(dc);
+                        /* my own cell, asked together with the destination (one round trip): nobody writes it in this round —
+                         * whoever wants it waits for me and moves in a later one */
+                        shows_me = a.cell(oc) == (POM_C_AGENT | m);
 #pragma unroll
                         for (int j = 0; j < 4; j++)
                             collide |= (j != m) & !((deadmask >> j) & 1) & (((dstp >> (8 * j)) & 0xFF) == (uint32_t)dkey);
@@ -1156,7 +1160,7 @@ struct PomStepper {
                         if (pc_is_flame(item)) { /* step.cpp:84-99 */
                             died = 1;
                             av |= 1 << 25;
-                            if (a.cell(oc) == (POM_C_AGENT | m)) a.put_cell(oc, vacated);
+                            if (shows_me) a.put_cell(oc, vacated);
                         } else if (!collide) {
                             if (pc_is_powerup(item)) { /* ConsumePowerup, step_utility.cpp:247-262 */
                                 if (item == POM_EXTRABOMB) a1v = (a1v & ~0xFFFF) | ((a1v + 1) & 0xFFFF);
@@ -1165,7 +1169,7 @@ struct PomStepper {
                                 item = POM_C_PASSAGE;
                             }
                             if (item == POM_C_PASSAGE) { /* step.cpp:120-140 */
-                                if (a.cell(oc) == (POM_C_AGENT | m)) a.put_cell(oc, vacated);
+                                if (shows_me) a.put_cell(oc, vacated);
                                 a.put_cell(dc, POM_C_AGENT | m);
                                 av = ag_setpos(av, ddx, ddy);
                             } else if (item == POM_C_BOMB) { /* step.cpp:147-184 */
@@ -1175,7 +1179,7 @@ struct PomStepper {
                                  * bomb can be heading for it: none moves), restoring both cells and his position.  The pair
                                  * is skipped — provided a queued bomb really sits there (a BOMB item without one bounces nobody)
                                  * and his own cell shows him, so that "restoring" it changes nothing. */
-                                if (!bombs_move && a.cell(oc) == (POM_C_AGENT | m) && bomb_index_alone(ddx | (ddy << 4)) >= 0) {
+                                if (!bombs_move && shows_me && bomb_index_alone(ddx | (ddy << 4)) >= 0) {
                                 } else {
                                     a.put_cell(oc, vacated);
                                     a.put_cell(dc, POM_C_AGENT | m);
