@@ -570,6 +570,8 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
 #endif
     long long c_steps = 0, c_episodes = 0, c_resets = 0, c_ub = 0;
 
+    /* the launch's first tick: asked for BEFORE the record, so that waiting for it (in-order vmcnt) does not wait for the record */
+    const uint32_t tick0 = p.tick0 + *p.tick_base;
     if (EPW == 16) load_tile16_x4(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane); /* 16-byte pieces, 7 instructions of 1 KB */
     else load_tile<EPW>(col_d, POM_TILE_ENVS, tile, sub);
     uint32_t m0 = 0, m1 = 0; /* POLICY: this lane's agent's memory */
@@ -577,7 +579,6 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         m0 = p.agent_mem[tile_id * 64 + lane];
         m1 = p.agent_mem[4 * np + tile_id * 64 + lane];
     }
-    const uint32_t tick0 = p.tick0 + *p.tick_base; /* a scalar load, in flight with the record */
     /* the first tick's moves do not depend on the record: hash / fetch them while the record is on its way */
     uint64_t draw0 = 0;
     int4 moves0 = make_int4(0, 0, 0, 0);
