@@ -44,13 +44,16 @@ POM_HD uint32_t pom_fmix32(uint32_t h)
     return h;
 }
 
-/* one 64-bit draw per (seed, env, tick); 16 bits per agent */
-POM_HD uint64_t pom_rng_draw(uint64_t seed, uint32_t env, uint32_t tick)
+/* one 64-bit draw per (seed, env, tick), 16 bits per agent: two independent 32-bit halves (agents 0, 1 / agents 2, 3), so that a
+ * device lane that speaks for one agent computes only the half it needs */
+POM_HD uint32_t pom_rng_draw_half(uint64_t seed, uint32_t env, uint32_t tick, int upper)
 {
     const uint32_t k = (uint32_t)seed ^ (env * 0x9E3779B1u) ^ (tick * 0x7FEB352Du + (uint32_t)(seed >> 32));
-    const uint32_t lo = pom_fmix32(k);
-    const uint32_t hi = pom_fmix32(lo ^ 0x68E31DA4u ^ env);
-    return (uint64_t)lo | ((uint64_t)hi << 32);
+    return pom_fmix32(upper ? k ^ 0x68E31DA4u : k);
+}
+POM_HD uint64_t pom_rng_draw(uint64_t seed, uint32_t env, uint32_t tick)
+{
+    return (uint64_t)pom_rng_draw_half(seed, env, tick, 0) | ((uint64_t)pom_rng_draw_half(seed, env, tick, 1) << 32);
 }
 
 POM_HD int32_t pom_rng_pick(uint32_t r16, int dist)

@@ -586,7 +586,8 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         if (p.moves) {
             if (valid) moves0 = reinterpret_cast<const int4*>(p.moves)[e];
         } else {
-            draw0 = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), tick0);
+            if (G == 4) draw0 = pom_rng_draw_half(p.seed, (uint32_t)(p.env_offset + e), tick0, member >> 1); /* lane m needs agent m's 16 bits only */
+            else draw0 = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), tick0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the DMA rows have landed (one wavefront per workgroup: no barrier) */
@@ -680,13 +681,13 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
 #endif
             { /* act() is only asked of live agents (environment.cpp:139-146); the wavefront's searches run together: every lane goes in */
                 const PomPolicyEnv E{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {L.a1[0], L.a1[1], L.a1[2], L.a1[3]}, L.bIdx, L.bCnt};
-                const uint64_t r = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), tick0 + (uint32_t)tk);
+                const uint32_t r = pom_rng_draw_half(p.seed, (uint32_t)(p.env_offset + e), tick0 + (uint32_t)tk, member >> 1);
                 const bool actor = active && !ag_dead(sel4(member, L.a0));
 #if defined(POM_DIAG)
                 long long pt_last = 0, pt_acc[POM_PP_N];
-                mv_own = pom_policy_wave(st, E, member, m0, m1, actor, (int)((((uint32_t)(r >> (16 * member)) & 0xFFFFu) * 5u) >> 16), sets, lane, pt_last, pt_acc);
+                mv_own = pom_policy_wave(st, E, member, m0, m1, actor, (int)((((r >> (16 * (member & 1))) & 0xFFFFu) * 5u) >> 16), sets, lane, pt_last, pt_acc);
 #else
-                mv_own = pom_policy_wave(st, E, member, m0, m1, actor, (int)((((uint32_t)(r >> (16 * member)) & 0xFFFFu) * 5u) >> 16), sets, lane);
+                mv_own = pom_policy_wave(st, E, member, m0, m1, actor, (int)((((r >> (16 * (member & 1))) & 0xFFFFu) * 5u) >> 16), sets, lane);
 #endif
             }
             p.agent_mem[tile_id * 64 + lane] = m0;
@@ -703,8 +704,8 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                     const int lo = (member & 1) ? moves0.y : moves0.x, hi = (member & 1) ? moves0.w : moves0.z;
                     mine = (member & 2) ? hi : lo;
                 } else {
-                    const uint64_t r = tk == 0 ? draw0 : pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), tick0 + (uint32_t)tk);
-                    mine = pom_rng_pick((uint32_t)(r >> (16 * member)) & 0xFFFFu, p.dist);
+                    const uint32_t r = tk == 0 ? (uint32_t)draw0 : pom_rng_draw_half(p.seed, (uint32_t)(p.env_offset + e), tick0 + (uint32_t)tk, member >> 1);
+                    mine = pom_rng_pick((r >> (16 * (member & 1))) & 0xFFFFu, p.dist);
                 }
                 mvp = stepper.pack_moves_quad(mine);
             } else {
@@ -950,8 +951,8 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
     POM_PSTAMP(POM_PP_PREPARE);
     { /* act() is only asked of live agents (environment.cpp:139-146); the wavefront's searches run together: every lane goes in */
         const bool actor = e < p.n && !frozen && !ag_dead(sel4(id, E.a0));
-        const uint64_t r = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), p.tick);
-        const int draw = (int)((((uint32_t)(r >> (16 * id)) & 0xFFFFu) * 5u) >> 16);
+        const uint32_t r = pom_rng_draw_half(p.seed, (uint32_t)(p.env_offset + e), p.tick, id >> 1);
+        const int draw = (int)((((r >> (16 * (id & 1))) & 0xFFFFu) * 5u) >> 16);
 #if defined(POM_DIAG)
         mv = pom_policy_wave(st, E, id, m0, m1, actor, draw, sets, lane, t_last, t_acc);
 #else
