@@ -564,22 +564,25 @@ def worker(args) -> None:
                            "ticks": launches * t_o,
                            "note": "ticks_per_launch > 1: the tile stays in LDS between ticks; not the canonical one-round-trip-per-tick step"}
             e4.close()
-        # the literal drop-in, one env at a time: pom_step (= bboard::Step(State*, Move*) behind the C-ABI: upload, one launch,
-        # download, all blocking).  Latency, not throughput: compare with cpu_baseline.config1.
-        from pomcpp_amd.batch import step_one
+        # the literal drop-in, one env at a time: pom_step (= bboard::Step(State*, Move*) behind the C-ABI: the State in a pinned
+        # page, ONE launch that reads, steps and writes it back, the host polling the kernel's last store).  Latency, not
+        # throughput: compare with cpu_baseline.config1.  Called through ctypes with the pointers prepared (≈ 1 us of Python per call).
+        from pomcpp_amd.batch import load_library
+        lib1 = load_library()
         one = np.ascontiguousarray(start[:1]).copy()
         mv1 = np.zeros(4, dtype=np.int32)
+        p_state, p_moves = one.ctypes.data, mv1.ctypes.data
         for _ in range(20):
-            step_one(one, mv1)
+            assert lib1.pom_step(p_state, p_moves) == 0
         t_l = time.perf_counter()
-        n_l = 200
+        n_l = 1000
         for k in range(n_l):
-            mv1[:] = (k % 5, (k + 1) % 5, (k + 2) % 5, (k + 3) % 5)  # HarmlessAgent's range: no bombs
-            step_one(one, mv1)
+            mv1[0] = k % 5  # HarmlessAgent's range: no bombs
+            lib1.pom_step(p_state, p_moves)
         us_l = (time.perf_counter() - t_l) / n_l * 1e6
         other["single_env_pom_step"] = {"value": 1e6 / us_l, "unit": "env-steps/s", "us_per_call": us_l, "calls": n_l,
-                                        "note": "pom_step(State*, Move[4]) on ONE env: host State up, one launch, State down, blocking; "
-                                                "the batch API is the product, this is the literal bboard::Step replacement"}
+                                        "note": "pom_step(State*, Move[4]) on ONE env: one launch reads the host State, steps it and writes "
+                                                "it back, blocking; the batch API is the product, this is the literal bboard::Step replacement"}
         other["explicit_moves_device_65536_envs"] = {
             "value": plan["n_envs"] / (ms_x * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_x, "steps": n_x,
             "note": "pom_batch_step_device with auto_reset = POM_RESET_AT_END: Move[4] from device memory, one launch per tick on the caller's stream"}

@@ -206,12 +206,21 @@ enum { POM_OBS_PLANES = 16, POM_OBS_AGENT_ATTRS = 8, POM_OBS_ENV_ATTRS = 4 };
 int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_agent, int32_t* agent_attrs_dev,
                       int32_t* env_attrs_dev);
 
-/* bboard::Step for a single host State on the GPU (a batch of one, device 0): the literal drop-in.  Compatibility path, not
- * a fast one: every call uploads the State, steps and downloads it, and ALL callers of the process share one internal
- * one-env handle behind a mutex — calls from several threads are safe but run one after the other, whereas the reference's
- * Step is re-entrant over distinct States (performance_test.cpp:71-94 steps one env per std::thread).  Code that steps
- * many States should hand them to one PomBatch (pom_batch_upload / pom_batch_step) instead. */
+/* bboard::Step (include/bboard.hpp:668, src/bboard/step.cpp:9-284) for a single host State on the GPU (device 0): the literal
+ * drop-in.  One launch per call: the kernel reads the State and Move[4] from a pinned page, plays the tick and writes the State
+ * back; the call returns when that is done (tens of microseconds — the launch and the trip over PCIe, not the tick).  ALL
+ * callers of the process share that page behind a mutex — calls from several threads are safe but run one after the other,
+ * whereas the reference's Step is re-entrant over distinct States (performance_test.cpp:71-94 steps one env per std::thread).
+ * Code that steps many States should hand them to one PomBatch (pom_batch_upload / pom_batch_step) instead.
+ * POM_E_UNREPRESENTABLE: the State holds a value the device record cannot hold; it is left as it is. */
 int pom_step(void* state_1004, const int32_t moves[4]);
+
+/* The same with Environment::Step's bookkeeping after the tick (src/bboard/environment.cpp:148-168): timeStep++, then
+ * done / winner (-1 = none) / draw as pom_batch_status reports them, judged on this tick alone; max_steps > 0 also ends the
+ * game at that timeStep.  The caller decides whether a game is stepped at all (the reference returns early from a finished
+ * one, environment.cpp:125).  Outputs may be NULL.  ubflags: the POM_UB_* of this tick. */
+int pom_env_step(void* state_1004, const int32_t moves[4], int32_t max_steps, int32_t* done, int32_t* winner, int32_t* draw,
+                 uint32_t* ubflags);
 
 #ifdef __cplusplus
 }

@@ -315,16 +315,15 @@ inline void StartGame(State* state, Agent* agents[AGENT_COUNT], int timeSteps)
     }
 }
 
-// One game with the reference's own surface (bboard.hpp:541-644, environment.cpp:48-213) over ONE slot of a device batch:
-// the tick and Environment::Step's bookkeeping (timeStep++, finished / winner / draw) run on the GPU in POM_MODE_ENV.
-// GetState() is the host mirror callers may edit between steps, as main.cpp:18-21 does, so every Step hands it to the device
-// and takes the result back (2 kB each way; a loop over many games wants BatchEnvironment).  Differences, all at points where
-// the reference is undefined: a dead agent's Move entry is IDLE (the reference leaves it uninitialised, environment.cpp:130,
-// SURVEY Q9); MakeGame's board comes from InitBoardItems above.
+// One game with the reference's own surface (bboard.hpp:541-644, environment.cpp:48-213): the tick and Environment::Step's
+// bookkeeping (timeStep++, finished / winner / draw) run on the GPU, one launch per Step (pom_env_step).  GetState() is the
+// host State callers may edit between steps, as main.cpp:18-21 does: every Step hands it to the device and takes the result
+// back (a loop over many games wants BatchEnvironment).  Differences, all at points where the reference is undefined: a dead
+// agent's Move entry is IDLE (the reference leaves it uninitialised, environment.cpp:130); MakeGame's board comes
+// from InitBoardItems above.
 class Environment {
 public:
     Environment() : state(std::make_unique<State>()) { agents.fill(nullptr); std::fill(lastMoves, lastMoves + AGENT_COUNT, Move::IDLE); }
-    ~Environment() { if (h_) pom_batch_destroy(h_); }
     Environment(const Environment&) = delete;
     Environment& operator=(const Environment&) = delete;
 
@@ -373,17 +372,8 @@ public:
                     lastMoves[i] = m[i];
                 }
         }
-        if (!h_) {
-            PomBatchOptions o{};
-            o.struct_size = sizeof o;
-            o.mode = POM_MODE_ENV;
-            pom_check(pom_batch_create(&h_, 1, &o));
-        }
-        pom_check(pom_batch_upload(h_, state.get(), 0, 1));
-        pom_check(pom_batch_step(h_, reinterpret_cast<const int32_t*>(m)));
-        pom_check(pom_batch_download(h_, state.get(), 0, 1));
         int32_t done = 0, winner = -1, draw = 0;
-        pom_check(pom_batch_status(h_, 0, 1, &done, &winner, &draw, nullptr, nullptr, nullptr));
+        pom_check(pom_env_step(state.get(), reinterpret_cast<const int32_t*>(m), 0, &done, &winner, &draw, nullptr));
         finished = done != 0;
         isDraw = draw != 0;
         if (winner >= 0) agentWon = winner;
@@ -409,7 +399,6 @@ private:
     bool finished = false, hasStarted = false, isDraw = false;
     int agentWon = -1;
     Move lastMoves[AGENT_COUNT];
-    PomBatch* h_ = nullptr;
 };
 
 // n concurrent games on one device: MakeGame / Step / IsDone / IsDraw / GetWinner / GetState of Environment,

@@ -114,6 +114,8 @@ def load_library() -> C.CDLL:
     lib.pom_batch_launch_shape.argtypes = [P, C.POINTER(I32), C.POINTER(I32), C.POINTER(I32)]
     lib.pom_batch_device_view.argtypes = [P, C.POINTER(VP), C.POINTER(I64), C.POINTER(I32)]
     lib.pom_step.argtypes = [VP, VP]
+    if not os.environ.get("POM_LIB") or hasattr(lib, "pom_env_step"):
+        lib.pom_env_step.argtypes = [VP, VP, I32, VP, VP, VP, VP]
     _lib = lib
     return lib
 
@@ -132,6 +134,21 @@ def step_one(state: np.ndarray, moves) -> None:
     buf = np.ascontiguousarray(state).reshape(1)
     _check(lib, lib.pom_step(buf.ctypes.data, mv.ctypes.data))
     state[...] = buf.reshape(state.shape)
+
+
+def env_step_one(state: np.ndarray, moves, max_steps: int = 0) -> dict:
+    """`Environment::Step`'s tick + bookkeeping on one host State (pom_env_step): timeStep++, done / winner / draw of this
+    tick.  The caller does not step a finished game (environment.cpp:125)."""
+    lib = load_library()
+    assert state.dtype == STATE_DTYPE and state.size == 1
+    mv = np.ascontiguousarray(moves, dtype=np.int32)
+    assert mv.shape == (4,)
+    buf = np.ascontiguousarray(state).reshape(1)
+    out = np.zeros(4, dtype=np.int32)
+    _check(lib, lib.pom_env_step(buf.ctypes.data, mv.ctypes.data, int(max_steps), out[0:].ctypes.data, out[1:].ctypes.data,
+                                 out[2:].ctypes.data, out[3:].ctypes.data))
+    state[...] = buf.reshape(state.shape)
+    return {"done": int(out[0]), "winner": int(out[1]), "draw": int(out[2]), "ubflags": int(out[3]) & 0xFFFFFFFF}
 
 
 class BatchEnvironment:

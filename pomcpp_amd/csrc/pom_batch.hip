@@ -709,25 +709,77 @@ int pom_batch_launch_shape(PomBatch* h, int32_t* envs_per_wave, int32_t* lanes_p
     return POM_OK;
 }
 
-int pom_step(void* state_1004, const int32_t moves[4])
+/* pom_step / pom_env_step: one pinned, device-mapped page the kernel reads the State from and writes it back to
+ * (pom_step_one_kernel), one launch per call, the host polling the kernel's last store.  One context per process, device 0,
+ * behind a mutex. */
+struct PomOne {
+    std::mutex mu;
+    int32_t* io = nullptr;     /* host address of the page */
+    int32_t* io_dev = nullptr; /* the same page as the device sees it */
+    hipStream_t stream = nullptr;
+    uint32_t seq = 0;
+    bool ready = false;
+};
+static PomOne g_one;
+
+static int step_one(void* state_1004, const int32_t moves[4], int32_t mode, int32_t max_steps, int32_t status4[4])
 {
-    static std::mutex mu;
-    static PomBatch* one = nullptr;
     if (!state_1004 || !moves) return POM_E_ARG;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!one) {
-        PomBatchOptions o;
-        memset(&o, 0, sizeof o);
-        o.struct_size = sizeof o;
-        o.mode = POM_MODE_RAW;
-        int rc = pom_batch_create(&one, 1, &o);
-        if (rc) return rc;
+    PomOne& o = g_one;
+    std::lock_guard<std::mutex> lock(o.mu);
+    HIPCHK(hipSetDevice(0));
+    if (!o.ready) {
+        if (!o.io) HIPCHK(hipHostMalloc((void**)&o.io, 4096, hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(hipHostGetDevicePointer((void**)&o.io_dev, o.io, 0));
+        if (!o.stream) HIPCHK(hipStreamCreateWithFlags(&o.stream, hipStreamNonBlocking));
+        memset(o.io, 0, 4096);
+        o.ready = true;
     }
-    int rc = pom_batch_upload(one, state_1004, 0, 1);
+    memcpy(o.io, state_1004, POM_STATE_BYTES);
+    memcpy(o.io + POM_ONE_MOVES, moves, 16);
+    StepOneParams p;
+    p.io = o.io_dev;
+    p.mode = mode;
+    p.max_steps = max_steps;
+    p.seq = ++o.seq ? o.seq : ++o.seq; /* never 0: the page starts zeroed */
+    pom_step_one_kernel<<<dim3(1), dim3(64), 0, o.stream>>>(p);
+    HIPCHK(hipGetLastError());
+    /* the kernel's last store is the sequence word; spin on it for a moment (a blocking wait costs more than the tick), then
+     * wait the ordinary way — which is also where a failed launch surfaces */
+    volatile uint32_t* seq_word = reinterpret_cast<volatile uint32_t*>(o.io) + POM_ONE_SEQ;
+    const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+    while (*seq_word != p.seq && std::chrono::steady_clock::now() < until) {
+    }
+    if (*seq_word != p.seq) {
+        HIPCHK(hipStreamSynchronize(o.stream));
+        if (*seq_word != p.seq) {
+            snprintf(g_err, sizeof g_err, "pom_step: the kernel finished without reporting");
+            return POM_E_HIP;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (o.io[POM_ONE_BAD]) {
+        snprintf(g_err, sizeof g_err, "pom_step: the State holds a value outside the representable game states (it was left as it is)");
+        return POM_E_UNREPRESENTABLE;
+    }
+    memcpy(state_1004, o.io + POM_ONE_OUT, POM_STATE_BYTES);
+    if (status4) memcpy(status4, o.io + POM_ONE_STATUS, 16);
+    return POM_OK;
+}
+
+int pom_step(void* state_1004, const int32_t moves[4]) { return step_one(state_1004, moves, POM_MODE_RAW, 0, nullptr); }
+
+int pom_env_step(void* state_1004, const int32_t moves[4], int32_t max_steps, int32_t* done, int32_t* winner, int32_t* draw,
+                 uint32_t* ubflags)
+{
+    int32_t st[4] = {0, -1, 0, 0};
+    const int rc = step_one(state_1004, moves, POM_MODE_ENV, max_steps, st);
     if (rc) return rc;
-    rc = pom_batch_step(one, moves);
-    if (rc) return rc;
-    return pom_batch_download(one, state_1004, 0, 1);
+    if (done) *done = st[0];
+    if (winner) *winner = st[1];
+    if (draw) *draw = st[2];
+    if (ubflags) *ubflags = (uint32_t)st[3];
+    return POM_OK;
 }
 
 } /* extern "C" */

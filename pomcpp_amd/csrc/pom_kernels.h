@@ -563,6 +563,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     const bool owner = G == 1 ? sub == 0 : member == 0; /* the lane that speaks for env e (register rows, counters) */
     const bool runs = G == 1 ? sub == 0 : true;         /* the lanes that execute env e's tick */
     const bool valid = runs && e < p.n;
+    const uint32_t env_key = (uint32_t)(p.env_offset + e); /* the env's number in the whole job: what its move draws are keyed by */
     uint32_t* t = tile + ec;
 
 #if defined(POM_DIAG)
@@ -582,12 +583,15 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     /* the first tick's moves do not depend on the record: hash / fetch them while the record is on its way */
     uint64_t draw0 = 0;
     int4 moves0 = make_int4(0, 0, 0, 0);
+    /* explicit moves come one tick per launch: the several-tick quad kernel never sees any (step_kernel_for) */
+    constexpr bool TAKES_MOVES = SINGLE || G == 1;
     if (!POLICY) {
-        if (p.moves) {
+        if (TAKES_MOVES && p.moves) {
             if (valid) moves0 = reinterpret_cast<const int4*>(p.moves)[e];
         } else {
-            if (G == 4) draw0 = pom_rng_draw_half(p.seed, (uint32_t)(p.env_offset + e), tick0, member >> 1); /* lane m needs agent m's 16 bits only */
-            else draw0 = pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), tick0);
+            if (G == 4 && !SINGLE) { /* several ticks per launch: the draw is made where it is used, nothing to carry */
+            } else if (G == 4) draw0 = pom_rng_draw_half(p.seed, env_key, tick0, member >> 1); /* lane m needs agent m's 16 bits only */
+            else draw0 = pom_rng_draw(p.seed, env_key, tick0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the DMA rows have landed (one wavefront per workgroup: no barrier) */
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
             /* fresh boards: a finished env starts its next game on the board (board_seed, env, games played) of
              * pom_boardgen.h, drawn into its tile column by the whole wavefront, one restarting env after the other —
              * the one place, first tick included */
-            const bool reload = e < p.n && env_mode && p.auto_reset == POM_RESET_AT_START && (status & POM_ST_DONE) && runs;
+            const bool reload = valid && env_mode && p.auto_reset == POM_RESET_AT_START && (status & POM_ST_DONE);
             uint64_t todo = __ballot(reload && owner);
             while (todo) {
                 const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)todo) - 1); /* an owner lane */
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         } else {
             /* a finished env restarts from its snapshot (tick 0: as the record says; later ticks of a launch: as the epilogue
              * found), one restarting env after the other, by the whole wavefront */
-            const bool reload = e < p.n && env_mode && p.auto_reset == POM_RESET_AT_START && (status & POM_ST_DONE) && runs;
+            const bool reload = valid && env_mode && p.auto_reset == POM_RESET_AT_START && (status & POM_ST_DONE);
             uint64_t todo = __ballot(reload && owner);
             if (todo) {
                 c_resets += __popcll(todo);
@@ -681,7 +685,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
 #endif
             { /* act() is only asked of live agents (environment.cpp:139-146); the wavefront's searches run together: every lane goes in */
                 const PomPolicyEnv E{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {L.a1[0], L.a1[1], L.a1[2], L.a1[3]}, L.bIdx, L.bCnt};
-                const uint32_t r = pom_rng_draw_half(p.seed, (uint32_t)(p.env_offset + e), tick0 + (uint32_t)tk, member >> 1);
+                const uint32_t r = pom_rng_draw_half(p.seed, env_key, tick0 + (uint32_t)tk, member >> 1);
                 const bool actor = active && !ag_dead(sel4(member, L.a0));
 #if defined(POM_DIAG)
                 long long pt_last = 0, pt_acc[POM_PP_N];
@@ -700,11 +704,11 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                 int mine;
                 if (POLICY) {
                     mine = mv_own;
-                } else if (p.moves) { /* explicit moves: one tick per launch */
+                } else if (TAKES_MOVES && p.moves) { /* explicit moves: one tick per launch */
                     const int lo = (member & 1) ? moves0.y : moves0.x, hi = (member & 1) ? moves0.w : moves0.z;
                     mine = (member & 2) ? hi : lo;
                 } else {
-                    const uint32_t r = tk == 0 ? (uint32_t)draw0 : pom_rng_draw_half(p.seed, (uint32_t)(p.env_offset + e), tick0 + (uint32_t)tk, member >> 1);
+                    const uint32_t r = SINGLE ? (uint32_t)draw0 : pom_rng_draw_half(p.seed, env_key, tick0 + (uint32_t)tk, member >> 1);
                     mine = pom_rng_pick((r >> (16 * (member & 1))) & 0xFFFFu, p.dist);
                 }
                 mvp = stepper.pack_moves_quad(mine);
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                 if (p.moves) {
                     mv[0] = moves0.x; mv[1] = moves0.y; mv[2] = moves0.z; mv[3] = moves0.w;
                 } else {
-                    const uint64_t r = tk == 0 ? draw0 : pom_rng_draw(p.seed, (uint32_t)(p.env_offset + e), tick0 + (uint32_t)tk);
+                    const uint64_t r = tk == 0 ? draw0 : pom_rng_draw(p.seed, env_key, tick0 + (uint32_t)tk);
 #pragma unroll
                     for (int i = 0; i < 4; i++) mv[i] = pom_rng_pick((uint32_t)(r >> (16 * i)) & 0xFFFFu, p.dist);
                 }
@@ -1236,6 +1240,172 @@ __global__ void pom_unpack_kernel(const uint32_t* __restrict__ state, int64_t fi
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     pom_unpack_state(state + pom_rec_col(first + i), POM_TILE_ENVS, aos + i * (POM_STATE_BYTES / 4));
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * ONE State, one tick, one launch: the literal `bboard::Step(State*, Move*)` (POM_MODE_RAW) and `Environment::Step`'s tick +
+ * bookkeeping (POM_MODE_ENV; environment.cpp:123-169) for callers that hold a single host State (pom_step, pom_env_step).
+ * `io` is pinned host memory the device reads and writes directly — no staging copies, no second and third launch:
+ *   dwords   0..250  in:  the State (include/pom_state.h)        252..255  in:  Move[4]
+ *   dwords 256..506  out: the State after the tick               508..511  out: done, winner, draw, ubflags
+ *   dword  512       out: 1 if the State is outside the representable game states (nothing else is written then)
+ *   dword  513       out: `seq`, written LAST (system-scope release): the host polls it
+ * One wavefront: all 64 lanes fetch, pack (pom_pack_state's fields, a dword per lane), the quad of lanes 0..3 plays the tick with
+ * the same PomStepper as pom_step_kernel, all lanes unpack and write back.
+ * ------------------------------------------------------------------------------------------- */
+struct StepOneParams {
+    int32_t* io;
+    int32_t mode, max_steps;
+    uint32_t seq;
+};
+enum { POM_ONE_MOVES = 252, POM_ONE_OUT = 256, POM_ONE_STATUS = 508, POM_ONE_BAD = 512, POM_ONE_SEQ = 513, POM_ONE_DWORDS = 514 };
+
+__global__ __launch_bounds__(64) void pom_step_one_kernel(StepOneParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[LDS_ROWS * 16];
+    __shared__ int32_t aos[256];
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) aos[lane + 64 * k] = p.io[lane + 64 * k]; /* State + Move[4]: four 256-B reads of host memory */
+    for (int k = lane; k < LDS_ROWS * 16; k += 64) tile[k] = 0u;           /* columns 1..15 stay blank and are never stepped */
+    __syncthreads();
+    /* pack into column 0: exactly pom_pack_state + the live-bomb test of pom_pack_kernel, a record dword per lane */
+    const int32_t* st = aos;
+    int bad = 0;
+    if (lane < 61) {
+        const int lo = pom_cell_encode(st[2 * lane]);
+        const int hi = 2 * lane + 1 < POM_CELLS ? pom_cell_encode(st[2 * lane + 1]) : 0;
+        bad |= (lo < 0) | (hi < 0);
+        tile[(POM_REC_BOARD + lane) * 16] = (uint32_t)(lo & 0xFFFF) | ((uint32_t)(hi & 0xFFFF) << 16);
+    }
+    const int32_t alive = st[122], bIdx = st[167], bCnt = st[168], fIdx = st[249], fCnt = st[250];
+    if (lane == 61) {
+        bad |= (alive < -128) | (alive > 127);
+        bad |= (bIdx < 0) | (bIdx >= POM_MAX_BOMBS) | (bCnt < 0) | (bCnt > POM_MAX_BOMBS);
+        bad |= (fIdx < 0) | (fIdx >= POM_MAX_BOMBS) | (fCnt < 0) | (fCnt > 255);
+        tile[POM_REC_TIMESTEP * 16] = (uint32_t)st[121];
+        tile[POM_REC_META * 16] = ((uint32_t)alive & 0xFF) | ((uint32_t)bIdx << 8) | ((uint32_t)bCnt << 16) | ((uint32_t)fIdx << 24);
+        tile[POM_REC_META2 * 16] = (uint32_t)fCnt & 0xFF;
+    }
+    if (lane < POM_AGENT_COUNT) {
+        const int32_t* a = st + 123 + 6 * lane;
+        const uint32_t flags = (uint32_t)a[5];
+        const int kick = (flags & 0xFF) != 0, dead = ((flags >> 8) & 0xFF) != 0;
+        bad |= (a[0] < 0) | (a[0] >= POM_BOARD_SIZE) | (a[1] < 0) | (a[1] >= POM_BOARD_SIZE);
+        bad |= (a[2] < -128) | (a[2] > 127);
+        bad |= (a[3] < -32768) | (a[3] > 32767) | (a[4] < 0) | (a[4] > 255);
+        tile[(POM_REC_AGENTS + 2 * lane) * 16] =
+            (uint32_t)a[0] | ((uint32_t)a[1] << 8) | (((uint32_t)a[2] & 0xFF) << 16) | ((uint32_t)kick << 24) | ((uint32_t)dead << 25);
+        tile[(POM_REC_AGENTS + 2 * lane + 1) * 16] = ((uint32_t)a[3] & 0xFFFF) | ((uint32_t)a[4] << 16);
+    }
+    if (lane >= 20 && lane < 20 + POM_MAX_BOMBS) {
+        const int k = lane - 20;
+        const int b = st[147 + k];
+        tile[(POM_REC_BOMBS + k) * 16] = (uint32_t)b;
+        /* live bombs must sit on the board and belong to a real agent: they index cells and agents (pom_pack_kernel) */
+        const int age = k - bIdx + (k < bIdx ? POM_Q : 0); /* slot k is the age-th bomb of the queue */
+        if (bIdx >= 0 && bIdx < POM_MAX_BOMBS && age < bCnt) bad |= (pb_x(b) >= POM_N) | (pb_y(b) >= POM_N) | (pb_id(b) >= POM_AGENT_COUNT);
+    }
+    if (lane >= 40 && lane < 40 + POM_MAX_BOMBS) {
+        const int32_t* f = st + 169 + 4 * (lane - 40);
+        bad |= (f[0] < 0) | (f[0] >= POM_BOARD_SIZE) | (f[1] < 0) | (f[1] >= POM_BOARD_SIZE); /* also the stale slots */
+        bad |= (f[2] < -128) | (f[2] > 127) | (f[3] < 0) | (f[3] > 255);
+        tile[(POM_REC_FLAMES + lane - 40) * 16] =
+            (uint32_t)f[0] | ((uint32_t)f[1] << 8) | (((uint32_t)f[2] & 0xFF) << 16) | ((uint32_t)f[3] << 24);
+    }
+    if (__ballot(bad != 0)) { /* the caller's State is left alone; pom_step reports POM_E_UNREPRESENTABLE */
+        if (lane == 0) {
+            p.io[POM_ONE_BAD] = 1;
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(p.io) + POM_ONE_SEQ, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    __syncthreads();
+
+    /* the tick: lane -> (env lane / 4, member lane % 4) as in pom_step_kernel<16, 4>; env 0 is the only one there is */
+    const int ec = lane >> 2, member = lane & 3;
+    uint32_t* t = tile + ec;
+    PomLane L;
+    int time_step = 0;
+    uint32_t status = 0;
+    lane_from_tile(L, time_step, status, t, 16);
+#if defined(POM_DIAG)
+    for (int k = 0; k < POM_PH_N; k++) L.t_acc[k] = 0;
+    L.t_last = 0;
+#endif
+#if defined(POM_TRUNC)
+    L.trunc = 990;
+#endif
+    LdsEnv<16, 4> acc{t, member};
+    PomStepper<LdsEnv<16, 4>> stepper(acc, L);
+    const bool env_mode = p.mode == POM_MODE_ENV;
+    if (ec == 0) {
+        const uint32_t mvp = stepper.pack_moves_quad(aos[POM_ONE_MOVES + member]);
+        L.ub = 0;
+        stepper.step_packed(mvp);
+        if (env_mode) {
+            time_step++;
+            status = pom_env_epilogue(L, time_step, p.max_steps, status);
+        }
+        if (member == 0) { /* the register-resident rows */
+            t[POM_REC_TIMESTEP * 16] = (uint32_t)time_step;
+            t[POM_REC_META * 16] = pom_lane_meta(L);
+            t[POM_REC_META2 * 16] = pom_lane_meta2(L, status);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                t[(POM_REC_AGENTS + 2 * i) * 16] = (uint32_t)L.a0[i];
+                t[(POM_REC_AGENTS + 2 * i + 1) * 16] = (uint32_t)L.a1[i];
+            }
+        }
+    }
+    __syncthreads();
+
+    /* unpack column 0 (pom_unpack_state, a few State dwords per lane) straight into host memory */
+    int32_t* out = p.io + POM_ONE_OUT;
+    const uint32_t m = tile[POM_REC_META * 16], m2 = tile[POM_REC_META2 * 16];
+    if (lane < 61) {
+        const uint32_t w = tile[(POM_REC_BOARD + lane) * 16];
+        out[2 * lane] = pom_cell_decode((int)(w & 0xFFFF));
+        if (2 * lane + 1 < POM_CELLS) out[2 * lane + 1] = pom_cell_decode((int)(w >> 16));
+    }
+    if (lane == 61) {
+        out[121] = (int32_t)tile[POM_REC_TIMESTEP * 16];
+        out[122] = pom_sext8(m);
+        out[167] = (int32_t)((m >> 8) & 0xFF);
+        out[168] = (int32_t)((m >> 16) & 0xFF);
+        out[249] = (int32_t)(m >> 24);
+        out[250] = (int32_t)(m2 & 0xFF);
+        const uint32_t s8 = (m2 >> 8) & 0xFF;
+        p.io[POM_ONE_STATUS + 0] = (s8 & POM_ST_DONE) ? 1 : 0;
+        p.io[POM_ONE_STATUS + 1] = (int)((s8 >> POM_ST_WINNER_SHIFT) & 7) - 1;
+        p.io[POM_ONE_STATUS + 2] = (s8 & POM_ST_DRAW) ? 1 : 0;
+        p.io[POM_ONE_STATUS + 3] = (int32_t)(m2 >> 16);
+        p.io[POM_ONE_BAD] = 0;
+    }
+    if (lane < POM_AGENT_COUNT) {
+        const uint32_t a0 = tile[(POM_REC_AGENTS + 2 * lane) * 16], a1 = tile[(POM_REC_AGENTS + 2 * lane + 1) * 16];
+        int32_t* a = out + 123 + 6 * lane;
+        a[0] = (int32_t)(a0 & 0xFF);
+        a[1] = (int32_t)((a0 >> 8) & 0xFF);
+        a[2] = pom_sext8(a0 >> 16);
+        a[3] = pom_sext16(a1);
+        a[4] = (int32_t)(a1 >> 16);
+        a[5] = (int32_t)(((a0 >> 24) & 1) | (((a0 >> 25) & 1) << 8));
+    }
+    if (lane >= 20 && lane < 20 + POM_MAX_BOMBS) out[147 + lane - 20] = (int32_t)tile[(POM_REC_BOMBS + lane - 20) * 16];
+    if (lane >= 40 && lane < 40 + POM_MAX_BOMBS) {
+        const uint32_t f = tile[(POM_REC_FLAMES + lane - 40) * 16];
+        int32_t* o = out + 169 + 4 * (lane - 40);
+        o[0] = (int32_t)(f & 0xFF);
+        o[1] = (int32_t)((f >> 8) & 0xFF);
+        o[2] = pom_sext8(f >> 16);
+        o[3] = (int32_t)(f >> 24);
+    }
+    __threadfence_system(); /* every lane's stores have left before ... */
+    __syncthreads();
+    if (lane == 0) /* ... the word the host is polling changes */
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(p.io) + POM_ONE_SEQ, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 /* out: 6 arrays of `count` int32: done, winner, draw, alive, timeStep, ubflags */

@@ -147,3 +147,23 @@ def test_gpu_replays_reference_environment_games(hip_lib):
             s = env.status()
             return s["done"], s["winner"], s["draw"]
         _replay_env_games(step_all)
+
+
+@pytest.mark.gpu
+def test_gpu_one_state_env_step_replays_reference_environment_games(hip_lib):
+    """The same games through pom_env_step: one host State per call, the tick and Environment::Step's bookkeeping in one launch
+    (what bboard::Environment::Step of include/pom_bboard.hpp calls).  The caller keeps finished games away from it
+    (environment.cpp:125-128)."""
+    from pomcpp_amd.batch import env_step_one
+    E = len(ENVT["start"])
+    status = [dict(done=0, winner=-1, draw=0) for _ in range(E)]
+
+    def step_all(st, mv, active):
+        for e in range(E):
+            if active[e] and not status[e]["done"]:
+                r = env_step_one(st[e:e + 1], mv[e])
+                status[e].update(done=r["done"], draw=r["draw"])
+                if r["winner"] >= 0:
+                    status[e]["winner"] = r["winner"]
+        return ([s["done"] for s in status], [s["winner"] for s in status], [s["draw"] for s in status])
+    _replay_env_games(step_all)

@@ -175,6 +175,67 @@ def test_single_state_drop_in_and_status_api(hip_lib, oracle):
         env.snapshot()  # current state becomes the restart point, status cleared there
 
 
+def test_one_state_path_random_play_rejection_and_env_bookkeeping(hip_lib, oracle):
+    """pom_step / pom_env_step (one pinned State, one launch): stress play with arbitrary Move values against the oracle every
+    tick, UB flags included; a State the record cannot hold is refused and left alone; max_steps ends a game."""
+    from pomcpp_amd.batch import step_one, env_step_one
+    rng = np.random.default_rng(11)
+    for kind, seed in (("stress", 3), ("ffa", 5), ("stress", 8)):
+        s = pa.make_boards(1, seed=seed, kind=kind)
+        ref = s.copy()
+        status = dict(done=0, winner=-1, draw=0)
+        for t in range(150):
+            mv = rng.integers(-1, 8, size=4, dtype=np.int32) if t % 7 == 0 else rng.integers(0, 6, size=4, dtype=np.int32)
+            if status["done"]:
+                break
+            r = env_step_one(s, mv)
+            ub = oracle.env_step(ref, mv, status)
+            assert _digest(s) == _digest(ref), (kind, t)
+            assert (r["done"], r["draw"], r["ubflags"]) == (status["done"], status["draw"], ub), (kind, t)
+            assert r["winner"] == (status["winner"] if status["done"] and not status["draw"] and r["winner"] >= 0 else -1)
+    # RAW: the bare Step never touches timeStep
+    s = pa.make_boards(1, seed=9, kind="stress")
+    ref = s.copy()
+    for t in range(60):
+        mv = rng.integers(0, 6, size=4, dtype=np.int32)
+        step_one(s, mv)
+        oracle.step(ref, mv)
+        assert _digest(s) == _digest(ref), t
+    assert int(s["timeStep"][0]) == 0
+    # refused, not altered — every kind of field the record cannot hold
+    def spoil(k):
+        bad = pa.make_boards(1, seed=2)
+        if k == 0:
+            bad["board"][0, 4, 4] = 12345678
+        elif k == 1:
+            bad["aliveAgents"][0] = 1000
+        elif k == 2:
+            bad["bombs_count"][0] = 21
+        elif k == 3:
+            bad["flames_queue"]["strength"][0, 17] = 300  # a stale slot: checked as well
+        elif k == 4:
+            bad["agents"]["x"][0, 2] = 11
+        elif k == 5:  # a live bomb owned by agent 7 would index agents[7]
+            bad["bombs_queue"][0, 0] = 3 | (3 << 4) | (7 << 8) | (2 << 12) | (9 << 16)
+            bad["bombs_count"][0] = 1
+        return bad
+    for k in range(6):
+        bad = spoil(k)
+        before = bad.copy()
+        with pytest.raises(PomError) as e:
+            step_one(bad, np.zeros(4, dtype=np.int32))
+        assert e.value.code == 3 and bad.tobytes() == before.tobytes(), k
+        with BatchEnvironment(1, mode=MODE_RAW) as env:  # the batch path refuses the same States
+            with pytest.raises(PomError):
+                env.make_game(before)
+    # the step cap
+    s = pa.make_boards(1, seed=1)
+    for t in range(5):
+        r = env_step_one(s, np.zeros(4, dtype=np.int32), max_steps=5)
+        assert r["done"] == (1 if t == 4 else 0) and r["winner"] == -1 and r["draw"] == 0
+    assert int(s["timeStep"][0]) == 5
+
+
 @pytest.mark.parametrize("epw,lpe", [(16, 4), (16, 1), (32, 1), (64, 1)])
 @pytest.mark.parametrize("kind,dist", [("ffa", DIST_RANDOM), ("stress", DIST_STRESS)])
 def test_every_kernel_variant_matches_oracle(hip_lib, oracle, epw, lpe, kind, dist):
