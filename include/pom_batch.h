@@ -77,7 +77,7 @@ typedef struct PomBatchOptions {
     int32_t reserved_;
 } PomBatchOptions;
 
-/* PomBatchOptions.issue_mode (environment POM_ISSUE = direct | threads | graph overrides it).  Measured per step at 65,536
+/* PomBatchOptions.issue_mode (environment POM_ISSUE = direct | threads | graph | chain overrides it).  Measured per step at 65,536
  * envs, 20-tick call from an idle device / 500-tick call: THREADS 18.0 / 15.5 us; DIRECT 17.2 .. 26.4 (host-dependent) /
  * 15.6 - 16.0 us; GRAPH 21.4 .. 23.5 / 16.1 us (pomcpp_amd/csrc/pom_runtime.h, profiles/r03_issue_modes.txt) */
 enum {
@@ -85,7 +85,11 @@ enum {
     POM_ISSUE_DIRECT = 1,  /* the calling thread issues every launch; the library owns no thread */
     POM_ISSUE_THREADS = 2, /* one helper thread per internal sub-stream issues that stream's launches (created on first use, joined by
                               pom_batch_destroy; a helper that cannot be started falls back to DIRECT for its part) */
-    POM_ISSUE_GRAPH = 3    /* chunks of 20 ticks replayed as HIP graphs, one per sub-stream; no library-owned thread */
+    POM_ISSUE_GRAPH = 3,   /* chunks of 20 ticks replayed as HIP graphs, one per sub-stream; no library-owned thread */
+    POM_ISSUE_CHAIN = 4    /* one launch per tick over the whole batch, on a queue of the library's own whose packets do not wait for
+                              each other: a tile's tick waits for the same tile's previous tick only (pomcpp_amd/csrc/pom_chain.h).
+                              A several-tick call BLOCKS until its ticks are done (HIP streams know nothing of that queue).  For the
+                              replay / no-policy shape; where it cannot be had the launches are issued as with POM_ISSUE_THREADS */
 };
 
 enum { POM_RESET_OFF = 0, POM_RESET_AT_START = 1, POM_RESET_AT_END = 2 };

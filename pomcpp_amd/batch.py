@@ -29,7 +29,7 @@ MODE_RAW, MODE_ENV = 0, 1
 RESET_OFF, RESET_AT_START, RESET_AT_END = 0, 1, 2  # PomBatchOptions.auto_reset (True = RESET_AT_START)
 DIST_HARMLESS, DIST_RANDOM, DIST_STRESS = 0, 1, 2
 CNT_STEPS, CNT_EPISODES, CNT_RESETS, CNT_UB_TICKS = 0, 1, 2, 3
-ISSUE_AUTO, ISSUE_DIRECT, ISSUE_THREADS, ISSUE_GRAPH = 0, 1, 2, 3  # PomBatchOptions.issue_mode
+ISSUE_AUTO, ISSUE_DIRECT, ISSUE_THREADS, ISSUE_GRAPH, ISSUE_CHAIN = 0, 1, 2, 3, 4  # PomBatchOptions.issue_mode
 UB_LOST_AGENT, UB_NULL_BOMB, UB_QUEUE_OVERFLOW, UB_REVERT_LOOP, UB_BAD_INDEX = 1, 2, 4, 8, 16
 
 

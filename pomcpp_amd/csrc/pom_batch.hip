@@ -22,6 +22,7 @@ int pom_batch_destroy(PomBatch* h)
 {
     if (!h) return POM_E_ARG;
     stop_issuers(h);
+    chain_destroy(&h->chain);
     (void)hipSetDevice(h->device);
     for (int k = 0; k < PomBatch::MAX_PARTS; k++)
         if (h->sub[k]) (void)hipStreamSynchronize(h->sub[k]);
@@ -140,7 +141,7 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
     h->fuse_policy = true;
     if (const char* ev = getenv("POM_FUSE")) h->fuse_policy = atoi(ev) != 0;
     if (const char* ev = getenv("POM_MAIN_PART")) h->main_part = atoi(ev) != 0;
-    if (o.issue_mode < POM_ISSUE_AUTO || o.issue_mode > POM_ISSUE_GRAPH) {
+    if (o.issue_mode < POM_ISSUE_AUTO || o.issue_mode > POM_ISSUE_CHAIN) {
         snprintf(g_err, sizeof g_err, "pom_batch_create: issue_mode must be one of POM_ISSUE_*");
         delete h;
         return POM_E_ARG;
@@ -150,6 +151,7 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
         if (!strcmp(ev, "direct")) h->issue_mode = POM_ISSUE_DIRECT;
         else if (!strcmp(ev, "threads")) h->issue_mode = POM_ISSUE_THREADS;
         else if (!strcmp(ev, "graph")) h->issue_mode = POM_ISSUE_GRAPH;
+        else if (!strcmp(ev, "chain")) h->issue_mode = POM_ISSUE_CHAIN;
     }
     if (const char* ev = getenv("POM_STREAMS")) {
         const int v = atoi(ev);
@@ -270,6 +272,7 @@ int pom_batch_download(PomBatch* h, void* states, int64_t first, int64_t count)
     if (rc || !states) return rc ? rc : POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     if (int jr = join_parts(h)) return jr;
+    if (int vr = chain_verify(h)) return vr;
     for (int64_t off = 0; off < count; off += h->staging_envs) {
         const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
         HIPCHK(hipMemsetAsync(h->staging, 0, (size_t)c * POM_STATE_BYTES, h->stream));
@@ -279,7 +282,7 @@ int pom_batch_download(PomBatch* h, void* states, int64_t first, int64_t count)
                               h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
-    return POM_OK;
+    return chain_check(h);
 }
 
 int pom_batch_snapshot(PomBatch* h)
@@ -421,7 +424,7 @@ int pom_batch_counters(PomBatch* h, int64_t out[POM_CNT_N])
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(out, h->totals_dev, POM_CNT_N * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    return POM_OK;
+    return chain_check(h);
 }
 
 int pom_batch_reset_counters(PomBatch* h)
@@ -438,8 +441,9 @@ int pom_batch_sync(PomBatch* h)
     if (!h) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     if (int jr = join_parts(h)) return jr;
+    if (int vr = chain_verify(h)) return vr;
     HIPCHK(hipStreamSynchronize(h->stream));
-    return POM_OK;
+    return chain_check(h);
 }
 
 int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_agent, int32_t* agent_attrs_dev,
@@ -520,6 +524,18 @@ int pom_batch_device_view(PomBatch* h, void** base, int64_t* n_pad, int32_t* rec
     return POM_OK;
 }
 
+#if defined(POM_CHAIN_DIAG)
+/* diagnostic build only: per tile 4 sums over the chained launches so far (cycles to the ticket, cycles polling, cycles in all, polls); cleared */
+int pom_chain_diag_read(PomBatch* h, unsigned long long* out, int64_t tiles)
+{
+    if (!h || !h->chain.tile_seq || tiles != h->n_pad / h->epw) return POM_E_ARG;
+    if (int jr = join_parts(h)) return jr;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->chain.tile_seq + tiles, (size_t)tiles * 160, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->chain.tile_seq + tiles, 0, (size_t)tiles * 160));
+    return POM_OK;
+}
+#endif
 #if defined(POM_DIAG)
 /* diagnostic build only: the step kernel with zero ticks = HBM -> LDS -> HBM round trip of every record */
 int pom_diag_copy_only(PomBatch* h)
@@ -661,7 +677,7 @@ int pom_batch_fork(PomBatch* h)
             h->issuers[k]->posted.fetch_add(1, std::memory_order_release);
             h->issuers[k]->cv.notify_all();
         }
-    return fork_parts(h);
+    return fork_parts(h, 0);
 }
 
 int pom_batch_flush(PomBatch* h)
@@ -705,7 +721,7 @@ int pom_batch_launch_shape(PomBatch* h, int32_t* envs_per_wave, int32_t* lanes_p
     if (!h) return POM_E_ARG;
     if (envs_per_wave) *envs_per_wave = h->epw;
     if (lanes_per_env) *lanes_per_env = h->quad ? 4 : 1;
-    if (launches_per_step) *launches_per_step = h->parts;
+    if (launches_per_step) *launches_per_step = (h->issue_mode == POM_ISSUE_CHAIN && h->chain.ok) ? 1 : h->parts; /* chained: one launch over all tiles per tick */
     return POM_OK;
 }
 

@@ -119,6 +119,13 @@ struct StepParams {
     uint32_t* episode;   /* games started so far per env (fresh boards: keys the next board) */
     uint64_t board_seed;
     int32_t fresh;       /* a restarting env gets the next board of pom_boardgen.h instead of its snapshot */
+    /* CHAIN instantiation (pom_chain.h): launches of one queue that do NOT wait for each other — a tile's tick waits for the
+     * same tile's previous tick instead.  Per tile one 64-bit word: bits 63..36 visits begun (tickets), 35..32 1 + the XCD
+     * that stored the tile last (0: none yet), 27..0 visits stored.  The j-th visitor of a tile plays tick tick0 + (j - chain_seq0)
+     * once the word says j visits are stored; which launch a visitor belongs to does not matter. */
+    unsigned long long* tile_seq;
+    uint32_t* chain_err; /* host-visible; bit 0: a wavefront gave up waiting, bit 1: a tile changed its XCD (its L2) */
+    uint32_t chain_seq0;
 #if defined(POM_DIAG)
     long long* diag; /* POM_PH_N accumulators per wavefront, diagnostic build only */
 #endif
@@ -229,7 +236,8 @@ __device__ __forceinline__ void store_tile(uint32_t* col, int64_t np, const uint
  * = 64 contiguous bytes in HBM and in LDS, so lane l takes envs 4(l%4)..+3 of row r0 + l/4 and one instruction covers 16 rows:
  * 7 instead of 28 per direction.  `base` = the tile's first dword, np = the row stride: with the buffers laid out tile by tile
  * (pom_packed.h) np = 16 and an instruction moves 1,024 contiguous bytes. */
-template <int ROWS = POM_REC_DWORDS>
+/* AUX: the instruction's cache policy bits (16 = sc1: served by the L2, never by this CU's vector cache) */
+template <int ROWS = POM_REC_DWORDS, int AUX = 0>
 __device__ __forceinline__ void load_tile16_x4(const uint32_t* base, int64_t np, uint32_t* tile, int lane)
 {
     static_assert(ROWS % 16 == 0 && ROWS <= POM_REC_DWORDS, "whole instructions, inside the record");
@@ -238,7 +246,7 @@ __device__ __forceinline__ void load_tile16_x4(const uint32_t* base, int64_t np,
 #pragma unroll
     for (int r0 = 0; r0 < ROWS; r0 += 16) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(tile + r0 * 16), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(tile + r0 * 16), 16, 0, AUX);
         g += stride;
     }
 }
@@ -514,9 +522,18 @@ __device__ __forceinline__ int pom_policy_wave(Store& st, const PomPolicyEnv& E,
  * record load per tick instead of two and no Move[4] round trip (pom_batch_step_simple). */
 /* SINGLE: the launch plays exactly one tick (p.ticks == 1: every launch of the bench, of an RL loop, of the explicit-move
  * steps) — an instantiation without the tick loop, so that nothing is kept alive "for the next tick". */
-template <int EPW, int G, bool FRESH, bool POLICY = false, bool ATEND = false, bool SINGLE = false>
+/* CHAIN: a launch of a queue without barriers between its packets (pom_chain.h): the wavefront first waits until its tile's
+ * previous tick has been stored (StepParams.tile_seq), fetches the record past the vector cache, and publishes the tile when
+ * its own stores have arrived.  A launch then no longer lasts as long as its slowest wavefront: the next launch's
+ * wavefronts start on the tiles that are ready. */
+extern "C" __device__ uint64_t pom_dispatch_id(void) __asm("llvm.amdgcn.dispatch.id"); /* the AQL packet's index in its queue */
+enum { POM_CHAIN_SPIN_LIMIT = 400000 }; /* polls of ~0.3 us before a wavefront gives up (it must never hang the device) */
+enum { POM_CHAIN_TICKET_SHIFT = 36, POM_CHAIN_COUNT_MASK = 0x0FFFFFFF };
+
+template <int EPW, int G, bool FRESH, bool POLICY = false, bool ATEND = false, bool SINGLE = false, bool CHAIN = false>
 __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW == 32 ? 2 : 1)) void pom_step_kernel(StepParams p)
 {
+    static_assert(!CHAIN || (SINGLE && !FRESH && !POLICY && !ATEND), "chained launches: the one-tick replay kernel");
     static_assert(!SINGLE || G == 4, "the one-tick instantiation exists for the quad shape");
     static_assert(G == 1 || (G == 4 && EPW == 16), "a quad per env needs 16 envs per wavefront");
     static_assert(!POLICY || G == 4, "the policy runs one agent per lane of the quad");
@@ -537,6 +554,21 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
      * second touch of a line became an L2 hit instead of a second HBM fetch; with a tile contiguous in memory (round 3) it
      * keeps an XCD's traffic in one region of memory. */
     int64_t tile_local;
+    uint32_t chain_xcd = 0;
+    if (CHAIN) {
+        /* the XCD the workgroup IS on decides its tile (launches of different queues start their round-robin at different
+         * XCDs): XCD x plays tiles x * q .. x * q + q - 1, its k-th workgroup (workgroup ids x0, x0 + 8, ...) the k-th of them.
+         * The grid is padded to a multiple of 8 workgroups. */
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(chain_xcd));
+        chain_xcd &= 0xFu;
+        const int64_t q = gridDim.x / 8;
+        tile_local = (int64_t)chain_xcd * q + blockIdx.x / 8;
+        if (chain_xcd >= 8u) { /* not the machine this was written for: nothing is stepped */
+            if (lane == 0) atomicOr(p.chain_err, 2u);
+            return;
+        }
+        if (POM_WPB == 1 && p.block0 + tile_local >= p.block_end) return; /* a workgroup of the padding */
+    } else {
 #if defined(POM_NO_XCD_REMAP)
     tile_local = blockIdx.x;
 #else
@@ -545,6 +577,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         tile_local = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
     }
 #endif
+    }
     if (POM_WPB > 1) {
         tile_local = tile_local * POM_WPB + (threadIdx.x >> 6);
         if (p.block0 + tile_local >= p.block_end) return; /* the last workgroup of a launch may be short of tiles */
@@ -572,8 +605,50 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     long long c_steps = 0, c_episodes = 0, c_resets = 0, c_ub = 0;
 
     /* the launch's first tick: asked for BEFORE the record, so that waiting for it (in-order vmcnt) does not wait for the record */
-    const uint32_t tick0 = p.tick0 + *p.tick_base;
-    if (EPW == 16) load_tile16_x4(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane); /* 16-byte pieces, 7 instructions of 1 KB */
+    uint32_t tick0 = p.tick0 + *p.tick_base;
+    unsigned long long chain_done = 0; /* what this wavefront adds to the tile's word when its stores have arrived */
+#if defined(POM_CHAIN_DIAG)
+    long long chain_t0 = 0, chain_t1 = 0, chain_t2 = 0, chain_rt0 = 0;
+    int chain_polls = 0;
+    uint32_t chain_visit = 0;
+#endif
+    if (CHAIN) {
+        const uint32_t xcd = chain_xcd + 1u;
+#if defined(POM_CHAIN_DIAG)
+        chain_t0 = (long long)__builtin_readcyclecounter();
+        chain_rt0 = (long long)wall_clock64();
+#endif
+        /* take a ticket: the old value says which visit of the tile this is — and, mostly, that the visit before it is stored */
+        unsigned long long w = 0;
+        if (lane == 0) w = __hip_atomic_fetch_add(p.tile_seq + tile_id, 1ull << POM_CHAIN_TICKET_SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
+        const uint32_t visit = (uint32_t)(w >> POM_CHAIN_TICKET_SHIFT);
+        tick0 += (visit - p.chain_seq0) & POM_CHAIN_COUNT_MASK;
+#if defined(POM_CHAIN_DIAG)
+        chain_t1 = (long long)__builtin_readcyclecounter();
+#endif
+        int polls = 0;
+        while (((uint32_t)w & POM_CHAIN_COUNT_MASK) != visit && ++polls <= POM_CHAIN_SPIN_LIMIT) { /* wave-uniform */
+            __builtin_amdgcn_s_sleep(1);
+            w = __hip_atomic_load(p.tile_seq + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint32_t was_on = (uint32_t)(w >> 32) & 0xFu;
+        const bool gave_up = ((uint32_t)w & POM_CHAIN_COUNT_MASK) != visit;
+        if (gave_up || (was_on != 0u && was_on != xcd)) {
+            /* the visit before this one never arrived, or it was stored through another XCD's L2: nothing is stepped, the
+             * host finds the flag and reports the call as failed.  (The tile's word is left as it is: later visitors give up too.) */
+            if (lane == 0) atomicOr(p.chain_err, gave_up ? 1u : 2u);
+            return;
+        }
+#if defined(POM_CHAIN_DIAG)
+        chain_t2 = (long long)__builtin_readcyclecounter();
+        chain_polls = polls;
+        chain_visit = visit;
+#endif
+        chain_done = 1ull + ((unsigned long long)(xcd - was_on) << 32);
+        /* the loads below are issued after the word has been seen: the record they fetch is the stored one */
+        load_tile16_x4<POM_REC_DWORDS, 16>(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane);
+    } else if (EPW == 16) load_tile16_x4(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane); /* 16-byte pieces, 7 instructions of 1 KB */
     else load_tile<EPW>(col_d, POM_TILE_ENVS, tile, sub);
     uint32_t m0 = 0, m1 = 0; /* POLICY: this lane's agent's memory */
     if (POLICY) {
@@ -828,6 +903,21 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     } else {
         store_tile<EPW>(col_d, POM_TILE_ENVS, tile, sub, el);
     }
+    if (CHAIN) { /* the record's stores have been acknowledged by the L2 before the word that hands the tile on is written */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(p.tile_seq + tile_id, chain_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(POM_CHAIN_DIAG)
+        if (lane == 0) { /* per tile, summed over launches: cycles to the ticket, cycles polling, cycles in all, polls */
+            unsigned long long* d = p.tile_seq + (p.block_end - p.block0) + 20 * tile_id;
+            d[4 + 2 * (chain_visit & 7)] = (unsigned long long)chain_rt0; /* the last 8 visits: start and end on the 100 MHz clock */
+            d[5 + 2 * (chain_visit & 7)] = (unsigned long long)wall_clock64();
+            d[0] += (unsigned long long)(chain_t1 - chain_t0);
+            d[1] += (unsigned long long)(chain_t2 - chain_t1);
+            d[2] += (unsigned long long)((long long)__builtin_readcyclecounter() - chain_t0);
+            d[3] += (unsigned long long)chain_polls;
+        }
+#endif
+    }
 
 #if defined(POM_DIAG)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -856,6 +946,16 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         if (c_resets) __hip_atomic_fetch_add(&wc[POM_CNT_RESETS], (unsigned long long)c_resets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c_ub) __hip_atomic_fetch_add(&wc[POM_CNT_UB_TICKS], (unsigned long long)c_ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+/* chained launches, after a join: every tile must have been visited exactly `visits` times and every visit stored (a
+ * workgroup -> XCD assignment that is not the round-robin the tile choice assumes would show here) */
+__global__ void pom_chain_verify_kernel(const unsigned long long* tile_seq, int64_t tiles, uint32_t visits, uint32_t* err)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    const unsigned long long w = tile_seq[t];
+    if (((uint32_t)w & POM_CHAIN_COUNT_MASK) != visits || (uint32_t)(w >> POM_CHAIN_TICKET_SHIFT) != visits) atomicOr(err, 4u);
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 #include <thread>
 
 #include "pom_kernels.h"
+#include "pom_chain.h"
 
 static thread_local char g_err[256] = "";
 static void set_err(const char* what, hipError_t e)
@@ -68,7 +69,8 @@ struct PomBatch {
     /* how the launches of a several-tick call are issued (launch_many; PomBatchOptions.issue_mode) */
     int issue_mode = POM_ISSUE_THREADS;
     struct PomIssuer* issuers[MAX_PARTS] = {}; /* POM_ISSUE_THREADS: one helper thread per sub-stream part, created on first use */
-    bool issuers_failed = false;               /* a helper thread could not be started: the calling thread issues everything */
+    bool issuers_failed = false;
+    int last_kind = 0;                         /* what has been launched on the streams since they were forked: POM_KIND_SPLIT / _CHAIN */               /* a helper thread could not be started: the calling thread issues everything */
     /* POM_ISSUE_GRAPH: multi-tick calls replay a captured chunk of launches (launch_many): POM_GRAPH_TICKS launches of every part as one HIP
      * graph per part.  tick_words[k] is the tick part k's replay starts at, read by the graph's kernels (StepParams.tick_base;
      * set by a one-lane kernel on the part's stream in front of each replay); tick_words[MAX_PARTS] stays 0 and is what every
@@ -77,6 +79,7 @@ struct PomBatch {
     struct PomStepGraph* graphs[MAX_GRAPHS] = {};
     uint64_t graph_clock = 0;
     uint32_t* tick_words = nullptr;
+    PomChain chain;          /* POM_ISSUE_CHAIN: the queue of barrier-free launches, set up on first use (pom_chain.h) */
     bool fuse_policy = true; /* pom_batch_step_simple: policy and tick in one kernel (quad shape); POM_FUSE=0 keeps them apart */
     /* optional per-launch timing (pom_batch_profile) */
     bool profiling = false;
@@ -90,7 +93,8 @@ struct PomBatch {
 
 static void drop_graphs(PomBatch* h);
 static void stop_issuers(PomBatch* h);
-static int fork_parts(PomBatch* h);
+enum { POM_KIND_SPLIT = 1, POM_KIND_CHAIN = 2 };
+static int fork_parts(PomBatch* h, int kind = POM_KIND_SPLIT);
 static int join_parts(PomBatch* h);
 static int ensure_sub_streams(PomBatch* h, int parts);
 
@@ -115,8 +119,13 @@ static int ensure_sub_streams(PomBatch* h, int parts)
 }
 
 /* caller's stream -> sub-streams: everything already queued on the caller's stream happens before the parts */
-static int fork_parts(PomBatch* h)
+static int fork_parts(PomBatch* h, int kind)
 {
+    /* sub-batch launches (every stream its own tiles) and chained launches (every launch all tiles, pom_chain.h) must not be
+     * in flight together: going from one kind to the other joins the streams first */
+    if (h->forked && h->last_kind && kind && h->last_kind != kind)
+        if (int jr = join_parts(h)) return jr;
+    if (kind) h->last_kind = kind; /* kind 0: only the fork (pom_batch_fork), no launches yet */
     if (h->parts == 1 || h->forked) return POM_OK;
     HIPCHK(hipEventRecord(h->ev_fork, h->stream));
     for (int k = h->main_part; k < h->parts; k++) HIPCHK(hipStreamWaitEvent(h->sub[k], h->ev_fork, 0));
@@ -132,6 +141,7 @@ static int join_parts(PomBatch* h)
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join[k], 0));
     }
     h->forked = false;
+    h->last_kind = 0;
     return POM_OK;
 }
 
@@ -538,11 +548,92 @@ static int launch_many_streams(PomBatch* h, const StepParams& p0, int launches, 
     return POM_OK;
 }
 
+/* POM_ISSUE_CHAIN (pom_chain.h): `launches` one-tick launches, each over the WHOLE batch, dealt round-robin to the handle's
+ * streams; the tiles' ticket words order the ticks.  *used = false: not available for this handle, nothing was launched, the
+ * caller takes the ordinary path. */
+static bool runs_chain(const PomBatch* h, bool policy, int ticks_per_launch)
+{
+    return h->issue_mode == POM_ISSUE_CHAIN && h->quad && h->parts > 1 && !policy && !runs_fresh(h) && !runs_at_end(h) && ticks_per_launch == 1 &&
+           !(h->chain.tried && !h->chain.ok);
+}
+/* the kernel's failure flags (pinned memory): looked at by every call that joins or launches */
+static int chain_check(PomBatch* h)
+{
+    PomChain* c = &h->chain;
+    if (!c->err_host) return POM_OK;
+    const uint32_t flags = *reinterpret_cast<volatile uint32_t*>(c->err_host);
+    if (!flags) return POM_OK;
+    *c->err_host = 0;
+    c->ok = false; /* no further chained launches on this handle */
+    snprintf(g_err, sizeof g_err, "a chained launch failed (%s%s%s): the batch is in an undefined state — upload again or destroy it",
+             (flags & 1u) ? "a wavefront gave up waiting for its tile" : "", (flags & 2u) ? " a tile changed its XCD" : "",
+             (flags & 4u) ? " the tiles were not visited evenly" : "");
+    return POM_E_HIP;
+}
+/* after a join, on the caller's stream: were all tiles visited equally often?  (the answer arrives with the next synchronize) */
+static int chain_verify(PomBatch* h)
+{
+    PomChain* c = &h->chain;
+    if (!c->unverified || !c->ok) return POM_OK;
+    const int64_t tiles = h->n_pad / h->epw;
+    pom_chain_verify_kernel<<<dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, h->stream>>>(c->tile_seq, tiles, c->visits, c->err_dev);
+    HIPCHK(hipGetLastError());
+    c->unverified = false;
+    return POM_OK;
+}
+static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bool* used)
+{
+    *used = false;
+    PomChain* c = &h->chain;
+    const int64_t tiles = h->n_pad / h->epw;
+    if (!chain_setup(c, tiles)) return POM_OK;
+    if (int rc = chain_check(h)) return rc;
+    if ((uint64_t)c->visits + (uint64_t)launches >= (1u << 27)) { /* the fields of the tile words must not run into each other */
+        if (int jr = join_parts(h)) return jr;
+        HIPCHK(hipMemsetAsync(c->tile_seq, 0, (size_t)tiles * 8, h->stream));
+        c->visits = 0;
+    }
+    if (int rc = fork_parts(h, POM_KIND_CHAIN)) return rc;
+    StepParams p = p0; /* the same for every launch of the call: which tick a wavefront plays follows from its ticket */
+    p.block0 = 0;
+    p.block_end = tiles;
+    p.ticks = 1;
+    p.tile_seq = c->tile_seq;
+    p.chain_err = c->err_dev;
+    p.chain_seq0 = c->visits;
+    static const PomStepKernel kernel = pom_step_kernel<16, 4, false, false, false, true, true>;
+    const dim3 grid((unsigned)(((tiles + POM_WPB - 1) / POM_WPB + 7) / 8 * 8)); /* a multiple of 8: every XCD gets as many workgroups as it has tiles */
+    for (int k = 0; k < launches; k++) {
+        const int part = (int)(c->turn++ % (uint32_t)h->parts);
+        hipStream_t st = part < h->main_part ? h->stream : h->sub[part];
+        const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
+        hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
+        StepParams q = p;
+        void* args[1] = {&q};
+        HIPCHK(hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, dim3(64 * POM_WPB), args, 0, st, ev0, ev1, 0));
+        if (prof) h->prof_n++;
+    }
+    c->visits += (uint32_t)launches;
+    c->unverified = true;
+    *used = true;
+    return POM_OK;
+}
+
 /* `launches` dispatches per part, ticks_per_launch ticks each; advances h->tick by what was queued */
 static int launch_many(PomBatch* h, uint64_t seed, int dist, int launches, int ticks_per_launch, bool policy)
 {
     static const int chunk = getenv("POM_GRAPH_TICKS") ? atoi(getenv("POM_GRAPH_TICKS")) : POM_GRAPH_TICKS;
     int done = 0;
+    if (runs_chain(h, policy, ticks_per_launch) && launches >= 1) {
+        StepParams p;
+        if (int rc = fill_params(h, p, nullptr, seed, dist, 1)) return rc;
+        bool used = false;
+        if (int rc = launch_many_chain(h, p, launches, &used)) return rc;
+        if (used) {
+            h->tick += (uint64_t)launches;
+            return POM_OK;
+        }
+    }
     if (h->issue_mode == POM_ISSUE_GRAPH && chunk >= 2 && launches >= chunk && !h->profiling) {
         StepParams p;
         memset(&p, 0, sizeof p); /* the cache compares the bytes */

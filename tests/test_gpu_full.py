@@ -305,14 +305,14 @@ def test_split_steps_over_streams_give_identical_results(hip_lib, oracle, stream
         BatchEnvironment(64, streams=9)
 
 
-@pytest.mark.parametrize("mode", ["direct", "threads", "graph"])
+@pytest.mark.parametrize("mode", ["direct", "threads", "graph", "chain"])
 @pytest.mark.parametrize("streams", [1, 3])
 def test_issue_modes_give_identical_results(hip_lib, oracle, mode, streams):
     """How the launches of a several-tick call are issued (PomBatchOptions.issue_mode: by the calling thread, by one helper thread
     per sub-stream, as replayed HIP graphs of 20 ticks) must not show in states, counters or the tick that keys the move stream —
     random play, ticks_per_launch 1 and 3, the fused SimpleAgent kernel, calls shorter and longer than a graph chunk."""
-    from pomcpp_amd.batch import ISSUE_DIRECT, ISSUE_GRAPH, ISSUE_THREADS
-    im = {"direct": ISSUE_DIRECT, "threads": ISSUE_THREADS, "graph": ISSUE_GRAPH}[mode]
+    from pomcpp_amd.batch import ISSUE_CHAIN, ISSUE_DIRECT, ISSUE_GRAPH, ISSUE_THREADS
+    im = {"direct": ISSUE_DIRECT, "threads": ISSUE_THREADS, "graph": ISSUE_GRAPH, "chain": ISSUE_CHAIN}[mode]
     n, seed = 4000, 99
     start = pa.make_boards(n, seed=12)
     want = start.copy()
