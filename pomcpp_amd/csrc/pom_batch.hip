@@ -146,7 +146,9 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
         delete h;
         return POM_E_ARG;
     }
-    h->issue_mode = o.issue_mode == POM_ISSUE_AUTO ? POM_ISSUE_THREADS : o.issue_mode;
+    /* AUTO: chained launches where they pay (measured up to 131,072 envs, even at 262,144: scripts/experiments/chain/sizes.sh)
+     * and can be had (the one-tick replay shape: pom_runtime.h runs_chain); the helper threads otherwise */
+    h->issue_mode = o.issue_mode != POM_ISSUE_AUTO ? o.issue_mode : (h->quad && h->n_pad <= 196608) ? POM_ISSUE_CHAIN : POM_ISSUE_THREADS;
     if (const char* ev = getenv("POM_ISSUE")) {
         if (!strcmp(ev, "direct")) h->issue_mode = POM_ISSUE_DIRECT;
         else if (!strcmp(ev, "threads")) h->issue_mode = POM_ISSUE_THREADS;
@@ -158,6 +160,13 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
         if (v >= 1 && v <= PomBatch::MAX_PARTS) h->parts = v;
     }
     if ((int64_t)h->parts > h->n_pad / h->epw) h->parts = (int)(h->n_pad / h->epw);
+    /* chained launches rotate over two streams unless the caller asked for a number (options / POM_STREAMS / pom_batch_set_streams:
+     * then that many; one stream = launches in a row, nothing to chain) */
+    h->chain_parts = (o.streams >= 1 || getenv("POM_STREAMS")) ? h->parts : 2;
+    if (const char* ev = getenv("POM_CHAIN_STREAMS")) {
+        const int v = atoi(ev);
+        if (v >= 1 && v <= PomBatch::MAX_PARTS) h->chain_parts = v;
+    }
     if (o.auto_reset == POM_RESET_AT_END && !h->quad) {
         snprintf(g_err, sizeof g_err, "pom_batch_create: auto_reset = POM_RESET_AT_END is built for the default kernel shape "
                  "(envs_per_wave 16, lanes_per_env 4) only");
@@ -191,7 +200,7 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
         }
         h->own_stream = true;
     }
-    if (ensure_sub_streams(h, h->parts) != POM_OK) {
+    if (ensure_sub_streams(h, h->parts > h->chain_parts ? h->parts : h->chain_parts) != POM_OK) {
         pom_batch_destroy(h);
         return POM_E_HIP;
     }
@@ -596,8 +605,9 @@ int pom_batch_set_streams(PomBatch* h, int32_t streams)
     if (int jr = join_parts(h)) return jr;
     const int64_t tiles = h->n_pad / h->epw;
     const int want = (int64_t)streams > tiles ? (int)tiles : streams;
-    if (int er = ensure_sub_streams(h, want)) return er;
+    if (int er = ensure_sub_streams(h, streams)) return er;
     h->parts = want;
+    h->chain_parts = streams; /* chained launches cover all tiles: their stream count is not bounded by the tiles */
     return POM_OK;
 }
 

@@ -47,8 +47,9 @@ static void chain_destroy(PomChain* c)
     *c = PomChain();
 }
 
-/* the tile words and the flag page, on first use; false: not to be had (the caller launches the ordinary way) */
-static bool chain_setup(PomChain* c, int64_t tiles)
+/* the tile words (zeroed on `stream`, which the chained launches' streams are forked from) and the flag page, on first use;
+ * false: not to be had (the caller launches the ordinary way) */
+static bool chain_setup(PomChain* c, int64_t tiles, hipStream_t stream)
 {
     if (c->tried) return c->ok;
     c->tried = true;
@@ -57,7 +58,8 @@ static bool chain_setup(PomChain* c, int64_t tiles)
 #else
     const size_t words = (size_t)tiles;
 #endif
-    if (hipMalloc((void**)&c->tile_seq, words * 8) != hipSuccess || hipMemset(c->tile_seq, 0, words * 8) != hipSuccess ||
+    if (hipMalloc((void**)&c->tile_seq, words * 8) != hipSuccess ||
+        hipMemsetAsync(c->tile_seq, 0, words * 8, stream) != hipSuccess || /* on the handle's stream: the fork orders the launches behind it */
         hipHostMalloc((void**)&c->err_host, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void**)&c->err_dev, c->err_host, 0) != hipSuccess) {
         (void)hipGetLastError();

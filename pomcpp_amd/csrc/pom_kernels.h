@@ -623,7 +623,9 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         if (lane == 0) w = __hip_atomic_fetch_add(p.tile_seq + tile_id, 1ull << POM_CHAIN_TICKET_SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
         const uint32_t visit = (uint32_t)(w >> POM_CHAIN_TICKET_SHIFT);
-        tick0 += (visit - p.chain_seq0) & POM_CHAIN_COUNT_MASK;
+        /* which tick: the call's first tick + how far this visit is from the call's first visit — a signed distance: launches of
+         * two calls may be in flight together, and a wavefront of the later call can draw a ticket of the earlier one */
+        tick0 += (uint32_t)((int32_t)((visit - p.chain_seq0) << 4) >> 4);
 #if defined(POM_CHAIN_DIAG)
         chain_t1 = (long long)__builtin_readcyclecounter();
 #endif

@@ -79,7 +79,8 @@ struct PomBatch {
     struct PomStepGraph* graphs[MAX_GRAPHS] = {};
     uint64_t graph_clock = 0;
     uint32_t* tick_words = nullptr;
-    PomChain chain;          /* POM_ISSUE_CHAIN: the queue of barrier-free launches, set up on first use (pom_chain.h) */
+    PomChain chain;          /* POM_ISSUE_CHAIN: the tiles' ticket words, set up on first use (pom_chain.h) */
+    int chain_parts = 2;     /* ... and how many streams the chained launches rotate over (2 measured best up to 131,072 envs) */
     bool fuse_policy = true; /* pom_batch_step_simple: policy and tick in one kernel (quad shape); POM_FUSE=0 keeps them apart */
     /* optional per-launch timing (pom_batch_profile) */
     bool profiling = false;
@@ -107,6 +108,12 @@ static int check_range(const PomBatch* h, int64_t first, int64_t count)
     return POM_OK;
 }
 
+/* the streams a fork / join has to cover: the sub-batch parts, or the streams chained launches rotate over */
+static int live_streams(const PomBatch* h)
+{
+    return (h->issue_mode == POM_ISSUE_CHAIN && h->chain_parts > h->parts) ? h->chain_parts : h->parts;
+}
+
 static int ensure_sub_streams(PomBatch* h, int parts)
 {
     if (parts <= 1) return POM_OK;
@@ -126,17 +133,19 @@ static int fork_parts(PomBatch* h, int kind)
     if (h->forked && h->last_kind && kind && h->last_kind != kind)
         if (int jr = join_parts(h)) return jr;
     if (kind) h->last_kind = kind; /* kind 0: only the fork (pom_batch_fork), no launches yet */
-    if (h->parts == 1 || h->forked) return POM_OK;
+    const int live = live_streams(h);
+    if (live == 1 || h->forked) return POM_OK;
     HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-    for (int k = h->main_part; k < h->parts; k++) HIPCHK(hipStreamWaitEvent(h->sub[k], h->ev_fork, 0));
+    for (int k = h->main_part; k < live; k++) HIPCHK(hipStreamWaitEvent(h->sub[k], h->ev_fork, 0));
     h->forked = true;
     return POM_OK;
 }
 /* sub-streams -> caller's stream: whatever is queued on the caller's stream next sees all parts finished */
 static int join_parts(PomBatch* h)
 {
-    if (h->parts == 1 || !h->forked) return POM_OK;
-    for (int k = h->main_part; k < h->parts; k++) {
+    const int live = live_streams(h);
+    if (live == 1 || !h->forked) return POM_OK;
+    for (int k = h->main_part; k < live; k++) {
         HIPCHK(hipEventRecord(h->ev_join[k], h->sub[k]));
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join[k], 0));
     }
@@ -553,7 +562,7 @@ static int launch_many_streams(PomBatch* h, const StepParams& p0, int launches, 
  * caller takes the ordinary path. */
 static bool runs_chain(const PomBatch* h, bool policy, int ticks_per_launch)
 {
-    return h->issue_mode == POM_ISSUE_CHAIN && h->quad && h->parts > 1 && !policy && !runs_fresh(h) && !runs_at_end(h) && ticks_per_launch == 1 &&
+    return h->issue_mode == POM_ISSUE_CHAIN && h->quad && h->chain_parts > 1 && !policy && !runs_fresh(h) && !runs_at_end(h) && ticks_per_launch == 1 &&
            !(h->chain.tried && !h->chain.ok);
 }
 /* the kernel's failure flags (pinned memory): looked at by every call that joins or launches */
@@ -586,7 +595,10 @@ static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bo
     *used = false;
     PomChain* c = &h->chain;
     const int64_t tiles = h->n_pad / h->epw;
-    if (!chain_setup(c, tiles)) return POM_OK;
+    if (!c->tried) { /* the words are zeroed on the caller's stream: the sub-streams must be forked after that, not before */
+        if (int jr = join_parts(h)) return jr;
+    }
+    if (!chain_setup(c, tiles, h->stream)) return POM_OK;
     if (int rc = chain_check(h)) return rc;
     if ((uint64_t)c->visits + (uint64_t)launches >= (1u << 27)) { /* the fields of the tile words must not run into each other */
         if (int jr = join_parts(h)) return jr;
@@ -604,7 +616,7 @@ static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bo
     static const PomStepKernel kernel = pom_step_kernel<16, 4, false, false, false, true, true>;
     const dim3 grid((unsigned)(((tiles + POM_WPB - 1) / POM_WPB + 7) / 8 * 8)); /* a multiple of 8: every XCD gets as many workgroups as it has tiles */
     for (int k = 0; k < launches; k++) {
-        const int part = (int)(c->turn++ % (uint32_t)h->parts);
+        const int part = (int)(c->turn++ % (uint32_t)h->chain_parts);
         hipStream_t st = part < h->main_part ? h->stream : h->sub[part];
         const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
         hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
@@ -668,7 +680,8 @@ static int launch_many(PomBatch* h, uint64_t seed, int dist, int launches, int t
     }
     StepParams p;
     if (int rc = fill_params(h, p, nullptr, seed, dist, ticks_per_launch)) return rc;
-    const bool threads = h->issue_mode == POM_ISSUE_THREADS && h->parts > 1 && launches - done >= 2;
+    /* (a handle of chained launches issues what cannot be chained — policy, fresh boards, several ticks per launch — with the helper threads) */
+    const bool threads = (h->issue_mode == POM_ISSUE_THREADS || h->issue_mode == POM_ISSUE_CHAIN) && h->parts > 1 && launches - done >= 2;
     if (int rc = launch_many_streams(h, p, launches - done, ticks_per_launch, policy, threads)) return rc;
     h->tick += (uint64_t)(launches - done) * (uint64_t)ticks_per_launch;
     return POM_OK;
