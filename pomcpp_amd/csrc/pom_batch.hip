@@ -200,7 +200,7 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
         }
         h->own_stream = true;
     }
-    if (ensure_sub_streams(h, h->parts > h->chain_parts ? h->parts : h->chain_parts) != POM_OK) {
+    if (ensure_sub_streams(h, streams_for(h, 0)) != POM_OK) { /* what its usual launches need; the rest when first needed */
         pom_batch_destroy(h);
         return POM_E_HIP;
     }

@@ -63,6 +63,7 @@ struct PomBatch {
     hipStream_t sub[MAX_PARTS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS] = {};
     bool forked = false;
+    int forked_n = 0; /* how many streams (indices below it) the fork covers */
     int main_part = 1; /* part 0 of a split step runs on the caller's stream itself, parts 1.. on sub-streams: one stream
                           fewer for the same overlap (3 parts: 21.2 -> 20.6 us per step at 65,536 envs); POM_MAIN_PART=0: all
                           parts on sub-streams */
@@ -108,12 +109,6 @@ static int check_range(const PomBatch* h, int64_t first, int64_t count)
     return POM_OK;
 }
 
-/* the streams a fork / join has to cover: the sub-batch parts, or the streams chained launches rotate over */
-static int live_streams(const PomBatch* h)
-{
-    return (h->issue_mode == POM_ISSUE_CHAIN && h->chain_parts > h->parts) ? h->chain_parts : h->parts;
-}
-
 static int ensure_sub_streams(PomBatch* h, int parts)
 {
     if (parts <= 1) return POM_OK;
@@ -125,31 +120,45 @@ static int ensure_sub_streams(PomBatch* h, int parts)
     return POM_OK;
 }
 
-/* caller's stream -> sub-streams: everything already queued on the caller's stream happens before the parts */
+static bool runs_fresh(const PomBatch* h);
+static bool runs_at_end(const PomBatch* h);
+/* how many streams launches of a kind use: the sub-batch parts, or the streams chained launches rotate over (kind 0: what the
+ * handle's several-tick calls will mostly be) */
+static int streams_for(const PomBatch* h, int kind)
+{
+    const bool chains = h->issue_mode == POM_ISSUE_CHAIN && h->quad && !runs_fresh(h) && !runs_at_end(h) && h->chain_parts > 1;
+    return kind == POM_KIND_CHAIN || (kind == 0 && chains) ? h->chain_parts : h->parts;
+}
+
+/* caller's stream -> sub-streams: everything already queued on the caller's stream happens before the parts.  Streams are
+ * created when a kind of launch first needs them (a process has few hardware queues: a handle should not hold streams it never
+ * uses); pom_batch_create and pom_batch_fork create what the handle's usual launches need. */
 static int fork_parts(PomBatch* h, int kind)
 {
     /* sub-batch launches (every stream its own tiles) and chained launches (every launch all tiles, pom_chain.h) must not be
      * in flight together: going from one kind to the other joins the streams first */
-    if (h->forked && h->last_kind && kind && h->last_kind != kind)
+    const int need = streams_for(h, kind);
+    if (h->forked && ((h->last_kind && kind && h->last_kind != kind) || need > h->forked_n))
         if (int jr = join_parts(h)) return jr;
     if (kind) h->last_kind = kind; /* kind 0: only the fork (pom_batch_fork), no launches yet */
-    const int live = live_streams(h);
-    if (live == 1 || h->forked) return POM_OK;
+    if (need == 1 || h->forked) return POM_OK;
+    if (int er = ensure_sub_streams(h, need)) return er;
     HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-    for (int k = h->main_part; k < live; k++) HIPCHK(hipStreamWaitEvent(h->sub[k], h->ev_fork, 0));
+    for (int k = h->main_part; k < need; k++) HIPCHK(hipStreamWaitEvent(h->sub[k], h->ev_fork, 0));
     h->forked = true;
+    h->forked_n = need;
     return POM_OK;
 }
 /* sub-streams -> caller's stream: whatever is queued on the caller's stream next sees all parts finished */
 static int join_parts(PomBatch* h)
 {
-    const int live = live_streams(h);
-    if (live == 1 || !h->forked) return POM_OK;
-    for (int k = h->main_part; k < live; k++) {
+    if (!h->forked) return POM_OK;
+    for (int k = h->main_part; k < h->forked_n; k++) {
         HIPCHK(hipEventRecord(h->ev_join[k], h->sub[k]));
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join[k], 0));
     }
     h->forked = false;
+    h->forked_n = 0;
     h->last_kind = 0;
     return POM_OK;
 }
