@@ -530,10 +530,17 @@ extern "C" __device__ uint64_t pom_dispatch_id(void) __asm("llvm.amdgcn.dispatch
 enum { POM_CHAIN_SPIN_LIMIT = 400000 }; /* polls of ~0.3 us before a wavefront gives up (it must never hang the device) */
 enum { POM_CHAIN_TICKET_SHIFT = 36, POM_CHAIN_COUNT_MASK = 0x0FFFFFFF };
 
+/* a dword that a wavefront of an earlier, still unfinished launch may have written (chained launches): past this CU's vector cache */
+template <bool CHAIN>
+__device__ __forceinline__ uint32_t pom_load_shared(const uint32_t* ptr)
+{
+    return CHAIN ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
+}
+
 template <int EPW, int G, bool FRESH, bool POLICY = false, bool ATEND = false, bool SINGLE = false, bool CHAIN = false>
 __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW == 32 ? 2 : 1)) void pom_step_kernel(StepParams p)
 {
-    static_assert(!CHAIN || (SINGLE && !FRESH && !POLICY && !ATEND), "chained launches: the one-tick replay kernel");
+    static_assert(!CHAIN || SINGLE, "chained launches play one tick each");
     static_assert(!SINGLE || G == 4, "the one-tick instantiation exists for the quad shape");
     static_assert(G == 1 || (G == 4 && EPW == 16), "a quad per env needs 16 envs per wavefront");
     static_assert(!POLICY || G == 4, "the policy runs one agent per lane of the quad");
@@ -654,8 +661,8 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     else load_tile<EPW>(col_d, POM_TILE_ENVS, tile, sub);
     uint32_t m0 = 0, m1 = 0; /* POLICY: this lane's agent's memory */
     if (POLICY) {
-        m0 = p.agent_mem[tile_id * 64 + lane];
-        m1 = p.agent_mem[4 * np + tile_id * 64 + lane];
+        m0 = pom_load_shared<CHAIN>(p.agent_mem + tile_id * 64 + lane);
+        m1 = pom_load_shared<CHAIN>(p.agent_mem + 4 * np + tile_id * 64 + lane);
     }
     /* the first tick's moves do not depend on the record: hash / fetch them while the record is on its way */
     uint64_t draw0 = 0;
@@ -705,7 +712,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                 const int ec_u = G == 1 ? src : src >> 2;
                 uint32_t ep = 0;
                 if (lane == src) {
-                    ep = p.episode[e] + 1u;
+                    ep = pom_load_shared<CHAIN>(p.episode + e) + 1u;
                     p.episode[e] = ep;
                 }
                 ep = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)ep, src));
@@ -860,7 +867,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                     if (FRESH) {
                         uint32_t ep = 0;
                         if (lane == src) {
-                            ep = p.episode[e_u] + 1u;
+                            ep = pom_load_shared<CHAIN>(p.episode + e_u) + 1u;
                             p.episode[e_u] = ep;
                         }
                         ep = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)ep, src));

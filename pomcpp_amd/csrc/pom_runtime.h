@@ -126,7 +126,7 @@ static bool runs_at_end(const PomBatch* h);
  * handle's several-tick calls will mostly be) */
 static int streams_for(const PomBatch* h, int kind)
 {
-    const bool chains = h->issue_mode == POM_ISSUE_CHAIN && h->quad && !runs_fresh(h) && !runs_at_end(h) && h->chain_parts > 1;
+    const bool chains = h->issue_mode == POM_ISSUE_CHAIN && h->quad && h->chain_parts > 1;
     return kind == POM_KIND_CHAIN || (kind == 0 && chains) ? h->chain_parts : h->parts;
 }
 
@@ -571,8 +571,8 @@ static int launch_many_streams(PomBatch* h, const StepParams& p0, int launches, 
  * caller takes the ordinary path. */
 static bool runs_chain(const PomBatch* h, bool policy, int ticks_per_launch)
 {
-    return h->issue_mode == POM_ISSUE_CHAIN && h->quad && h->chain_parts > 1 && !policy && !runs_fresh(h) && !runs_at_end(h) && ticks_per_launch == 1 &&
-           !(h->chain.tried && !h->chain.ok);
+    (void)policy; /* every one-tick instantiation of the quad shape has its chained twin */
+    return h->issue_mode == POM_ISSUE_CHAIN && h->quad && h->chain_parts > 1 && ticks_per_launch == 1 && !(h->chain.tried && !h->chain.ok);
 }
 /* the kernel's failure flags (pinned memory): looked at by every call that joins or launches */
 static int chain_check(PomBatch* h)
@@ -599,7 +599,7 @@ static int chain_verify(PomBatch* h)
     c->unverified = false;
     return POM_OK;
 }
-static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bool* used)
+static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bool policy, bool* used)
 {
     *used = false;
     PomChain* c = &h->chain;
@@ -622,7 +622,12 @@ static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bo
     p.tile_seq = c->tile_seq;
     p.chain_err = c->err_dev;
     p.chain_seq0 = c->visits;
-    static const PomStepKernel kernel = pom_step_kernel<16, 4, false, false, false, true, true>;
+    static const PomStepKernel chained[8] = {
+        pom_step_kernel<16, 4, false, false, false, true, true>, pom_step_kernel<16, 4, false, false, true, true, true>,
+        pom_step_kernel<16, 4, false, true, false, true, true>,  pom_step_kernel<16, 4, false, true, true, true, true>,
+        pom_step_kernel<16, 4, true, false, false, true, true>,  pom_step_kernel<16, 4, true, false, true, true, true>,
+        pom_step_kernel<16, 4, true, true, false, true, true>,   pom_step_kernel<16, 4, true, true, true, true, true>};
+    const PomStepKernel kernel = chained[(runs_fresh(h) ? 4 : 0) | (policy ? 2 : 0) | (runs_at_end(h) ? 1 : 0)];
     const dim3 grid((unsigned)(((tiles + POM_WPB - 1) / POM_WPB + 7) / 8 * 8)); /* a multiple of 8: every XCD gets as many workgroups as it has tiles */
     for (int k = 0; k < launches; k++) {
         const int part = (int)(c->turn++ % (uint32_t)h->chain_parts);
@@ -649,7 +654,7 @@ static int launch_many(PomBatch* h, uint64_t seed, int dist, int launches, int t
         StepParams p;
         if (int rc = fill_params(h, p, nullptr, seed, dist, 1)) return rc;
         bool used = false;
-        if (int rc = launch_many_chain(h, p, launches, &used)) return rc;
+        if (int rc = launch_many_chain(h, p, launches, policy, &used)) return rc;
         if (used) {
             h->tick += (uint64_t)launches;
             return POM_OK;
