@@ -244,8 +244,8 @@ def cpu_baseline(start: np.ndarray, seed: int, dist_id: int, max_steps: int, bud
 
 def measure_traffic(args) -> dict | None:
     """--measure-traffic: HBM bytes per step of THIS build on THIS workload, from the PMC counters: two child runs of this script under rocprofv3
-    (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: separate passes, counters only, no tracing), one launch per step so that no
-    concurrent dispatch shares the counters.  gfx950: FETCH_SIZE reports half of a coalesced streaming read (MI355X guide;
+    (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: separate passes, counters only, no tracing); a chained launch covers the whole batch,
+    one tick (with sub-batches — `--streams N` under another issue mode — a step is N dispatches: pass `--streams 1` for a per-step figure).  gfx950: FETCH_SIZE reports half of a coalesced streaming read (MI355X guide;
     calibrated in round 1 on a zero-tick launch of this kernel: 0.513), both counters are in KB.  None if the profiler is not
     there or a pass fails — the caller then falls back to the committed measurement."""
     import csv
@@ -255,7 +255,8 @@ def measure_traffic(args) -> dict | None:
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return {"failed": "rocprofv3 not found"}
-    child = [sys.executable, os.path.abspath(__file__), "--traffic-probe", "--streams", "1", "--steps", "60", "--warmup", "10",
+    # (the launches as the parent issues them — chained by default: the profiler plays dispatches one at a time while it counts)
+    child = [sys.executable, os.path.abspath(__file__), "--traffic-probe", "--streams", str(args.streams), "--steps", "60", "--warmup", "10",
              "--envs", str(args.envs), "--kind", args.kind, "--dist", args.dist, "--seed", str(args.seed), "--max-steps", str(args.max_steps),
              "--burn-in", str(args.burn_in), "--no-cpu-baseline", "--no-config3"]  # (direct launches: 60 steps = 3 graph chunks would also do)
     env = dict(os.environ, TMPDIR="/tmp")
@@ -473,6 +474,7 @@ def worker(args) -> None:
     # a step is issued as `parts` launches of pom_step_kernel over contiguous sub-batches on parallel streams; time the
     # individual launches too (HIP events attached to each dispatch), outside the timed region
     epw, lpe, parts = env.launch_shape()
+    issue, issue_streams = env.issue_info()
     env.profile(True)
     run_steps(max(1, 256 // parts))
     launch_ms, n_launch = env.profile_read()
@@ -635,6 +637,10 @@ def worker(args) -> None:
                 "policy": args.policy,
                 "envs_per_gpu": args.envs, "global_envs": plan["global_envs"], "ticks_per_launch": tpl,
                 "envs_per_wave": epw, "lanes_per_env": lpe, "launches_per_step": parts,
+                # chain: every launch covers ALL tiles and plays one tick, consecutive launches go to different streams, a ticket
+                # word per tile orders that tile's ticks (pomcpp_amd/csrc/pom_chain.h); threads / direct / graph: `launches_per_step`
+                # sub-batches per tick on parallel streams
+                "issue": issue, "issue_streams": issue_streams,
                 "burn_in_ticks": args.burn_in, "launches_per_step_tuning_ms": tuned, "untimed_tuning_steps": tuning_steps,
                 "parallelism": f"env-shard x{world}", "ranks": world, "collective_backend": backend,
                 "rccl_ranks": dist.get_world_size() if world > 1 else 1,
@@ -656,13 +662,19 @@ def worker(args) -> None:
                 # same clock.  Bytes the kernel does not move — the device record is packed to 448 B — so not a utilisation (it can
                 # pass 1.0); kept because rounds 1-2 reported it as `frac`.
                 "contract_achieved": contract, "contract_frac": contract / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": algo_bytes,
-                "limited_by": "instruction issue and the slowest wavefront of a launch (one round of 4 wavefronts per SIMD), not HBM: "
-                              "DESIGN.md §4, SQ / I-cache counters in profiles/",
+                "limited_by": ("per-wavefront instruction latency (one round of 4 wavefronts per SIMD); with chained launches a tile's next tick "
+                               "no longer waits for the slowest wavefront of the whole launch: DESIGN.md §4, SQ / I-cache counters in profiles/"
+                               if issue == "chain" else
+                               "instruction issue and the slowest wavefront of a launch (one round of 4 wavefronts per SIMD), not HBM: "
+                               "DESIGN.md §4, SQ / I-cache counters in profiles/"),
                 # <envs per wavefront, lanes per env, fresh boards, fused policy, reset at end, one tick per launch>, as rocprofv3 names it
+                # ..., chained launches>
                 "kernel": f"pom_step_kernel<{epw}, {lpe}, {'true' if args.fresh_boards else 'false'}, {'true' if args.policy == 'simple' else 'false'}, false, "
-                          f"{'true' if (tpl == 1 and lpe == 4) else 'false'}>",
+                          f"{'true' if (tpl == 1 and lpe == 4) else 'false'}, {'true' if issue == 'chain' and tpl == 1 else 'false'}>",
                 "step_ms_hip_events": step_ms, "ms_per_step": ms_per_step,
-                # one step = `launches_per_step` concurrent launches; per launch: bytes / mean duration (matches rocprofv3's AverageNs)
+                # one step = `launches_per_step` launches; per launch: bytes / mean duration (matches rocprofv3's AverageNs).  Chained
+                # launches of consecutive ticks overlap on the device: a launch then lasts longer than the step period, and
+                # `achieved` above (bytes per step over the period) is the figure that says what the memory system sees
                 "launches_per_step": parts,
                 "launch": {"envs": plan["n_envs"] // parts, "hbm_bytes": moved // parts, "algorithmic_bytes": algo_bytes // parts,
                            "packed_bytes": footprint // parts, "ms": launch_ms, "timed_launches": n_launch,

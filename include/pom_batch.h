@@ -73,7 +73,8 @@ typedef struct PomBatchOptions {
                               device inside the tick, the host is not involved */
     uint64_t board_seed;   /* seed of those boards; pom_batch_generate replaces it */
     int32_t issue_mode;    /* how the launches of a several-tick call (pom_batch_step_random / _step_simple) are issued — POM_ISSUE_*;
-                              results do not depend on it.  0 = POM_ISSUE_THREADS where a step is several launches */
+                              results do not depend on it.  0 = POM_ISSUE_CHAIN up to 196,608 envs (default kernel shape),
+                              POM_ISSUE_THREADS otherwise */
     int32_t reserved_;
 } PomBatchOptions;
 
@@ -178,6 +179,9 @@ int pom_batch_profile(PomBatch* h, int enable);
 int pom_batch_profile_read(PomBatch* h, double* mean_ms, int64_t* launches);
 /* how a step is issued: envs per wavefront, lanes per env and kernel launches (sub-batches) per step */
 int pom_batch_launch_shape(PomBatch* h, int32_t* envs_per_wave, int32_t* lanes_per_env, int32_t* launches_per_step);
+/* how the launches of a several-tick call are issued: the POM_ISSUE_* in force (AUTO resolved; POM_ISSUE_CHAIN only while chained
+ * launches are available to the handle) and the number of streams they go to */
+int pom_batch_issue_info(PomBatch* h, int32_t* issue_mode, int32_t* streams);
 
 /* the hipStream_t the handle's work is ordered on (the one given at creation, or the library's own), so that a caller can
  * order its own device work against steps and observations with events instead of pom_batch_sync */

@@ -112,6 +112,8 @@ def load_library() -> C.CDLL:
     lib.pom_batch_profile.argtypes = [P, C.c_int]
     lib.pom_batch_profile_read.argtypes = [P, C.POINTER(C.c_double), C.POINTER(I64)]
     lib.pom_batch_launch_shape.argtypes = [P, C.POINTER(I32), C.POINTER(I32), C.POINTER(I32)]
+    if not os.environ.get("POM_LIB") or hasattr(lib, "pom_batch_issue_info"):
+        lib.pom_batch_issue_info.argtypes = [P, C.POINTER(I32), C.POINTER(I32)]
     lib.pom_batch_device_view.argtypes = [P, C.POINTER(VP), C.POINTER(I64), C.POINTER(I32)]
     lib.pom_step.argtypes = [VP, VP]
     if not os.environ.get("POM_LIB") or hasattr(lib, "pom_env_step"):
@@ -393,6 +395,12 @@ class BatchEnvironment:
         epw, lpe, parts = C.c_int32(), C.c_int32(), C.c_int32()
         _check(self._lib, self._lib.pom_batch_launch_shape(self._h, C.byref(epw), C.byref(lpe), C.byref(parts)))
         return epw.value, lpe.value, parts.value
+
+    def issue_info(self):
+        """(name of the issue mode in force for several-tick calls, streams their launches go to)"""
+        mode, streams = C.c_int32(), C.c_int32()
+        _check(self._lib, self._lib.pom_batch_issue_info(self._h, C.byref(mode), C.byref(streams)))
+        return {ISSUE_DIRECT: "direct", ISSUE_THREADS: "threads", ISSUE_GRAPH: "graph", ISSUE_CHAIN: "chain"}.get(mode.value, "?"), streams.value
 
     def device_view(self):
         base, n_pad, rec = C.c_void_p(), C.c_int64(), C.c_int32()

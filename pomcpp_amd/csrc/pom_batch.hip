@@ -731,7 +731,16 @@ int pom_batch_launch_shape(PomBatch* h, int32_t* envs_per_wave, int32_t* lanes_p
     if (!h) return POM_E_ARG;
     if (envs_per_wave) *envs_per_wave = h->epw;
     if (lanes_per_env) *lanes_per_env = h->quad ? 4 : 1;
-    if (launches_per_step) *launches_per_step = (h->issue_mode == POM_ISSUE_CHAIN && h->chain.ok) ? 1 : h->parts; /* chained: one launch over all tiles per tick */
+    if (launches_per_step) *launches_per_step = runs_chain(h, false, 1) ? 1 : h->parts; /* chained: one launch over all tiles per tick */
+    return POM_OK;
+}
+
+int pom_batch_issue_info(PomBatch* h, int32_t* issue_mode, int32_t* streams)
+{
+    if (!h) return POM_E_ARG;
+    const bool chains = runs_chain(h, false, 1);
+    if (issue_mode) *issue_mode = h->issue_mode == POM_ISSUE_CHAIN && !chains ? POM_ISSUE_THREADS : h->issue_mode;
+    if (streams) *streams = chains ? h->chain_parts : h->parts;
     return POM_OK;
 }
 

@@ -16,6 +16,9 @@ python3 bench.py --fresh-boards --steps 300 --warmup 20 $Q 2>/dev/null | tail -1
 python3 bench.py --policy simple --envs 262144 --steps 100 --warmup 20 $Q 2>/dev/null | tail -1 > $OUT/bench_simple_262144_envs.json
 python3 bench.py --policy simple --steps 200 --warmup 50 $Q 2>/dev/null | tail -1 > $OUT/bench_simple_65536_envs.json
 for n in 4096 16384 131072 524288 1048576; do python3 bench.py --envs $n --steps 100 --warmup 20 $Q 2>/dev/null | tail -1 > $OUT/bench_${n}_envs.json; done
+# the headline with sub-batches on parallel streams (the default before chained launches), for comparison
+POM_ISSUE=threads python3 bench.py --steps 500 --warmup 50 $Q 2>/dev/null | tail -1 > $OUT/bench_issue_threads.json
+python3 bench.py --policy simple --envs 32768 --steps 200 --warmup 50 $Q 2>/dev/null | tail -1 > $OUT/bench_simple_32768_envs.json
 for f in $OUT/*.json $OUT/*.jsonl; do python3 - "$f" <<'PY'
 import json, sys
 for line in open(sys.argv[1]).read().strip().splitlines():

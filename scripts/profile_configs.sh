@@ -2,14 +2,16 @@
 # scripts/profile_configs.sh <tag> — rocprofv3 summaries for every BASELINE single-GPU config (run through gpurun):
 #   head1   config "headline" with ONE launch per step (--streams 1): 65,536 envs in one dispatch, so that
 #           bytes / AverageNs / peak is checkable from the kernel-trace alone
-#   head3   the headline as bench.py runs it by default (3 launches per step on parallel streams): kernel trace only
+#   headc   the headline as bench.py runs it by default: chained launches (one launch over all tiles per tick, two streams):
+#           kernel trace + the byte counters (the profiler plays dispatches one at a time while it counts)
+#   head3   the headline as 3 sub-batches per step on parallel streams (POM_ISSUE=threads: the default before chained launches): kernel trace only
 #   c5      config 5: 65,536 envs, kick / chain-explosion stress boards and move mix
 #   c3      config 3: 65,536 envs, 4x SimpleAgent policy fused with the tick
 #   c2      config 2: 4,096 envs, random moves
 # Kernel traces and PMC passes are separate runs (never combined with sys/hip traces).  Output: gpurun_out/prof_<tag>/<cfg>/.
 set -u
 TAG=$1; shift
-WHICH=${*:-head1 head3 c5 c3 c2}
+WHICH=${*:-headc head1 head3 c5 c3 c2}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 TOP=$REPO/gpurun_out/prof_$TAG
 mkdir -p $TOP
@@ -18,12 +20,14 @@ COMMON="--no-cpu-baseline --no-config3 --streams 1"
 for CFG in $WHICH; do
   case $CFG in
     head1) ARGS="--steps 200 --warmup 20 $COMMON" ;;
-    head3) ARGS="--steps 200 --warmup 20 --no-cpu-baseline --no-config3 --streams 3" ;;
+    headc) ARGS="--steps 200 --warmup 20 --no-cpu-baseline --no-config3" ;;
+    head3) ARGS="--steps 200 --warmup 20 --no-cpu-baseline --no-config3 --streams 3"; export POM_ISSUE=threads ;;
     c5)    ARGS="--steps 200 --warmup 60 --kind stress --dist stress $COMMON" ;;
     c3)    ARGS="--steps 200 --warmup 200 --policy simple $COMMON" ;;
     c2)    ARGS="--steps 400 --warmup 60 --envs 4096 $COMMON" ;;
     *) echo "unknown config $CFG"; exit 2 ;;
   esac
+  [ "$CFG" = head3 ] || unset POM_ISSUE
   OUT=$TOP/$CFG
   rm -rf $OUT && mkdir -p $OUT
   echo "== $CFG: bench.py $ARGS"
@@ -40,7 +44,7 @@ for CFG in $WHICH; do
   # instruction fetch / branches (round 3): the I-cache counters live in the SQC block, the fetch / branch / SALU-cycle counters in the SQ
   rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_ICACHE_BUSY_CYCLES --output-format csv -d $OUT/ic1 -- python3 $REPO/bench.py $ARGS > $OUT/ic1.log 2>&1 || { echo "ic1 pass failed"; tail -5 $OUT/ic1.log; }
   rocprofv3 --pmc SQ_IFETCH SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/ic2 -- python3 $REPO/bench.py $ARGS > $OUT/ic2.log 2>&1 || { echo "ic2 pass failed"; tail -5 $OUT/ic2.log; }
-  if [ "$CFG" = head1 ] || [ "${POM_PROFILE_BYTES:-0}" = 1 ]; then
+  if [ "$CFG" = head1 ] || [ "$CFG" = headc ] || [ "${POM_PROFILE_BYTES:-0}" = 1 ]; then
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $REPO/bench.py $ARGS > $OUT/fetch.log 2>&1 || exit 1
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $REPO/bench.py $ARGS > $OUT/write.log 2>&1 || exit 1
   fi
