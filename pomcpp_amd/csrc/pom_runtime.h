@@ -609,7 +609,10 @@ static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bo
     }
     if (!chain_setup(c, tiles, h->stream)) return POM_OK;
     if (int rc = chain_check(h)) return rc;
-    if ((uint64_t)c->visits + (uint64_t)launches >= (1u << 27)) { /* the fields of the tile words must not run into each other */
+    /* the fields of the tile words must not run into each other: after 2^27 visits (20 minutes of stepping) the words start over.
+     * (POM_CHAIN_RESET_AT: a smaller number, so that tests get to see it happen) */
+    static const uint64_t reset_at = getenv("POM_CHAIN_RESET_AT") ? (uint64_t)atoll(getenv("POM_CHAIN_RESET_AT")) : (uint64_t)(1u << 27);
+    if ((uint64_t)c->visits + (uint64_t)launches >= (reset_at < (1u << 27) && reset_at > 0 ? reset_at : (uint64_t)(1u << 27))) {
         if (int jr = join_parts(h)) return jr;
         HIPCHK(hipMemsetAsync(c->tile_seq, 0, (size_t)tiles * 8, h->stream));
         c->visits = 0;
