@@ -54,9 +54,9 @@ static bool chain_setup(PomChain* c, int64_t tiles, hipStream_t stream)
     if (c->tried) return c->ok;
     c->tried = true;
 #if defined(POM_CHAIN_DIAG)
-    const size_t words = (size_t)tiles * 21; /* + 20 diagnostic words per tile */
+    const size_t words = (size_t)tiles * (POM_CHAIN_WORD_STRIDE + 20); /* + 20 diagnostic words per tile */
 #else
-    const size_t words = (size_t)tiles;
+    const size_t words = (size_t)tiles * POM_CHAIN_WORD_STRIDE;
 #endif
     if (hipMalloc((void**)&c->tile_seq, words * 8) != hipSuccess ||
         hipMemsetAsync(c->tile_seq, 0, words * 8, stream) != hipSuccess || /* on the handle's stream: the fork orders the launches behind it */

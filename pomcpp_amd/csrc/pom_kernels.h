@@ -529,6 +529,10 @@ __device__ __forceinline__ int pom_policy_wave(Store& st, const PomPolicyEnv& E,
 extern "C" __device__ uint64_t pom_dispatch_id(void) __asm("llvm.amdgcn.dispatch.id"); /* the AQL packet's index in its queue */
 enum { POM_CHAIN_SPIN_LIMIT = 400000 }; /* polls of ~0.3 us before a wavefront gives up (it must never hang the device) */
 enum { POM_CHAIN_TICKET_SHIFT = 36, POM_CHAIN_COUNT_MASK = 0x0FFFFFFF };
+#ifndef POM_CHAIN_WORD_STRIDE
+#define POM_CHAIN_WORD_STRIDE 16 /* 64-bit words between the ticket words of neighbouring tiles: a 128-byte line each (10.28 - 10.30 us
+                                    per step against 10.41 - 10.48 with the words packed: atomics of neighbouring tiles do not queue on one line) */
+#endif
 
 /* a dword that a wavefront of an earlier, still unfinished launch may have written (chained launches): past this CU's vector cache */
 template <bool CHAIN>
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     long long c_steps = 0, c_episodes = 0, c_resets = 0, c_ub = 0;
 
     /* the launch's first tick: asked for BEFORE the record, so that waiting for it (in-order vmcnt) does not wait for the record */
-    uint32_t tick0 = p.tick0 + *p.tick_base;
+    uint32_t tick0 = CHAIN ? p.tick0 : p.tick0 + *p.tick_base; /* (graphs replay sub-batch launches, never chained ones) */
     unsigned long long chain_done = 0; /* what this wavefront adds to the tile's word when its stores have arrived */
 #if defined(POM_CHAIN_DIAG)
     long long chain_t0 = 0, chain_t1 = 0, chain_t2 = 0, chain_rt0 = 0;
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
 #endif
         /* take a ticket: the old value says which visit of the tile this is — and, mostly, that the visit before it is stored */
         unsigned long long w = 0;
-        if (lane == 0) w = __hip_atomic_fetch_add(p.tile_seq + tile_id, 1ull << POM_CHAIN_TICKET_SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) w = __hip_atomic_fetch_add(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, 1ull << POM_CHAIN_TICKET_SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
         const uint32_t visit = (uint32_t)(w >> POM_CHAIN_TICKET_SHIFT);
         /* which tick: the call's first tick + how far this visit is from the call's first visit — a signed distance: launches of
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         int polls = 0;
         while (((uint32_t)w & POM_CHAIN_COUNT_MASK) != visit && ++polls <= POM_CHAIN_SPIN_LIMIT) { /* wave-uniform */
             __builtin_amdgcn_s_sleep(1);
-            w = __hip_atomic_load(p.tile_seq + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w = __hip_atomic_load(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const uint32_t was_on = (uint32_t)(w >> 32) & 0xFu;
         const bool gave_up = ((uint32_t)w & POM_CHAIN_COUNT_MASK) != visit;
@@ -914,10 +918,10 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     }
     if (CHAIN) { /* the record's stores have been acknowledged by the L2 before the word that hands the tile on is written */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(p.tile_seq + tile_id, chain_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_fetch_add(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, chain_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(POM_CHAIN_DIAG)
         if (lane == 0) { /* per tile, summed over launches: cycles to the ticket, cycles polling, cycles in all, polls */
-            unsigned long long* d = p.tile_seq + (p.block_end - p.block0) + 20 * tile_id;
+            unsigned long long* d = p.tile_seq + (p.block_end - p.block0) * POM_CHAIN_WORD_STRIDE + 20 * tile_id;
             d[4 + 2 * (chain_visit & 7)] = (unsigned long long)chain_rt0; /* the last 8 visits: start and end on the 100 MHz clock */
             d[5 + 2 * (chain_visit & 7)] = (unsigned long long)wall_clock64();
             d[0] += (unsigned long long)(chain_t1 - chain_t0);
@@ -963,7 +967,7 @@ __global__ void pom_chain_verify_kernel(const unsigned long long* tile_seq, int6
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tiles) return;
-    const unsigned long long w = tile_seq[t];
+    const unsigned long long w = tile_seq[t * POM_CHAIN_WORD_STRIDE];
     if (((uint32_t)w & POM_CHAIN_COUNT_MASK) != visits || (uint32_t)(w >> POM_CHAIN_TICKET_SHIFT) != visits) atomicOr(err, 4u);
 }
 

@@ -614,7 +614,7 @@ static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bo
     static const uint64_t reset_at = getenv("POM_CHAIN_RESET_AT") ? (uint64_t)atoll(getenv("POM_CHAIN_RESET_AT")) : (uint64_t)(1u << 27);
     if ((uint64_t)c->visits + (uint64_t)launches >= (reset_at < (1u << 27) && reset_at > 0 ? reset_at : (uint64_t)(1u << 27))) {
         if (int jr = join_parts(h)) return jr;
-        HIPCHK(hipMemsetAsync(c->tile_seq, 0, (size_t)tiles * 8, h->stream));
+        HIPCHK(hipMemsetAsync(c->tile_seq, 0, (size_t)tiles * 8 * POM_CHAIN_WORD_STRIDE, h->stream));
         c->visits = 0;
     }
     if (int rc = fork_parts(h, POM_KIND_CHAIN)) return rc;

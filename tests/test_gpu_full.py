@@ -276,7 +276,8 @@ def test_split_steps_over_streams_give_identical_results(hip_lib, oracle, stream
     want = start.copy()
     oracle.run_random(want, start, ticks, seed, 0, 0, DIST_RANDOM, 800)
     with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800, streams=streams) as env:
-        assert env.launch_shape()[2] == streams
+        # one stream: plain launches in a row; more: chained launches (one launch over all tiles per tick) rotating over them
+        assert env.issue_info() == (("chain", streams) if streams > 1 else ("threads", 1)) and env.launch_shape()[2] == 1
         env.make_game(start)
         env.step_random(seed, DIST_RANDOM, ticks=ticks // 2)
         mid = env.get_state()          # joins the sub-streams
