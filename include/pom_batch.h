@@ -64,8 +64,9 @@ typedef struct PomBatchOptions {
     int32_t max_steps;    /* ENV mode: env is done once timeStep reaches this (0 = no limit); StartGame's bound, environment.cpp:71 */
     int64_t env_offset;   /* global index of env 0, keys the synthetic move stream when a job is sharded over GPUs */
     int32_t envs_per_wave; /* 0 = default (16); else 16, 32 or 64 envs per wavefront (results are identical) */
-    int32_t streams;       /* 0 = choose by batch size; else 1..8 sub-batches per step, each on an internal stream, so that
-                              one part's load/store overlaps the others' compute (results are identical) */
+    int32_t streams;       /* 0 = choose (2 for chained launches; sub-batches by batch size); else 1..8: the streams chained
+                              launches rotate over, and the sub-batches per step — each on an internal stream — where launches
+                              are not chained (results are identical; 1 = plain launches in a row on the handle's stream) */
     int32_t lanes_per_env; /* 0 = default (4: a quad of adjacent lanes runs each env's tick and splits its order-free parts,
                               needs envs_per_wave 16); 1 = one lane per env */
     int32_t fresh_boards;  /* with auto_reset: a finished env starts its next game on a newly generated board (pom_boardgen.h:
@@ -79,8 +80,10 @@ typedef struct PomBatchOptions {
 } PomBatchOptions;
 
 /* PomBatchOptions.issue_mode (environment POM_ISSUE = direct | threads | graph | chain overrides it).  Measured per step at 65,536
- * envs, 20-tick call from an idle device / 500-tick call: THREADS 18.0 / 15.5 us; DIRECT 17.2 .. 26.4 (host-dependent) /
- * 15.6 - 16.0 us; GRAPH 21.4 .. 23.5 / 16.1 us (pomcpp_amd/csrc/pom_runtime.h, profiles/r03_issue_modes.txt) */
+ * envs, 20-tick call from an idle device / 500-tick call: CHAIN 12.0 - 12.4 / 10.3 - 10.5 us (profiles/r03y_*); with the batch as
+ * three sub-batches on parallel streams: THREADS 16.2 - 17.0 / 14.5 us, DIRECT and GRAPH behind that (measured earlier in the
+ * round, 18.0 / 15.5 for THREADS then: DIRECT 17.2 .. 26.4 (host-dependent) / 15.6 - 16.0 us; GRAPH 21.4 .. 23.5 / 16.1 us;
+ * pomcpp_amd/csrc/pom_runtime.h, profiles/r03_issue_modes.txt) */
 enum {
     POM_ISSUE_AUTO = 0,
     POM_ISSUE_DIRECT = 1,  /* the calling thread issues every launch; the library owns no thread */
@@ -171,7 +174,7 @@ int pom_batch_flush(PomBatch* h);
  * next step's launches need no cross-stream event first (a latency-sensitive caller does this before it starts its clock;
  * stepping does it by itself otherwise) */
 int pom_batch_fork(PomBatch* h);
-/* change the number of sub-batches a step is issued as (1..8, see PomBatchOptions.streams); results do not depend on it,
+/* change the number of streams launches go to (1..8, see PomBatchOptions.streams); results do not depend on it,
  * the best value depends on how many hardware queues the process has free — a caller may try a few and keep the fastest */
 int pom_batch_set_streams(PomBatch* h, int32_t streams);
 /* per-launch timing with HIP events on the launch streams: enable, step (at most 256 launches are kept), read the mean */

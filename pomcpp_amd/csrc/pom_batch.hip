@@ -22,11 +22,11 @@ int pom_batch_destroy(PomBatch* h)
 {
     if (!h) return POM_E_ARG;
     stop_issuers(h);
-    chain_destroy(&h->chain);
     (void)hipSetDevice(h->device);
     for (int k = 0; k < PomBatch::MAX_PARTS; k++)
         if (h->sub[k]) (void)hipStreamSynchronize(h->sub[k]);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    chain_destroy(&h->chain); /* after the streams have drained: launches in flight still use the tiles' words */
     drop_graphs(h);
     for (int k = 0; k < PomBatch::MAX_PARTS; k++) {
         if (h->sub[k]) (void)hipStreamDestroy(h->sub[k]);
