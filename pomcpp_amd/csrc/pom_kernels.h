@@ -250,6 +250,7 @@ __device__ __forceinline__ void load_tile16_x4(const uint32_t* base, int64_t np,
         g += stride;
     }
 }
+template <bool NT = false>
 __device__ __forceinline__ void store_tile16_x4(uint32_t* base, int64_t np, const uint32_t* tile, int lane)
 {
     uint4* g = reinterpret_cast<uint4*>(base + (int64_t)(lane >> 2) * np + 4 * (lane & 3));
@@ -257,7 +258,11 @@ __device__ __forceinline__ void store_tile16_x4(uint32_t* base, int64_t np, cons
     const uint4* l = reinterpret_cast<const uint4*>(tile) + lane;
 #pragma unroll
     for (int r0 = 0; r0 < POM_REC_DWORDS; r0 += 16) {
-        *g = l[r0 * 4];
+        if (NT) {
+            typedef uint32_t pom_u32x4 __attribute__((ext_vector_type(4)));
+            const uint4 v = l[r0 * 4];
+            __builtin_nontemporal_store(pom_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<pom_u32x4*>(g));
+        } else *g = l[r0 * 4];
         g += stride;
     }
 }
@@ -529,6 +534,9 @@ __device__ __forceinline__ int pom_policy_wave(Store& st, const PomPolicyEnv& E,
 extern "C" __device__ uint64_t pom_dispatch_id(void) __asm("llvm.amdgcn.dispatch.id"); /* the AQL packet's index in its queue */
 enum { POM_CHAIN_SPIN_LIMIT = 400000 }; /* polls of ~0.3 us before a wavefront gives up (it must never hang the device) */
 enum { POM_CHAIN_TICKET_SHIFT = 36, POM_CHAIN_COUNT_MASK = 0x0FFFFFFF };
+#ifndef POM_CHAIN_LOAD_AUX
+#define POM_CHAIN_LOAD_AUX 16 /* sc1 */
+#endif
 #ifndef POM_CHAIN_WORD_STRIDE
 #define POM_CHAIN_WORD_STRIDE 16 /* 64-bit words between the ticket words of neighbouring tiles: a 128-byte line each (10.28 - 10.30 us
                                     per step against 10.41 - 10.48 with the words packed: atomics of neighbouring tiles do not queue on one line) */
@@ -660,7 +668,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
 #endif
         chain_done = 1ull + ((unsigned long long)(xcd - was_on) << 32);
         /* the loads below are issued after the word has been seen: the record they fetch is the stored one */
-        load_tile16_x4<POM_REC_DWORDS, 16>(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane);
+        load_tile16_x4<POM_REC_DWORDS, POM_CHAIN_LOAD_AUX>(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane);
     } else if (EPW == 16) load_tile16_x4(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane); /* 16-byte pieces, 7 instructions of 1 KB */
     else load_tile<EPW>(col_d, POM_TILE_ENVS, tile, sub);
     uint32_t m0 = 0, m1 = 0; /* POLICY: this lane's agent's memory */
@@ -912,7 +920,11 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
          * see through, so that they are computed here */
         int lane_late = lane;
         asm volatile("" : "+v"(lane_late));
-        store_tile16_x4(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane_late);
+#if defined(POM_STORE_NT_ALL)
+        store_tile16_x4<true>(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane_late);
+#else
+        store_tile16_x4<CHAIN>(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane_late);
+#endif
     } else {
         store_tile<EPW>(col_d, POM_TILE_ENVS, tile, sub, el);
     }
