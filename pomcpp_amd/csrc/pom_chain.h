@@ -25,7 +25,8 @@
  *    no order of dispatch can deadlock.  Should a wait still not end (400 k polls) the wavefront gives up and flags it (bit 0):
  *    no launch can hang the device.
  * A flag makes the next call that looks (every call that joins or launches) fail with POM_E_HIP; the handle then launches the
- * ordinary way.
+ * ordinary way.  Before the first chained launch of a handle a 64-workgroup probe checks the workgroup -> XCD pattern itself (a
+ * partitioned device, or another chip, does not have it): no chained launch is ever issued where it does not hold.
  */
 #ifndef POM_CHAIN_H_
 #define POM_CHAIN_H_
@@ -66,6 +67,26 @@ static bool chain_setup(PomChain* c, int64_t tiles, hipStream_t stream)
         return false;
     }
     *c->err_host = 0;
+    /* the assumption behind the tile choice, probed once (twice, on this stream): workgroups b, b + 8, b + 16 ... of a launch land
+     * on one XCD, and the eight residues on eight different XCDs numbered 0 .. 7 */
+    enum { PROBE = 64 };
+    uint32_t* probe_dev = reinterpret_cast<uint32_t*>(c->tile_seq); /* not yet in use; zeroed again below */
+    for (int pass = 0; pass < 2; pass++) {
+        uint32_t got[PROBE];
+        pom_chain_probe_kernel<<<dim3(PROBE), dim3(64), 0, stream>>>(probe_dev);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(got, probe_dev, sizeof got, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        uint32_t seen = 0;
+        for (int b = 0; b < PROBE; b++) {
+            if (got[b] >= 8u || got[b] != got[b % 8]) return false;
+            if (b < 8) seen |= 1u << got[b];
+        }
+        if (seen != 0xFFu) return false;
+    }
+    if (hipMemsetAsync(c->tile_seq, 0, PROBE * 4, stream) != hipSuccess) return false;
     c->ok = true;
     return true;
 }

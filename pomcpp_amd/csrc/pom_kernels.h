@@ -973,6 +973,15 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     }
 }
 
+/* chained launches, before the first one: which XCD does workgroup b of a small grid land on?  (pom_chain.h checks that it is the
+ * round-robin over eight XCDs the tile choice assumes — a partitioned device, or another chip, is not) */
+__global__ void pom_chain_probe_kernel(uint32_t* xcd_of_block)
+{
+    uint32_t x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    if (threadIdx.x == 0) xcd_of_block[blockIdx.x] = x & 0xFu;
+}
+
 /* chained launches, after a join: every tile must have been visited exactly `visits` times and every visit stored (a
  * workgroup -> XCD assignment that is not the round-robin the tile choice assumes would show here) */
 __global__ void pom_chain_verify_kernel(const unsigned long long* tile_seq, int64_t tiles, uint32_t visits, uint32_t* err)
