@@ -160,12 +160,16 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
         if (v >= 1 && v <= PomBatch::MAX_PARTS) h->parts = v;
     }
     if ((int64_t)h->parts > h->n_pad / h->epw) h->parts = (int)(h->n_pad / h->epw);
-    /* chained launches rotate over two streams unless the caller asked for a number (options / POM_STREAMS / pom_batch_set_streams:
-     * then that many; one stream = launches in a row, nothing to chain) */
-    h->chain_parts = (o.streams >= 1 || getenv("POM_STREAMS")) ? h->parts : 2;
+    /* chained launches rotate over two streams (short calls) or three (long ones) unless the caller asked for a number (options /
+     * POM_STREAMS / pom_batch_set_streams: then that many; one stream = launches in a row, nothing to chain) */
+    h->chain_auto = !(o.streams >= 1 || getenv("POM_STREAMS"));
+    h->chain_parts = h->chain_auto ? 3 : h->parts;
     if (const char* ev = getenv("POM_CHAIN_STREAMS")) {
         const int v = atoi(ev);
-        if (v >= 1 && v <= PomBatch::MAX_PARTS) h->chain_parts = v;
+        if (v >= 1 && v <= PomBatch::MAX_PARTS) {
+            h->chain_parts = v;
+            h->chain_auto = false;
+        }
     }
     if (o.auto_reset == POM_RESET_AT_END && !h->quad) {
         snprintf(g_err, sizeof g_err, "pom_batch_create: auto_reset = POM_RESET_AT_END is built for the default kernel shape "
@@ -609,6 +613,7 @@ int pom_batch_set_streams(PomBatch* h, int32_t streams)
     if (int er = ensure_sub_streams(h, streams)) return er;
     h->parts = want;
     h->chain_parts = streams; /* chained launches cover all tiles: their stream count is not bounded by the tiles */
+    h->chain_auto = false;
     return POM_OK;
 }
 
@@ -741,7 +746,7 @@ int pom_batch_issue_info(PomBatch* h, int32_t* issue_mode, int32_t* streams)
     if (!h) return POM_E_ARG;
     const bool chains = runs_chain(h, false, 1);
     if (issue_mode) *issue_mode = h->issue_mode == POM_ISSUE_CHAIN && !chains ? POM_ISSUE_THREADS : h->issue_mode;
-    if (streams) *streams = chains ? h->chain_parts : h->parts;
+    if (streams) *streams = !chains ? h->parts : h->chain_auto ? h->chain_last_use : h->chain_parts;
     return POM_OK;
 }
 

@@ -81,7 +81,10 @@ struct PomBatch {
     uint64_t graph_clock = 0;
     uint32_t* tick_words = nullptr;
     PomChain chain;          /* POM_ISSUE_CHAIN: the tiles' ticket words, set up on first use (pom_chain.h) */
-    int chain_parts = 2;     /* ... and how many streams the chained launches rotate over (2 measured best up to 131,072 envs) */
+    int chain_parts = 3;     /* ... and how many streams the chained launches may rotate over */
+    bool chain_auto = true;  /* ... of which a call uses two if it is short and three if it is long (launch_many_chain) — unless the caller
+                                asked for a number of streams */
+    int chain_last_use = 2;  /* what the last chained call used (pom_batch_issue_info) */
     bool fuse_policy = true; /* pom_batch_step_simple: policy and tick in one kernel (quad shape); POM_FUSE=0 keeps them apart */
     /* optional per-launch timing (pom_batch_profile) */
     bool profiling = false;
@@ -566,6 +569,9 @@ static int launch_many_streams(PomBatch* h, const StepParams& p0, int launches, 
     return POM_OK;
 }
 
+#ifndef POM_CHAIN_LONG_CALL
+#define POM_CHAIN_LONG_CALL 40
+#endif
 /* POM_ISSUE_CHAIN (pom_chain.h): `launches` one-tick launches, each over the WHOLE batch, dealt round-robin to the handle's
  * streams; the tiles' ticket words order the ticks.  *used = false: not available for this handle, nothing was launched, the
  * caller takes the ordinary path. */
@@ -632,8 +638,13 @@ static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bo
         pom_step_kernel<16, 4, true, true, false, true, true>,   pom_step_kernel<16, 4, true, true, true, true, true>};
     const PomStepKernel kernel = chained[(runs_fresh(h) ? 4 : 0) | (policy ? 2 : 0) | (runs_at_end(h) ? 1 : 0)];
     const dim3 grid((unsigned)(((tiles + POM_WPB - 1) / POM_WPB + 7) / 8 * 8)); /* a multiple of 8: every XCD gets as many workgroups as it has tiles */
+    /* how many streams: a third launch in flight pays once the pipeline runs (65,536 envs, per step: 400-tick call 9.1 us on
+     * three streams against 9.9 on two, 60 ticks 10.1 / 10.7) and costs while it fills and drains (20 ticks 12.8 / 12.5, 10 ticks
+     * 16.8 / 15.2; scripts/experiments/chain/call_length.py).  Any mix is fine: the tickets order the ticks, not the streams. */
+    const int use = !h->chain_auto ? h->chain_parts : launches >= POM_CHAIN_LONG_CALL ? 3 : 2;
+    h->chain_last_use = use;
     for (int k = 0; k < launches; k++) {
-        const int part = (int)(c->turn++ % (uint32_t)h->chain_parts);
+        const int part = (int)(c->turn++ % (uint32_t)use);
         hipStream_t st = part < h->main_part ? h->stream : h->sub[part];
         const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
         hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;

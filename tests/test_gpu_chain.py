@@ -25,8 +25,14 @@ def _same(got, ref):
 
 
 def test_default_issue_mode_is_chained_where_it_applies(hip_lib):
-    with BatchEnvironment(65536) as env:
+    with BatchEnvironment(65536, auto_reset=True, max_steps=800) as env:
         assert env.issue_info() == ("chain", 2) and env.launch_shape() == (16, 4, 1)
+        env.make_game(pa.make_boards(65536, seed=1))
+        env.step_random(1, DIST_RANDOM, ticks=60)   # a long call rotates over three streams, a short one over two
+        assert env.issue_info() == ("chain", 3)
+        env.step_random(1, DIST_RANDOM, ticks=12)
+        assert env.issue_info() == ("chain", 2)
+        assert env.counters()[CNT_STEPS] == 65536 * 72
     with BatchEnvironment(262144) as env:  # from 196,608 envs up: sub-batches on parallel streams
         assert env.issue_info() == ("threads", 3) and env.launch_shape() == (16, 4, 3)
     with BatchEnvironment(4096, streams=1) as env:  # one stream: launches in a row, nothing to chain
