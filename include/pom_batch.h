@@ -64,7 +64,7 @@ typedef struct PomBatchOptions {
     int32_t max_steps;    /* ENV mode: env is done once timeStep reaches this (0 = no limit); StartGame's bound, environment.cpp:71 */
     int64_t env_offset;   /* global index of env 0, keys the synthetic move stream when a job is sharded over GPUs */
     int32_t envs_per_wave; /* 0 = default (16); else 16, 32 or 64 envs per wavefront (results are identical) */
-    int32_t streams;       /* 0 = choose (2 for chained launches; sub-batches by batch size); else 1..8: the streams chained
+    int32_t streams;       /* 0 = choose (chained launches: 2 in a short call, 3 from 40 launches up; sub-batches by batch size); else 1..8: the streams chained
                               launches rotate over, and the sub-batches per step — each on an internal stream — where launches
                               are not chained (results are identical; 1 = plain launches in a row on the handle's stream) */
     int32_t lanes_per_env; /* 0 = default (4: a quad of adjacent lanes runs each env's tick and splits its order-free parts,
@@ -80,7 +80,7 @@ typedef struct PomBatchOptions {
 } PomBatchOptions;
 
 /* PomBatchOptions.issue_mode (environment POM_ISSUE = direct | threads | graph | chain overrides it).  Measured per step at 65,536
- * envs, 20-tick call from an idle device / 500-tick call: CHAIN 12.0 - 12.4 / 10.3 - 10.5 us (profiles/r03y_*); with the batch as
+ * envs, 20-tick call from an idle device / 500-tick call: CHAIN 11.4 - 12.3 / 9.2 us (profiles/r03y_*); with the batch as
  * three sub-batches on parallel streams: THREADS 16.2 - 17.0 / 14.5 us, DIRECT and GRAPH behind that (measured earlier in the
  * round, 18.0 / 15.5 for THREADS then: DIRECT 17.2 .. 26.4 (host-dependent) / 15.6 - 16.0 us; GRAPH 21.4 .. 23.5 / 16.1 us;
  * pomcpp_amd/csrc/pom_runtime.h, profiles/r03_issue_modes.txt) */

@@ -533,7 +533,6 @@ __device__ __forceinline__ int pom_policy_wave(Store& st, const PomPolicyEnv& E,
  * wavefronts start on the tiles that are ready. */
 extern "C" __device__ uint64_t pom_dispatch_id(void) __asm("llvm.amdgcn.dispatch.id"); /* the AQL packet's index in its queue */
 enum { POM_CHAIN_SPIN_LIMIT = 400000 }; /* polls of ~0.3 us before a wavefront gives up (it must never hang the device) */
-enum { POM_CHAIN_TICKET_SHIFT = 36, POM_CHAIN_COUNT_MASK = 0x0FFFFFFF };
 #ifndef POM_CHAIN_LOAD_AUX
 #define POM_CHAIN_LOAD_AUX 16 /* sc1 */
 #endif
@@ -644,7 +643,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         const uint32_t visit = (uint32_t)(w >> POM_CHAIN_TICKET_SHIFT);
         /* which tick: the call's first tick + how far this visit is from the call's first visit — a signed distance: launches of
          * two calls may be in flight together, and a wavefront of the later call can draw a ticket of the earlier one */
-        tick0 += (uint32_t)((int32_t)((visit - p.chain_seq0) << 4) >> 4);
+        tick0 += pom_chain_visit_distance(visit, p.chain_seq0);
 #if defined(POM_CHAIN_DIAG)
         chain_t1 = (long long)__builtin_readcyclecounter();
 #endif

@@ -173,4 +173,13 @@ POM_HD void pom_unpack_state(const uint32_t* rec, int64_t stride, int32_t* st)
     st[250] = (int32_t)(m2 & 0xFF);
 }
 
+/* Chained launches (pom_chain.h): the tile words count visits in 28-bit fields (tickets in bits 63..36, stored visits in 27..0) and
+ * are zeroed before either reaches 2^27.  A visit's distance from the first visit of the call whose launch it rides in is SIGNED:
+ * launches of two calls can be in flight together, and a wavefront of the later call may draw a ticket of the earlier one. */
+enum { POM_CHAIN_TICKET_SHIFT = 36, POM_CHAIN_COUNT_MASK = 0x0FFFFFFF };
+POM_HD uint32_t pom_chain_visit_distance(uint32_t visit, uint32_t first_visit_of_call)
+{
+    return (uint32_t)((int32_t)((visit - first_visit_of_call) << 4) >> 4);
+}
+
 #endif /* POM_PACKED_H_ */

@@ -150,4 +150,7 @@ uint32_t pom_emul_step(void* state_1004, const int32_t* moves, int env_mode, int
     return L.ub;
 }
 
+/* chained launches: a visit's distance from its call's first visit (pom_packed.h) */
+uint32_t pom_emul_chain_visit_distance(uint32_t visit, uint32_t first) { return pom_chain_visit_distance(visit, first); }
+
 }

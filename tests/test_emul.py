@@ -126,3 +126,18 @@ def test_device_tick_body_reproduces_every_reference_step_case(emul_bins, oracle
             assert len(api.trace) == len(after)
             for k, (_b, _m, a) in enumerate(api.trace):
                 assert a == after[k].tobytes(), f"{name}: state after step {k} differs from the reference's"
+
+
+def test_chain_visit_distance_is_signed_and_survives_the_field_width(emul_bins):
+    """Chained launches (pomcpp_amd/csrc/pom_chain.h): a wavefront plays tick tick0 + (its visit - the first visit of the call its
+    launch belongs to).  Launches of two calls are in flight together, so the difference can be negative; visits live in 28-bit
+    fields that are zeroed before they reach 2^27."""
+    import ctypes as C
+    f = emul_bins.pom_emul_chain_visit_distance
+    f.restype, f.argtypes = C.c_uint32, [C.c_uint32, C.c_uint32]
+    as_signed = lambda v: v - (1 << 32) if v >= (1 << 31) else v
+    for visit, first in ((0, 0), (5, 0), (47, 47), (45, 47), (0, 3), ((1 << 27) - 1, 0), (0, (1 << 27) - 1), (100, (1 << 27) - 5),
+                         ((1 << 27) - 5, 100), (123456, 123400)):
+        assert as_signed(f(visit, first)) == visit - first, (visit, first)
+    # a tick is tick0 + distance in 32-bit arithmetic: an earlier call's ticket gives an earlier tick
+    assert (1000 + f(45, 47)) & 0xFFFFFFFF == 998
