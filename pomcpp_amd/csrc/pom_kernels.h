@@ -533,9 +533,6 @@ __device__ __forceinline__ int pom_policy_wave(Store& st, const PomPolicyEnv& E,
  * wavefronts start on the tiles that are ready. */
 extern "C" __device__ uint64_t pom_dispatch_id(void) __asm("llvm.amdgcn.dispatch.id"); /* the AQL packet's index in its queue */
 enum { POM_CHAIN_SPIN_LIMIT = 400000 }; /* polls of ~0.3 us before a wavefront gives up (it must never hang the device) */
-#ifndef POM_CHAIN_LOAD_AUX
-#define POM_CHAIN_LOAD_AUX 16 /* sc1 */
-#endif
 #ifndef POM_CHAIN_WORD_STRIDE
 #define POM_CHAIN_WORD_STRIDE 16 /* 64-bit words between the ticket words of neighbouring tiles: a 128-byte line each (10.28 - 10.30 us
                                     per step against 10.41 - 10.48 with the words packed: atomics of neighbouring tiles do not queue on one line) */
@@ -647,8 +644,10 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
 #if defined(POM_CHAIN_DIAG)
         chain_t1 = (long long)__builtin_readcyclecounter();
 #endif
+        /* stored visits == this visit's number: its turn.  (More can only be seen after a visit has failed and been counted
+         * regardless, below: then nobody waits any more.) */
         int polls = 0;
-        while (((uint32_t)w & POM_CHAIN_COUNT_MASK) != visit && ++polls <= POM_CHAIN_SPIN_LIMIT) { /* wave-uniform */
+        while ((int32_t)pom_chain_visit_distance((uint32_t)w & POM_CHAIN_COUNT_MASK, visit) < 0 && ++polls <= POM_CHAIN_SPIN_LIMIT) { /* wave-uniform */
             __builtin_amdgcn_s_sleep(1);
             w = __hip_atomic_load(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -656,8 +655,12 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         const bool gave_up = ((uint32_t)w & POM_CHAIN_COUNT_MASK) != visit;
         if (gave_up || (was_on != 0u && was_on != xcd)) {
             /* the visit before this one never arrived, or it was stored through another XCD's L2: nothing is stepped, the
-             * host finds the flag and reports the call as failed.  (The tile's word is left as it is: later visitors give up too.) */
-            if (lane == 0) atomicOr(p.chain_err, gave_up ? 1u : 2u);
+             * host finds the flag and reports the call as failed (the batch is then in an undefined state).  The visit is still
+             * counted as stored, so that the tile's later visitors do not each wait their limit out. */
+            if (lane == 0) {
+                atomicOr(p.chain_err, gave_up ? 1u : 2u);
+                __hip_atomic_fetch_add(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             return;
         }
 #if defined(POM_CHAIN_DIAG)
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
 #endif
         chain_done = 1ull + ((unsigned long long)(xcd - was_on) << 32);
         /* the loads below are issued after the word has been seen: the record they fetch is the stored one */
-        load_tile16_x4<POM_REC_DWORDS, POM_CHAIN_LOAD_AUX>(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane);
+        load_tile16_x4<POM_REC_DWORDS, 16>(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane);
     } else if (EPW == 16) load_tile16_x4(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane); /* 16-byte pieces, 7 instructions of 1 KB */
     else load_tile<EPW>(col_d, POM_TILE_ENVS, tile, sub);
     uint32_t m0 = 0, m1 = 0; /* POLICY: this lane's agent's memory */
@@ -919,11 +922,9 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
          * see through, so that they are computed here */
         int lane_late = lane;
         asm volatile("" : "+v"(lane_late));
-#if defined(POM_STORE_NT_ALL)
-        store_tile16_x4<true>(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane_late);
-#else
+        /* chained: with the non-temporal hint (-2.5 % per step: the stores are acknowledged sooner and the wavefront's slot is free
+         * sooner; on the sub-batch kernels' stores, or on the loads, the hint gains nothing or loses) */
         store_tile16_x4<CHAIN>(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane_late);
-#endif
     } else {
         store_tile<EPW>(col_d, POM_TILE_ENVS, tile, sub, el);
     }
