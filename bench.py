@@ -662,8 +662,9 @@ def worker(args) -> None:
                 # same clock.  Bytes the kernel does not move — the device record is packed to 448 B — so not a utilisation (it can
                 # pass 1.0); kept because rounds 1-2 reported it as `frac`.
                 "contract_achieved": contract, "contract_frac": contract / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": algo_bytes,
-                "limited_by": ("per-wavefront instruction latency (one round of 4 wavefronts per SIMD); with chained launches a tile's next tick "
-                               "no longer waits for the slowest wavefront of the whole launch: DESIGN.md §4, SQ / I-cache counters in profiles/"
+                "limited_by": ("with chained launches a tile's next tick no longer waits for the slowest wavefront of the whole launch; what is "
+                               "left is shared between the memory system (933 B moved per env-step: 8 TB/s would be 8.6 G env-steps/s) and the "
+                               "wavefronts' own instruction latency (4 per SIMD): DESIGN.md §4, SQ / I-cache counters in profiles/"
                                if issue == "chain" else
                                "instruction issue and the slowest wavefront of a launch (one round of 4 wavefronts per SIMD), not HBM: "
                                "DESIGN.md §4, SQ / I-cache counters in profiles/"),
