@@ -55,7 +55,7 @@ static bool chain_setup(PomChain* c, int64_t tiles, hipStream_t stream)
     if (c->tried) return c->ok;
     c->tried = true;
 #if defined(POM_CHAIN_DIAG)
-    const size_t words = (size_t)tiles * (POM_CHAIN_WORD_STRIDE + 20); /* + 20 diagnostic words per tile */
+    const size_t words = (size_t)tiles * (POM_CHAIN_WORD_STRIDE + 68); /* + 68 diagnostic words per tile */
 #else
     const size_t words = (size_t)tiles * POM_CHAIN_WORD_STRIDE;
 #endif

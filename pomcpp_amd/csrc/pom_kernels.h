@@ -933,9 +933,9 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         if (lane == 0) __hip_atomic_fetch_add(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, chain_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(POM_CHAIN_DIAG)
         if (lane == 0) { /* per tile, summed over launches: cycles to the ticket, cycles polling, cycles in all, polls */
-            unsigned long long* d = p.tile_seq + (p.block_end - p.block0) * POM_CHAIN_WORD_STRIDE + 20 * tile_id;
-            d[4 + 2 * (chain_visit & 7)] = (unsigned long long)chain_rt0; /* the last 8 visits: start and end on the 100 MHz clock */
-            d[5 + 2 * (chain_visit & 7)] = (unsigned long long)wall_clock64();
+            unsigned long long* d = p.tile_seq + (p.block_end - p.block0) * POM_CHAIN_WORD_STRIDE + 68 * tile_id;
+            d[4 + 2 * (chain_visit & 31)] = (unsigned long long)chain_rt0; /* the last 32 visits: start and end on the 100 MHz clock */
+            d[5 + 2 * (chain_visit & 31)] = (unsigned long long)wall_clock64();
             d[0] += (unsigned long long)(chain_t1 - chain_t0);
             d[1] += (unsigned long long)(chain_t2 - chain_t1);
             d[2] += (unsigned long long)((long long)__builtin_readcyclecounter() - chain_t0);

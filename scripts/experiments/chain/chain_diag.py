@@ -19,7 +19,7 @@ env.make_game(pa.make_boards(N, seed=1, kind="ffa"))
 env.step_random(1, 1, ticks=300)
 L = B.load_library()
 tiles = (N + 63) // 64 * 64 // 16
-buf = np.zeros((tiles, 20), dtype=np.uint64)
+buf = np.zeros((tiles, 68), dtype=np.uint64)
 L.pom_chain_diag_read.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
 assert L.pom_chain_diag_read(env._h, buf.ctypes.data, tiles) == 0
 for steps in (tuple(int(x) for x in os.environ["POM_STEPS"].split(",")) if "POM_STEPS" in os.environ else (20, 500)):
@@ -32,9 +32,11 @@ for steps in (tuple(int(x) for x in os.environ["POM_STEPS"].split(",")) if "POM_
     b = buf[: N // 16].astype(np.float64) / steps
     print(f"{N} envs, {steps} steps: {dt:.2f} us per step; per wavefront-tick (shader cycles): to the ticket {b[:,0].mean():.0f}, polling {b[:,1].mean():.0f} "
           f"({b[:,3].mean():.2f} polls), in all {b[:,2].mean():.0f}; by tile: in-all p50 {np.percentile(b[:,2],50):.0f} p99 {np.percentile(b[:,2],99):.0f}")
-    # the last 8 visits of every tile: when did the wavefronts of a launch start and end (us, relative to the earliest start)?
+    # the last 32 visits of every tile: when did the wavefronts of a launch start and end (us, relative to the earliest start)?
     st = buf[: N // 16, 4::2].astype(np.int64)
     en = buf[: N // 16, 5::2].astype(np.int64)
+    used = st.min(axis=0) > 0
+    st, en = st[:, used], en[:, used]
     order = np.argsort(st.min(axis=0))
     t00 = st.min()
     for k in order:
