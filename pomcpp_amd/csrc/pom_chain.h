@@ -39,6 +39,8 @@ struct PomChain {
     uint32_t visits = 0;                    /* visits every tile has had since its word was last zeroed */
     uint32_t turn = 0;                      /* which stream the next launch goes to */
     bool unverified = false;                /* chained launches since the visit counts were last checked */
+    StepParams last_key;                    /* what the chained launches possibly still in flight were launched with (tick0 = the */
+    void (*last_kernel)(StepParams) = nullptr; /* offset between ticks and visits), and which instantiation */
 };
 
 static void chain_destroy(PomChain* c)

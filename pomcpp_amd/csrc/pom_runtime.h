@@ -623,7 +623,11 @@ static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bo
         HIPCHK(hipMemsetAsync(c->tile_seq, 0, (size_t)tiles * 8 * POM_CHAIN_WORD_STRIDE, h->stream));
         c->visits = 0;
     }
-    if (int rc = fork_parts(h, POM_KIND_CHAIN)) return rc;
+    static const PomStepKernel chained[8] = {
+        pom_step_kernel<16, 4, false, false, false, true, true>, pom_step_kernel<16, 4, false, false, true, true, true>,
+        pom_step_kernel<16, 4, false, true, false, true, true>,  pom_step_kernel<16, 4, false, true, true, true, true>,
+        pom_step_kernel<16, 4, true, false, false, true, true>,  pom_step_kernel<16, 4, true, false, true, true, true>,
+        pom_step_kernel<16, 4, true, true, false, true, true>,   pom_step_kernel<16, 4, true, true, true, true, true>};
     StepParams p = p0; /* the same for every launch of the call: which tick a wavefront plays follows from its ticket */
     p.block0 = 0;
     p.block_end = tiles;
@@ -631,12 +635,21 @@ static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bo
     p.tile_seq = c->tile_seq;
     p.chain_err = c->err_dev;
     p.chain_seq0 = c->visits;
-    static const PomStepKernel chained[8] = {
-        pom_step_kernel<16, 4, false, false, false, true, true>, pom_step_kernel<16, 4, false, false, true, true, true>,
-        pom_step_kernel<16, 4, false, true, false, true, true>,  pom_step_kernel<16, 4, false, true, true, true, true>,
-        pom_step_kernel<16, 4, true, false, false, true, true>,  pom_step_kernel<16, 4, true, false, true, true, true>,
-        pom_step_kernel<16, 4, true, true, false, true, true>,   pom_step_kernel<16, 4, true, true, true, true, true>};
     const PomStepKernel kernel = chained[(runs_fresh(h) ? 4 : 0) | (policy ? 2 : 0) | (runs_at_end(h) ? 1 : 0)];
+    /* Launches in flight together must be interchangeable — "the j-th visitor of a tile plays the tile's j-th tick" holds only
+     * if every launch would play that tick the same way: the same kernel, seed, move distribution, mode ... and the same offset
+     * between ticks and visits.  A call that differs in any of that from the chained launches still in flight waits for them
+     * (tests/test_gpu_chain.py: random sequences of calls with a seed of their own each). */
+    {
+        StepParams key = p;
+        key.tick0 = p.tick0 - p.chain_seq0;
+        key.chain_seq0 = 0;
+        if (h->forked && h->last_kind == POM_KIND_CHAIN && (kernel != c->last_kernel || memcmp(&key, &c->last_key, sizeof key) != 0))
+            if (int jr = join_parts(h)) return jr;
+        c->last_key = key;
+        c->last_kernel = kernel;
+    }
+    if (int rc = fork_parts(h, POM_KIND_CHAIN)) return rc;
     const dim3 grid((unsigned)(((tiles + POM_WPB - 1) / POM_WPB + 7) / 8 * 8)); /* a multiple of 8: every XCD gets as many workgroups as it has tiles */
     /* how many streams: a third launch in flight pays once the pipeline runs (65,536 envs, per step: 400-tick call 9.1 us on
      * three streams against 9.9 on two, 60 ticks 10.1 / 10.7) and costs while it fills and drains (20 ticks 12.8 / 12.5, 10 ticks
@@ -666,6 +679,7 @@ static int launch_many(PomBatch* h, uint64_t seed, int dist, int launches, int t
     int done = 0;
     if (runs_chain(h, policy, ticks_per_launch) && launches >= 1) {
         StepParams p;
+        memset(&p, 0, sizeof p); /* consecutive calls' parameters are compared byte for byte */
         if (int rc = fill_params(h, p, nullptr, seed, dist, 1)) return rc;
         bool used = false;
         if (int rc = launch_many_chain(h, p, launches, policy, &used)) return rc;

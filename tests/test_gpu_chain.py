@@ -168,3 +168,64 @@ print("ok")
 ''' % ROOT
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, POM_CHAIN_RESET_AT="50"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("auto_reset,fresh", [(True, False), (RESET_AT_END, False), (True, True)])
+def test_random_api_sequences_chained_against_plain(hip_lib, auto_reset, fresh):
+    """Differential: the same seeded random sequence of calls on a handle with chained launches and on a twin that never chains
+    (one stream, plain launches; compared with the oracle by the other suites).  Steps of every kind, several-tick-per-launch
+    calls, stream changes, snapshots, partial uploads, tick changes and reads in between — states, status, counters, agent memory
+    and episode counts must never differ."""
+    n = 1777
+    start = pa.make_boards(n, seed=21)
+    for seq in range(6):
+        rng = np.random.default_rng(1000 * seq + (7 if fresh else 0) + int(auto_reset))
+        kw = dict(mode=MODE_ENV, auto_reset=auto_reset, max_steps=300, fresh_boards=fresh, board_seed=5)
+        with BatchEnvironment(n, issue_mode=ISSUE_CHAIN, streams=int(rng.integers(2, 5)), **kw) as a, \
+             BatchEnvironment(n, issue_mode=ISSUE_THREADS, streams=1, **kw) as b:
+            for e in (a, b):
+                if fresh:
+                    e.generate(5)
+                else:
+                    e.make_game(start)
+            for op in range(14):
+                kind = int(rng.integers(0, 10))
+                seed, ticks = int(rng.integers(1, 1 << 30)), int(rng.integers(1, 50))
+                if kind <= 2:
+                    for e in (a, b):
+                        e.step_random(seed, DIST_RANDOM, ticks=ticks)
+                elif kind == 3:
+                    tpl = int(rng.integers(2, 5))
+                    for e in (a, b):
+                        e.step_random(seed, DIST_STRESS, ticks=tpl * (1 + ticks // 8), ticks_per_launch=tpl)
+                elif kind == 4:
+                    for e in (a, b):
+                        e.step_simple(seed, 1 + ticks // 4)
+                elif kind == 5:
+                    mv = rng.integers(0, 6, size=(n, 4), dtype=np.int32)
+                    for e in (a, b):
+                        e.step(mv)
+                elif kind == 6:
+                    a.set_streams(int(rng.integers(1, 6)))
+                    tick = int(rng.integers(0, 1000))
+                    for e in (a, b):
+                        e.set_tick(tick)
+                elif kind == 7 and not fresh:
+                    for e in (a, b):
+                        e.snapshot()
+                elif kind == 8 and not fresh:
+                    first, count = int(rng.integers(0, n - 200)), int(rng.integers(1, 200))
+                    for e in (a, b):
+                        e.make_game(np.ascontiguousarray(start[first:first + count]), first=first)
+                else:
+                    sa, sb = a.status(), b.status()
+                    assert all(np.array_equal(sa[k], sb[k]) for k in sa), (seq, op)
+                if op % 4 == 3:
+                    assert _same(a.get_state(), b.get_state()), (seq, op, kind)
+            assert _same(a.get_state(), b.get_state()), seq
+            assert np.array_equal(a.counters(), b.counters()), seq
+            assert np.array_equal(a.policy_memory(), b.policy_memory()), seq
+            assert np.array_equal(a.episodes(), b.episodes()), seq
+            if auto_reset == RESET_AT_END:
+                ra, rb = a.last_results(), b.last_results()
+                assert all(np.array_equal(ra[k], rb[k]) for k in ra), seq
