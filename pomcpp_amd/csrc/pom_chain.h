@@ -17,6 +17,9 @@
  * after the previous packet's, whatever the occupancy: chain_diag.py), so the XCDs drift apart but no tile ever sees an early
  * successor.  Different queues overlap freely, hence the streams.
  *
+ * Launches that are in flight together must be interchangeable (the same instantiation, seed, distribution, mode, offset between
+ * ticks and visits): launch_many_chain joins the streams before a call that differs from the launches still in flight.
+ *
  * What is relied on, and how each point is checked at run time:
  *  - a tile is always handled by the same XCD (workgroup id -> XCD round-robin, the same grid every launch): its record then
  *    goes from tick to tick through ONE L2 with no cache maintenance; the loads bypass the CU's vector cache (sc1).  The kernel
