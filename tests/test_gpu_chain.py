@@ -178,7 +178,7 @@ def test_random_api_sequences_chained_against_plain(hip_lib, auto_reset, fresh):
     and episode counts must never differ."""
     n = 1777
     start = pa.make_boards(n, seed=21)
-    for seq in range(6):
+    for seq in range(8):
         rng = np.random.default_rng(1000 * seq + (7 if fresh else 0) + int(auto_reset))
         kw = dict(mode=MODE_ENV, auto_reset=auto_reset, max_steps=300, fresh_boards=fresh, board_seed=5)
         with BatchEnvironment(n, issue_mode=ISSUE_CHAIN, streams=int(rng.integers(2, 5)), **kw) as a, \
@@ -217,6 +217,10 @@ def test_random_api_sequences_chained_against_plain(hip_lib, auto_reset, fresh):
                     first, count = int(rng.integers(0, n - 200)), int(rng.integers(1, 200))
                     for e in (a, b):
                         e.make_game(np.ascontiguousarray(start[first:first + count]), first=first)
+                elif kind == 9 and op % 2:
+                    for e in (a, b):  # the two-kernel form of a SimpleAgent tick: policy into the move buffer, then the step
+                        e.policy_simple(seed)
+                        e.step_policy()
                 else:
                     sa, sb = a.status(), b.status()
                     assert all(np.array_equal(sa[k], sb[k]) for k in sa), (seq, op)
