@@ -334,3 +334,32 @@ def test_issue_modes_give_identical_results(hip_lib, oracle, mode, streams):
         assert np.array_equal(env.policy_memory(), mems)
     with pytest.raises(PomError):
         BatchEnvironment(64, issue_mode=7)
+
+
+def test_one_state_path_from_several_threads(hip_lib, oracle):
+    """pom_step is safe to call from several threads (it serialises them: one pinned page, one stream, a mutex) — the reference's
+    Step is re-entrant over distinct States (performance_test.cpp:71-94 steps one env per std::thread)."""
+    import threading
+    from pomcpp_amd.batch import step_one
+    n_threads, ticks = 6, 120
+    states = [pa.make_boards(1, seed=40 + k, kind="stress") for k in range(n_threads)]
+    refs = [s.copy() for s in states]
+    moves = [np.random.default_rng(k).integers(0, 6, size=(ticks, 4), dtype=np.int32) for k in range(n_threads)]
+    errors = []
+
+    def play(k):
+        try:
+            for t in range(ticks):
+                step_one(states[k], moves[k][t])
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+    th = [threading.Thread(target=play, args=(k,)) for k in range(n_threads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+    for k in range(n_threads):
+        for t in range(ticks):
+            oracle.step(refs[k], moves[k][t])
+        assert _digest(states[k]) == _digest(refs[k]), k
