@@ -677,6 +677,9 @@ def worker(args) -> None:
                 # launches of consecutive ticks overlap on the device: a launch then lasts longer than the step period, and
                 # `achieved` above (bytes per step over the period) is the figure that says what the memory system sees
                 "launches_per_step": parts,
+                # mean launch duration x launches per step / step period: how many launches are in flight on the device on average
+                # (1 = launches one after the other; chained launches of consecutive ticks overlap: 2 - 3)
+                "launches_in_flight": (launch_ms * parts / ms_per_step) if (launch_ms > 0 and ms_per_step > 0) else None,
                 "launch": {"envs": plan["n_envs"] // parts, "hbm_bytes": moved // parts, "algorithmic_bytes": algo_bytes // parts,
                            "packed_bytes": footprint // parts, "ms": launch_ms, "timed_launches": n_launch,
                            "achieved": (moved / parts) / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else None,
