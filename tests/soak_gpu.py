@@ -19,6 +19,7 @@ ap.add_argument("--ticks", type=int, default=20000)
 ap.add_argument("--policy-ticks", type=int, default=3000)
 ap.add_argument("--chunk", type=int, default=16, help="ticks between comparisons (random-move configurations)")
 ap.add_argument("--policy-chunk", type=int, default=20)
+ap.add_argument("--seed", type=int, default=101, help="move-stream seed (board seeds follow from it)")
 a = ap.parse_args()
 ora = Oracle()
 N, cap = 65536, 800
@@ -29,7 +30,7 @@ for name, fresh, kind, dist, at_end in (("replay, ffa, random moves", False, "ff
                                         ("replay, stress boards, stress moves", False, "stress", 2, False),
                                         ("replay, reset at the END of the tick, ffa, random moves", False, "ffa", 1, True),
                                         ("replay, reset at the END of the tick, stress", False, "stress", 2, True)):
-    seed, bseed = 101, 202
+    seed, bseed = a.seed, 2 * a.seed
     env = BatchEnvironment(N, mode=MODE_ENV, auto_reset=RESET_AT_END if at_end else True, max_steps=cap, fresh_boards=fresh,
                            board_seed=bseed, streams=(2, 3)[len(name) % 2])
     if fresh:
@@ -72,7 +73,7 @@ for name, fresh, kind, dist, at_end in (("replay, ffa, random moves", False, "ff
           f"({int((ub != 0).sum())} envs flagged now); 4 slices of 384 envs = oracle every {a.chunk} ticks", flush=True)
     env.close()
 # SimpleAgent games with fresh boards
-seed, bseed = 7, 9
+seed, bseed = (7, 9) if a.seed == 101 else (a.seed + 6, a.seed + 8)
 env = BatchEnvironment(N, mode=MODE_ENV, auto_reset=True, max_steps=cap, fresh_boards=True, board_seed=bseed)
 env.generate(bseed)
 pslices = [(0, 192), (30000, 192), (N - 192, 192)]
