@@ -233,3 +233,24 @@ def test_random_api_sequences_chained_against_plain(hip_lib, auto_reset, fresh):
             if auto_reset == RESET_AT_END:
                 ra, rb = a.last_results(), b.last_results()
                 assert all(np.array_equal(ra[k], rb[k]) for k in ra), seq
+
+
+def test_full_size_chained_against_plain(hip_lib):
+    """65,536 envs (the headline's size: every wavefront slot of the chip taken by one launch, so launches really queue behind each
+    other): long and short chained calls, stress moves, the fused SimpleAgent kernel, against a twin that never chains."""
+    n = 65536
+    start = pa.make_boards(n, seed=33, kind="stress")
+    kw = dict(mode=MODE_ENV, auto_reset=True, max_steps=800)
+    with BatchEnvironment(n, **kw) as a, BatchEnvironment(n, issue_mode=ISSUE_THREADS, streams=1, **kw) as b:
+        assert a.issue_info()[0] == "chain" and b.issue_info()[0] == "threads"
+        for e in (a, b):
+            e.make_game(start)
+            e.step_random(5, DIST_STRESS, ticks=130)   # three streams
+            e.step_random(5, DIST_STRESS, ticks=9)     # two streams, in flight together with the call before
+            e.step_random(6, DIST_RANDOM, ticks=45)    # another seed: waits for the launches before it
+            e.step_simple(6, 25)
+            e.step_random(6, DIST_RANDOM, ticks=3)
+        assert _same(a.get_state(), b.get_state())
+        assert np.array_equal(a.counters(), b.counters()) and np.array_equal(a.policy_memory(), b.policy_memory())
+        sa, sb = a.status(), b.status()
+        assert all(np.array_equal(sa[k], sb[k]) for k in sa)
