@@ -544,8 +544,8 @@ int pom_chain_diag_read(PomBatch* h, unsigned long long* out, int64_t tiles)
     if (!h || !h->chain.tile_seq || tiles != h->n_pad / h->epw) return POM_E_ARG;
     if (int jr = join_parts(h)) return jr;
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(out, h->chain.tile_seq + tiles * POM_CHAIN_WORD_STRIDE, (size_t)tiles * 160, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(h->chain.tile_seq + tiles * POM_CHAIN_WORD_STRIDE, 0, (size_t)tiles * 160));
+    HIPCHK(hipMemcpy(out, h->chain.tile_seq + tiles * POM_CHAIN_WORD_STRIDE, (size_t)tiles * 544, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->chain.tile_seq + tiles * POM_CHAIN_WORD_STRIDE, 0, (size_t)tiles * 544));
     HIPCHK(hipDeviceSynchronize());
     return POM_OK;
 }
