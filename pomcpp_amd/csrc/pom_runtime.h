@@ -281,13 +281,17 @@ static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int
 }
 
 /* ---- several ticks in one call ---------------------------------------------------------------------------------------------
- * A step is `parts` launches (one per sub-batch, on parallel streams) every ~16 us at 65,536 envs: the host has ~5 us per
+ * The default up to 196,608 envs is POM_ISSUE_CHAIN (launch_many_chain below, pom_chain.h): one launch over all tiles per tick,
+ * consecutive launches on different streams, a ticket word per tile ordering the tile's ticks — 9.2 us per step at 65,536 envs
+ * where sub-batches take 14.5.  What follows is how SUB-BATCH launches are issued: what a handle does where launches are not
+ * chained (several ticks per launch, batches from 196,608 envs up, the one-lane-per-env shapes, a handle asked for another mode).
+ * A step is then `parts` launches (one per sub-batch, on parallel streams) every ~16 us at 65,536 envs: the host has ~5 us per
  * launch, and a call of K ticks is judged by how soon all parts' first launches are out and whether the queues stay fed.
  * Three ways to issue them (PomBatchOptions.issue_mode; results cannot depend on the choice: the same kernels with the same
  * arguments go to the same streams in the same per-stream order).  Measured on MI355X, 65,536 envs, 3 parts, per step
  * (profiles/r03_issue_modes.txt):
  *                                   20-tick call from an idle device (the bench driver's shape)      500-tick call
- *   POM_ISSUE_THREADS (default)     18.0 us, run to run the same                                      15.5 us
+ *   POM_ISSUE_THREADS               18.0 us, run to run the same                                      15.5 us
  *   POM_ISSUE_DIRECT                17.2 .. 26.4 us: one thread issues all 60 launches (2.8 us each   15.6 - 16.0 us
  *                                   on a quiet host, then it is ahead of the device; on a busy one it is not)
  *   POM_ISSUE_GRAPH                 21.4 .. 23.5 us: queued in 48 us, but the replayed nodes run with   16.1 - 16.2 us
