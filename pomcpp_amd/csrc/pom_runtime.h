@@ -617,7 +617,12 @@ static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bo
     if (!c->tried) { /* the words are zeroed on the caller's stream: the sub-streams must be forked after that, not before */
         if (int jr = join_parts(h)) return jr;
     }
-    if (!chain_setup(c, tiles, h->stream)) return POM_OK;
+    if (!chain_setup(c, tiles, h->stream)) {
+        if (getenv("POM_CHAIN_VERBOSE"))
+            fprintf(stderr, "pom: chained launches are not available on this device (allocation failed or the workgroup -> XCD probe did not find the "
+                            "eight-XCD round-robin); launching sub-batches\n");
+        return POM_OK;
+    }
     if (int rc = chain_check(h)) return rc;
     /* the fields of the tile words must not run into each other: after 2^27 visits (20 minutes of stepping) the words start over.
      * (POM_CHAIN_RESET_AT: a smaller number, so that tests get to see it happen) */
