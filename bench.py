@@ -456,9 +456,18 @@ def worker(args) -> None:
     elapsed = timed_region(run_steps, args.steps, barrier, counters_allreduce if reduce_in_region else None)
     elapsed = reduce_max(elapsed, device, dist)
     if not reduce_in_region:  # one GPU: bookkeeping after the region (what the K steps did)
+        env.sync()  # (also the check behind chained launches: a tile a wavefront could not play is caught up, and counted, here)
         env.counters_into(counters.data_ptr())
         torch.cuda.synchronize()
     total_steps = int(counters[CNT_STEPS].item())
+    if reduce_in_region and total_steps != plan["global_envs"] * args.steps * tpl:
+        # the in-region reduction does not block, so it cannot run that check: should a tile have been left behind (never seen), every
+        # rank sees the same short total and all of them reduce again after catching up
+        env.sync()
+        env.counters_into(counters.data_ptr())
+        torch.cuda.synchronize()
+        reduce_counters(counters, dist)
+        total_steps = int(counters[CNT_STEPS].item())
     episodes_finished = int(counters[1].item())
     # the same number of steps again between two HIP events on the launch stream (untimed: the events and the join they need
     # would add their own latency to the region above): GPU-side time per step, all launches of a step
@@ -545,7 +554,22 @@ def worker(args) -> None:
         ev7.record(stream)
         e3.sync()
         ms_x = ev6.elapsed_time(ev7) / n_x
+        # the same moves as a K-tick TAPE (pom_batch_step_device_many): Step(State*, Move[4]) with the moves fixed K ticks ahead — replays,
+        # open-loop rollouts — issued as chained launches like the headline (the kernel reads tick d of the tape by its ticket)
+        n_tape = 200
+        tape = torch.randint(0, 6, (n_tape, plan["n_envs"], 4), dtype=torch.int32, device=device, generator=gen)
+        torch.cuda.synchronize()
+        e3.step_device_many(tape)
+        e3.sync()
+        ev6.record(stream)
+        e3.step_device_many(tape)
+        e3.flush()
+        ev7.record(stream)
+        e3.sync()
+        ms_tape = ev6.elapsed_time(ev7) / n_tape
+        tape_stats = e3.chain_stats()
         e3.close()
+        del tape
         # Throughput mode: ticks_per_launch = T > 1 keeps the record in LDS for T ticks (synthetic move stream only) —
         # NOT the canonical roofline run (a step there is one HBM round trip per tick); reported on its own, per tick
         for name, n_o, t_o in (("throughput_T4_65536_envs", 65536, 4), ("throughput_T16_65536_envs", 65536, 16),
@@ -582,12 +606,97 @@ def worker(args) -> None:
             mv1[0] = k % 5  # HarmlessAgent's range: no bombs
             lib1.pom_step(p_state, p_moves)
         us_l = (time.perf_counter() - t_l) / n_l * 1e6
-        other["single_env_pom_step"] = {"value": 1e6 / us_l, "unit": "env-steps/s", "us_per_call": us_l, "calls": n_l,
+        threads8 = None
+        try:  # eight native threads, a State each (tests/cpp/step_threads.cpp), as performance_test.cpp:71-94 steps one env per std::thread
+            import tempfile
+            exe = entry.build_step_threads()
+            with tempfile.TemporaryDirectory() as td:
+                nt, calls = 8, 2000
+                start[:nt].tofile(os.path.join(td, "s.bin"))
+                np.random.default_rng(1).integers(0, 5, size=(nt, calls, 4), dtype=np.int32).tofile(os.path.join(td, "m.bin"))
+                out_t = subprocess.run([exe, str(nt), str(calls), os.path.join(td, "s.bin"), os.path.join(td, "m.bin")], capture_output=True,
+                                       text=True, timeout=120)
+                rt = json.loads(out_t.stdout.strip().splitlines()[-1])
+                threads8 = {"threads": nt, "calls_per_s_1_thread": rt["calls_per_s_1_thread"], "calls_per_s_all_threads": rt["calls_per_s_all_threads"],
+                            "speedup": rt["calls_per_s_all_threads"] / rt["calls_per_s_1_thread"]}
+        except Exception as exc:  # the figure is context, not the headline
+            threads8 = {"failed": f"{type(exc).__name__}: {str(exc)[:120]}"}
+        other["single_env_pom_step"] = {"value": 1e6 / us_l, "unit": "env-steps/s", "us_per_call": us_l, "calls": n_l, "native_threads": threads8,
                                         "note": "pom_step(State*, Move[4]) on ONE env: one launch reads the host State, steps it and writes "
                                                 "it back, blocking; the batch API is the product, this is the literal bboard::Step replacement"}
+        other["explicit_moves_device_chained_65536_envs"] = {
+            "value": plan["n_envs"] / (ms_tape * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_tape, "steps": n_tape,
+            "chain_tiles_recovered": tape_stats["tiles_recovered"],
+            "note": "pom_batch_step_device_many with auto_reset = POM_RESET_AT_END: a 200-tick Move[4] tape in device memory, chained launches "
+                    "(one launch over all tiles per tick on rotating streams, the tile's ticket picks the tape's tick)"}
         other["explicit_moves_device_65536_envs"] = {
             "value": plan["n_envs"] / (ms_x * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_x, "steps": n_x,
             "note": "pom_batch_step_device with auto_reset = POM_RESET_AT_END: Move[4] from device memory, one launch per tick on the caller's stream"}
+    if other is not None:
+        # what a LONG call reaches (the timed region above is the driver's shape, a few hundred microseconds from an idle device: a fifth
+        # of it is the pipeline filling and draining): 500 steps in one call, HIP events on the launch stream
+        traffic_65536 = None
+        tjp = os.path.join(ROOT, TRAFFIC_JSON)
+        if os.path.exists(tjp):
+            traffic_65536 = json.load(open(tjp))["hbm_bytes_per_step"]
+        evA, evB = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        env.make_game(start)  # (config 3 above left SimpleAgent games in the batch)
+        env.set_tick(0)
+        run_steps(args.burn_in)
+        env.sync()
+        evA.record(stream)
+        run_steps(500)
+        env.flush()
+        evB.record(stream)
+        env.sync()
+        ms_500 = evA.elapsed_time(evB) / 500
+        moved_500 = traffic_65536 or PACKED_BYTES_PER_STEP * plan["n_envs"]
+        other["headline_500_steps"] = {
+            "value": plan["n_envs"] / (ms_500 * 1e-3), "unit": "env-steps/s", "us_per_step": ms_500 * 1e3, "steps": 500,
+            "bytes_per_step": moved_500, "achieved_GBps": moved_500 / (ms_500 * 1e-3) / 1e9, "frac": moved_500 / (ms_500 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "cache_resident": True,
+            "note": "the headline workload in one 500-step call (chained launches, three streams); bytes = the committed PMC figure "
+                    "(L2 <-> fabric: FETCH_SIZE x 2 + WRITE_SIZE); state + snapshot (59 MB) sit inside the 256 MiB memory-side cache"}
+        # beyond the memory-side cache: 1,048,576 envs = 470 MB of state (+ 470 MB of snapshots): every step streams the records from and
+        # to HBM proper.  Boards drawn on the device (same distribution), snapshot replay, sub-batches on parallel streams.
+        n_big = 1048576
+        eb = BatchEnvironment(n_big, device=local_rank, mode=MODE_ENV, auto_reset=True, max_steps=args.max_steps, stream=stream.cuda_stream)
+        eb.generate(args.seed)
+        eb.step_random(args.seed, dist_id, ticks=300)
+        eb.sync()
+        evA.record(stream)
+        eb.step_random(args.seed, dist_id, ticks=60)
+        eb.flush()
+        evB.record(stream)
+        eb.sync()
+        ms_big = evA.elapsed_time(evB) / 60
+        big_issue = eb.issue_info()
+        eb.close()
+        moved_big = (traffic_65536 or PACKED_BYTES_PER_STEP * 65536) * (n_big // 65536)
+        other["headline_1048576_envs"] = {
+            "value": n_big / (ms_big * 1e-3), "unit": "env-steps/s", "us_per_step": ms_big * 1e3, "steps": 60, "issue": big_issue[0],
+            "bytes_per_step": moved_big, "achieved_GBps": moved_big / (ms_big * 1e-3) / 1e9, "frac": moved_big / (ms_big * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "cache_resident": False,
+            "note": "1,048,576 envs: 470 MB of records, 4 x the memory-side cache — the fraction of the HBM peak proper; bytes = the "
+                    "65,536-env PMC figure per env"}
+    # like-for-like base of an N > 1 line: this rank's shard stepped while the other ranks' GPUs idle (same envs per GPU, same kernels)
+    single_base = None
+    if world > 1:
+        barrier()
+        if rank == 0:
+            evA, evB = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            run_steps(args.warmup)
+            env.sync()
+            evA.record(stream)
+            run_steps(args.steps)
+            env.flush()
+            evB.record(stream)
+            env.sync()
+            ms_b = evA.elapsed_time(evB) / args.steps
+            single_base = {"value": plan["n_envs"] / (ms_b * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_b, "steps": args.steps,
+                           "note": f"rank 0's shard ({plan['n_envs']} envs) stepped alone while the other ranks wait: what `--gpus 1 --envs "
+                                   f"{plan['n_envs']}` measures (HIP events); N x this is the linear-scaling line"}
+        barrier()
     expect = plan["global_envs"] * args.steps * tpl
     if total_steps != expect:
         raise SystemExit(f"step counter {total_steps} != envs x ticks {expect}")
@@ -649,11 +758,17 @@ def worker(args) -> None:
                 "per_gpu_batch_note": (f"{ENVS_SINGLE_GPU} envs on one GPU (the headline), {ENVS_PER_GPU_SHARDED} per GPU with several "
                                        "(config 4 = 262,144 envs at 8 GPUs): compare N > 1 lines with `--gpus 1 --envs 32768`"),
                 "episodes_finished": episodes_finished,
+                "single_gpu_base": single_base,
             },
             "roofline": {
                 "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
                 # physical: bytes really moved per step over the clock `value` uses
                 "achieved": hbm, "frac": hbm / HBM_PEAK_GBPS,
+                # what the byte counters see: traffic between the L2s and the fabric (FETCH_SIZE x 2 + WRITE_SIZE), Infinity-Cache hits
+                # included — an upper bound on HBM bytes.  This workload's records (state + snapshot) fit the 256 MiB memory-side cache when
+                # cache_resident is true; other_configs.headline_1048576_envs is the same step with the records streaming from HBM proper
+                "traffic_level": "L2 <-> fabric (EA) bytes; memory-side-cache hits included: an upper bound on HBM bytes",
+                "cache_resident": 2 * footprint < 256 * 2**20,
                 "traffic": traffic, "traffic_source": traffic_source, "traffic_measured_in_run": measured_in_run,
                 "traffic_fallback": bool(args.measure_traffic and not measured_in_run), "traffic_failure": traffic_failure,
                 "hbm_bytes_per_step": moved, "hbm_bytes_kind": "pmc" if traffic is not None else "packed footprint (2 x 448 B per env)",

@@ -90,10 +90,17 @@ enum {
     POM_ISSUE_THREADS = 2, /* one helper thread per internal sub-stream issues that stream's launches (created on first use, joined by
                               pom_batch_destroy; a helper that cannot be started falls back to DIRECT for its part) */
     POM_ISSUE_GRAPH = 3,   /* chunks of 20 ticks replayed as HIP graphs, one per sub-stream; no library-owned thread */
-    POM_ISSUE_CHAIN = 4    /* one launch per tick over the whole batch, on a queue of the library's own whose packets do not wait for
-                              each other: a tile's tick waits for the same tile's previous tick only (pomcpp_amd/csrc/pom_chain.h).
-                              A several-tick call BLOCKS until its ticks are done (HIP streams know nothing of that queue).  For the
-                              replay / no-policy shape; where it cannot be had the launches are issued as with POM_ISSUE_THREADS */
+    POM_ISSUE_CHAIN = 4    /* chained launches (pomcpp_amd/csrc/pom_chain.h): every launch covers the WHOLE batch and plays one tick,
+                              consecutive launches go to different internal HIP streams (two in a short call, three from 40 ticks
+                              up), and a ticket word per 16-env tile orders that tile's ticks — a tile's next tick waits for the
+                              same tile's previous tick only, not for the slowest wavefront of the launch before.  Asynchronous
+                              like the other modes: the call returns when its launches are queued; every other call of this API
+                              joins the streams.  pom_batch_create probes the device once (workgroup -> XCD round-robin over
+                              eight XCDs); where that does not hold, and for shapes without a chained twin (one lane per env,
+                              several ticks per launch, one stream), launches are issued as with POM_ISSUE_THREADS.  A wavefront
+                              that cannot play its tile (its predecessor did not show up within 2 s of wall-clock time) leaves
+                              the tile alone; the next call that reads or changes the batch finds it and replays the tile's
+                              missing ticks with ordinary launches (pom_batch_chain_stats counts such events: expected 0) */
 };
 
 enum { POM_RESET_OFF = 0, POM_RESET_AT_START = 1, POM_RESET_AT_END = 2 };
@@ -126,6 +133,16 @@ int pom_batch_episodes(PomBatch* h, int64_t first, int64_t count, uint32_t* out)
 /* one tick with explicit moves: int32[n_envs][4], host or device memory */
 int pom_batch_step(PomBatch* h, const int32_t* moves_host);
 int pom_batch_step_device(PomBatch* h, const int32_t* moves_dev);
+/* `ticks` ticks of bboard::Step(State*, Move[4]) with explicit moves from a TAPE in device memory, int32[ticks][n_envs][4] (tick t
+ * of env e reads moves_dev[(t * n_envs + e) * 4 ..]; dead agents' entries included): what K calls of pom_batch_step_device with
+ * moves_dev + t * n_envs * 4 do — same states, same counters — but issued as chained launches where the handle chains
+ * (POM_ISSUE_CHAIN; ticks >= 2), i.e. at the speed of pom_batch_step_random instead of one joined launch per tick.  For replays,
+ * open-loop rollouts and planners that fix K moves ahead; a policy that needs the state of tick t to choose the move of tick
+ * t + 1 calls pom_batch_step_device per tick.  The tape is read asynchronously: it was written on the handle's stream (or before
+ * the call) and must stay unchanged until the handle has been synchronised (pom_batch_sync, or any call that reads results
+ * back).  Does not advance the tick of the synthetic move stream.  With POM_RESET_AT_END the caller sees only the last tick's
+ * "finished" marks; winner / length of each env's most recent episode are kept as always. */
+int pom_batch_step_device_many(PomBatch* h, const int32_t* moves_dev, int32_t ticks);
 /* `ticks` ticks with the pom_rng.h move stream (seed, env_offset+env, tick); ticks_per_launch >= 1 keeps
  * the env tile resident in LDS for that many ticks per kernel launch (1 = state round-trips HBM each tick) */
 int pom_batch_step_random(PomBatch* h, uint64_t seed, int32_t dist, int32_t ticks, int32_t ticks_per_launch);
@@ -163,7 +180,8 @@ int pom_batch_last_results(PomBatch* h, int64_t first, int64_t count, int32_t* f
 int pom_batch_download_terminal(PomBatch* h, void* states, int64_t first, int64_t count);
 
 int pom_batch_counters(PomBatch* h, int64_t out[POM_CNT_N]);
-/* same totals left in device memory (int64[POM_CNT_N]) on the handle's stream, e.g. for an RCCL all-reduce */
+/* same totals left in device memory (int64[POM_CNT_N]) on the handle's stream, e.g. for an RCCL all-reduce; does not block
+ * (and therefore does not run the check behind chained launches: a tile caught up later adds its steps later) */
 int pom_batch_counters_device(PomBatch* h, void* dev_int64x4);
 int pom_batch_reset_counters(PomBatch* h);
 int pom_batch_sync(PomBatch* h);
@@ -185,6 +203,10 @@ int pom_batch_launch_shape(PomBatch* h, int32_t* envs_per_wave, int32_t* lanes_p
 /* how the launches of a several-tick call are issued: the POM_ISSUE_* in force (AUTO resolved; POM_ISSUE_CHAIN only while chained
  * launches are available to the handle) and the number of streams they go to */
 int pom_batch_issue_info(PomBatch* h, int32_t* issue_mode, int32_t* streams);
+
+/* chained launches since creation: out[0] launches issued, out[1] checks run (one per join that followed chained launches),
+ * out[2] tiles that a check found left behind by a wavefront that could not play them, out[3] ticks replayed for those tiles */
+int pom_batch_chain_stats(PomBatch* h, int64_t out[4]);
 
 /* the hipStream_t the handle's work is ordered on (the one given at creation, or the library's own), so that a caller can
  * order its own device work against steps and observations with events instead of pom_batch_sync */
@@ -219,10 +241,11 @@ int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_
 
 /* bboard::Step (include/bboard.hpp:668, src/bboard/step.cpp:9-284) for a single host State on the GPU (device 0): the literal
  * drop-in.  One launch per call: the kernel reads the State and Move[4] from a pinned page, plays the tick and writes the State
- * back; the call returns when that is done (tens of microseconds — the launch and the trip over PCIe, not the tick).  ALL
- * callers of the process share that page behind a mutex — calls from several threads are safe but run one after the other,
- * whereas the reference's Step is re-entrant over distinct States (performance_test.cpp:71-94 steps one env per std::thread).
- * Code that steps many States should hand them to one PomBatch (pom_batch_upload / pom_batch_step) instead.
+ * back; the call returns when that is done (about ten microseconds — the launch and the trip over PCIe, not the tick).
+ * Re-entrant over distinct States like the reference's Step (performance_test.cpp:71-94 steps one env per std::thread): every
+ * calling thread gets a pinned page and a stream of its own (up to 64 threads; more share), so threads stepping their own
+ * States do not wait for each other.  Code that steps many States should still hand them to one PomBatch
+ * (pom_batch_upload / pom_batch_step): a launch per State is latency, not throughput.
  * POM_E_UNREPRESENTABLE: the State holds a value the device record cannot hold; it is left as it is. */
 int pom_step(void* state_1004, const int32_t moves[4]);
 

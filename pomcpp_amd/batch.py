@@ -91,6 +91,9 @@ def load_library() -> C.CDLL:
     lib.pom_batch_snapshot.argtypes = [P]
     lib.pom_batch_step.argtypes = [P, VP]
     lib.pom_batch_step_device.argtypes = [P, VP]
+    if not os.environ.get("POM_LIB") or hasattr(lib, "pom_batch_step_device_many"):
+        lib.pom_batch_step_device_many.argtypes = [P, VP, I32]
+        lib.pom_batch_chain_stats.argtypes = [P, VP]
     lib.pom_batch_step_random.argtypes = [P, U64, I32, I32, I32]
     lib.pom_batch_set_tick.argtypes = [P, I64]
     lib.pom_batch_policy_simple.argtypes = [P, U64, VP]
@@ -240,6 +243,32 @@ class BatchEnvironment:
                 raise ValueError(f"moves live on {dev}, the batch on device {self.device}")
             moves = moves.data_ptr()
         _check(self._lib, self._lib.pom_batch_step_device(self._h, int(moves)))
+
+    def step_device_many(self, moves, ticks: Optional[int] = None) -> None:
+        """K ticks with explicit moves from a tape in device memory: a tensor int32[K, n, 4] on this handle's device (or the raw
+        device address of one, with `ticks` = K).  Chained launches where the handle chains (pom_batch_step_device_many)."""
+        if hasattr(moves, "data_ptr"):
+            shape = tuple(getattr(moves, "shape", ()))
+            if len(shape) != 3 or shape[1:] != (self.n, 4) or (ticks is not None and ticks != shape[0]):
+                raise ValueError(f"moves must be int32[ticks, {self.n}, 4] (dead agents included), got shape {shape}")
+            if "int32" not in str(getattr(moves, "dtype", "")):
+                raise ValueError(f"moves must be int32, got {getattr(moves, 'dtype', None)}")
+            if hasattr(moves, "is_contiguous") and not moves.is_contiguous():
+                raise ValueError("moves must be contiguous")
+            dev = getattr(moves, "device", None)
+            if dev is not None and (getattr(dev, "type", "cuda") != "cuda" or getattr(dev, "index", self.device) not in (None, self.device)):
+                raise ValueError(f"moves live on {dev}, the batch on device {self.device}")
+            ticks = shape[0]
+            moves = moves.data_ptr()
+        if ticks is None:
+            raise ValueError("a raw device address needs `ticks`")
+        _check(self._lib, self._lib.pom_batch_step_device_many(self._h, int(moves), int(ticks)))
+
+    def chain_stats(self) -> dict:
+        """chained launches since creation: launches issued, checks run, tiles found left behind, ticks replayed for them"""
+        out = np.zeros(4, dtype=np.int64)
+        _check(self._lib, self._lib.pom_batch_chain_stats(self._h, out.ctypes.data))
+        return dict(zip(("launches", "settles", "tiles_recovered", "ticks_replayed"), (int(v) for v in out)))
 
     def step_random(self, seed: int, dist: int = DIST_RANDOM, ticks: int = 1, ticks_per_launch: int = 1) -> None:
         _check(self._lib, self._lib.pom_batch_step_random(self._h, seed, dist, ticks, ticks_per_launch))

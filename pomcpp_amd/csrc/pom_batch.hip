@@ -3,6 +3,7 @@
  * (INTEGRATION.md).  Kernels: pom_kernels.h; streams, launches and the handle: pom_runtime.h.  gfx950 only; there is no CPU
  * path: without a HIP device pom_batch_create fails with POM_E_HIP.
  */
+#include <atomic>
 #include <mutex>
 
 #include "pom_runtime.h"
@@ -234,6 +235,13 @@ int pom_batch_create(PomBatch** out, int64_t n_envs, const PomBatchOptions* opts
         pom_batch_destroy(h);
         return POM_E_HIP;
     }
+    /* chained launches: the tiles' words and the probe of the workgroup -> XCD pattern, here rather than in the first step (the
+     * probe synchronises the stream); where they cannot be had the handle launches sub-batches */
+    if (h->issue_mode == POM_ISSUE_CHAIN && h->quad && h->chain_parts > 1) {
+        if (!chain_setup(&h->chain, h->n_pad / h->epw, h->stream) && getenv("POM_CHAIN_VERBOSE"))
+            fprintf(stderr, "pom: chained launches are not available on this device (allocation failed or the workgroup -> XCD probe did not find the "
+                            "eight-XCD round-robin); launching sub-batches\n");
+    }
     *out = h;
     return POM_OK;
 }
@@ -246,7 +254,7 @@ int pom_batch_upload(PomBatch* h, const void* states, int64_t first, int64_t cou
     int rc = check_range(h, first, count);
     if (rc || !states) return rc ? rc : POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
+    if (int jr = quiesce(h)) return jr;
     const int big = INT_MAX;
     HIPCHK(hipMemcpyAsync(h->first_bad, &big, sizeof big, hipMemcpyHostToDevice, h->stream));
     int64_t bad_env = -1;
@@ -284,8 +292,7 @@ int pom_batch_download(PomBatch* h, void* states, int64_t first, int64_t count)
     int rc = check_range(h, first, count);
     if (rc || !states) return rc ? rc : POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    if (int vr = chain_verify(h)) return vr;
+    if (int jr = quiesce(h)) return jr;
     for (int64_t off = 0; off < count; off += h->staging_envs) {
         const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
         HIPCHK(hipMemsetAsync(h->staging, 0, (size_t)c * POM_STATE_BYTES, h->stream));
@@ -295,14 +302,14 @@ int pom_batch_download(PomBatch* h, void* states, int64_t first, int64_t count)
                               h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
-    return chain_check(h);
+    return POM_OK;
 }
 
 int pom_batch_snapshot(PomBatch* h)
 {
     if (!h) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
+    if (int jr = quiesce(h)) return jr;
     pom_snapshot_kernel<<<dim3((unsigned)((h->n_pad + 255) / 256)), dim3(256), 0, h->stream>>>(h->state, h->snap, h->n_pad);
     HIPCHK(hipGetLastError());
     return POM_OK;
@@ -317,11 +324,44 @@ int pom_batch_step_device(PomBatch* h, const int32_t* moves_dev)
     return launch_step(h, moves_dev, 0, 0, 1, false, true);
 }
 
+int pom_batch_step_device_many(PomBatch* h, const int32_t* moves_dev, int32_t ticks)
+{
+    if (!h || !moves_dev || ticks < 0) return POM_E_ARG;
+    if (ticks == 0) return POM_OK;
+    HIPCHK(hipSetDevice(h->device));
+    /* chained where the handle chains: one launch over all tiles per tick, the launches on different streams, a tile's visitor at
+     * distance d from the call's first visit reads tick d of the tape (pom_chain.h).  Elsewhere, and for a single tick: plain
+     * launches in a row on the caller's stream, as pom_batch_step_device. */
+    if (ticks >= 2 && runs_chain(h, false, 1)) {
+        StepParams p;
+        memset(&p, 0, sizeof p);
+        if (int rc = fill_params(h, p, moves_dev, 0, 0, 1)) return rc;
+        bool used = false;
+        const uint64_t tick_before = h->tick;
+        const int rc = launch_many_chain(h, p, ticks, false, &used);
+        h->tick = tick_before; /* explicit moves do not advance the tick that keys the synthetic stream (as pom_batch_step_device) */
+        if (rc || used) return rc;
+    }
+    for (int32_t t = 0; t < ticks; t++)
+        if (int rc = launch_step(h, moves_dev + (int64_t)t * h->n * 4, 0, 0, 1, false, true)) return rc;
+    return POM_OK;
+}
+
+int pom_batch_chain_stats(PomBatch* h, int64_t out[4])
+{
+    if (!h || !out) return POM_E_ARG;
+    out[0] = h->chain.stat_launches;
+    out[1] = h->chain.stat_settles;
+    out[2] = h->chain.stat_tiles_recovered;
+    out[3] = h->chain.stat_ticks_replayed;
+    return POM_OK;
+}
+
 int pom_batch_step(PomBatch* h, const int32_t* moves_host)
 {
     if (!h || !moves_host) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    int rc = join_parts(h); /* the previous step's parts still read moves_dev */
+    int rc = quiesce(h); /* the previous step's parts still read moves_dev */
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(h->moves_dev, moves_host, (size_t)h->n * 16, hipMemcpyHostToDevice, h->stream));
     return launch_step(h, h->moves_dev, 0, 0, 1, false, true);
@@ -358,7 +398,7 @@ int pom_batch_status(PomBatch* h, int64_t first, int64_t count, int32_t* done, i
     int rc = check_range(h, first, count);
     if (rc) return rc;
     HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
+    if (int jr = quiesce(h)) return jr;
     void* outs[6] = {done, winner, draw, alive, time_step, ubflags};
     /* the AoS staging buffer doubles as scratch: 6 ints per env << 251 */
     for (int64_t off = 0; off < count; off += h->staging_envs) {
@@ -383,7 +423,7 @@ int pom_batch_last_results(PomBatch* h, int64_t first, int64_t count, int32_t* f
         return POM_E_ARG;
     }
     HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
+    if (int jr = quiesce(h)) return jr;
     void* outs[5] = {finished, winner, draw, length, alive};
     for (int64_t off = 0; off < count; off += h->staging_envs) {
         const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
@@ -407,7 +447,7 @@ int pom_batch_download_terminal(PomBatch* h, void* states, int64_t first, int64_
         return POM_E_ARG;
     }
     HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
+    if (int jr = quiesce(h)) return jr;
     for (int64_t off = 0; off < count; off += h->staging_envs) {
         const int64_t c = count - off < h->staging_envs ? count - off : h->staging_envs;
         HIPCHK(hipMemsetAsync(h->staging, 0, (size_t)c * POM_STATE_BYTES, h->stream));
@@ -433,18 +473,20 @@ int pom_batch_counters_device(PomBatch* h, void* dev_int64x4)
 int pom_batch_counters(PomBatch* h, int64_t out[POM_CNT_N])
 {
     if (!h || !out) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    if (int qr = quiesce(h)) return qr; /* (a tile left behind by chained launches is caught up first: its steps count) */
     int rc = pom_batch_counters_device(h, h->totals_dev);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(out, h->totals_dev, POM_CNT_N * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    return chain_check(h);
+    return POM_OK;
 }
 
 int pom_batch_reset_counters(PomBatch* h)
 {
     if (!h) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
+    if (int jr = quiesce(h)) return jr;
     HIPCHK(hipMemsetAsync(h->wave_counters, 0, (size_t)h->n_waves * POM_CNT_N * 8, h->stream));
     return POM_OK;
 }
@@ -453,10 +495,9 @@ int pom_batch_sync(PomBatch* h)
 {
     if (!h) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
-    if (int vr = chain_verify(h)) return vr;
+    if (int jr = quiesce(h)) return jr;
     HIPCHK(hipStreamSynchronize(h->stream));
-    return chain_check(h);
+    return POM_OK;
 }
 
 int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_agent, int32_t* agent_attrs_dev,
@@ -491,7 +532,7 @@ int pom_batch_generate(PomBatch* h, uint64_t board_seed)
 {
     if (!h) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
+    if (int jr = quiesce(h)) return jr;
     h->board_seed = board_seed;
     pom_generate_kernel<<<dim3((unsigned)((h->n + 15) / 16)), dim3(64), 0, h->stream>>>(h->state, h->snap, h->episode, h->n, h->n_pad,
                                                                                          h->env_offset, board_seed);
@@ -506,7 +547,7 @@ int pom_batch_episodes(PomBatch* h, int64_t first, int64_t count, uint32_t* out)
     int rc = check_range(h, first, count);
     if (rc || !out) return rc ? rc : POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
+    if (int jr = quiesce(h)) return jr;
     HIPCHK(hipMemcpyAsync(out, h->episode + first, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return POM_OK;
@@ -531,6 +572,8 @@ int pom_batch_stream(PomBatch* h, void** stream)
 int pom_batch_device_view(PomBatch* h, void** base, int64_t* n_pad, int32_t* rec_dwords)
 {
     if (!h) return POM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    if (int qr = quiesce(h)) return qr;
     if (base) *base = h->state;
     if (n_pad) *n_pad = h->n_pad;
     if (rec_dwords) *rec_dwords = POM_REC_DWORDS;
@@ -607,7 +650,7 @@ int pom_batch_set_streams(PomBatch* h, int32_t streams)
 {
     if (!h || streams < 1 || streams > PomBatch::MAX_PARTS) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
+    if (int jr = quiesce(h)) return jr;
     const int64_t tiles = h->n_pad / h->epw;
     const int want = (int64_t)streams > tiles ? (int)tiles : streams;
     if (int er = ensure_sub_streams(h, streams)) return er;
@@ -625,7 +668,7 @@ int pom_batch_policy_simple(PomBatch* h, uint64_t seed, int32_t* moves_out_host)
     int rc = launch_policy(h, seed);
     if (rc) return rc;
     if (moves_out_host) {
-        if (int jr = join_parts(h)) return jr;
+        if (int jr = quiesce(h)) return jr;
         HIPCHK(hipMemcpyAsync(moves_out_host, h->moves_dev, (size_t)h->n * 16, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
@@ -664,7 +707,7 @@ int pom_batch_policy_memory(PomBatch* h, int64_t first, int64_t count, int32_t* 
     int rc = check_range(h, first, count);
     if (rc || !out16) return rc ? rc : POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
+    if (int jr = quiesce(h)) return jr;
     if (!h->agent_mem) {
         memset(out16, 0, (size_t)count * 4 * 16 * sizeof(int32_t));
         return POM_OK;
@@ -718,7 +761,7 @@ int pom_batch_profile_read(PomBatch* h, double* mean_ms, int64_t* launches)
 {
     if (!h) return POM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
+    if (int jr = quiesce(h)) return jr;
     HIPCHK(hipStreamSynchronize(h->stream));
     double sum = 0;
     for (int k = 0; k < h->prof_n; k++) {
@@ -750,9 +793,13 @@ int pom_batch_issue_info(PomBatch* h, int32_t* issue_mode, int32_t* streams)
     return POM_OK;
 }
 
-/* pom_step / pom_env_step: one pinned, device-mapped page the kernel reads the State from and writes it back to
- * (pom_step_one_kernel), one launch per call, the host polling the kernel's last store.  One context per process, device 0,
- * behind a mutex. */
+/* pom_step / pom_env_step: a pinned, device-mapped page the kernel reads the State from and writes it back to
+ * (pom_step_one_kernel), one launch per call, the host polling the kernel's last store.  The reference's Step is re-entrant over
+ * distinct States and its performance test steps one env per std::thread (unit_test/bboard/performance_test.cpp:40-50,71-94):
+ * every calling thread gets a context of its own — page, stream, sequence number — so that threads stepping their own States do
+ * not wait for each other (device 0).  POM_ONE_SLOTS contexts; threads beyond that share (slot = thread number mod slots), which
+ * is what the per-slot mutex is for. */
+enum { POM_ONE_SLOTS = 64 };
 struct PomOne {
     std::mutex mu;
     int32_t* io = nullptr;     /* host address of the page */
@@ -761,12 +808,15 @@ struct PomOne {
     uint32_t seq = 0;
     bool ready = false;
 };
-static PomOne g_one;
+static PomOne g_one[POM_ONE_SLOTS];
+static std::atomic<unsigned> g_one_threads{0};
 
 static int step_one(void* state_1004, const int32_t moves[4], int32_t mode, int32_t max_steps, int32_t status4[4])
 {
     if (!state_1004 || !moves) return POM_E_ARG;
-    PomOne& o = g_one;
+    static thread_local int my_slot = -1;
+    if (my_slot < 0) my_slot = (int)(g_one_threads.fetch_add(1) % POM_ONE_SLOTS);
+    PomOne& o = g_one[my_slot];
     std::lock_guard<std::mutex> lock(o.mu);
     HIPCHK(hipSetDevice(0));
     if (!o.ready) {

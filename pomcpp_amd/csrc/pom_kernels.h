@@ -124,8 +124,11 @@ struct StepParams {
      * that stored the tile last (0: none yet), 27..0 visits stored.  The j-th visitor of a tile plays tick tick0 + (j - chain_seq0)
      * once the word says j visits are stored; which launch a visitor belongs to does not matter. */
     unsigned long long* tile_seq;
-    uint32_t* chain_err; /* host-visible; bit 0: a wavefront gave up waiting, bit 1: a tile changed its XCD (its L2) */
+    uint32_t* chain_err; /* a device word of POM_CHAIN_E_* flags, read back by the host after the next join (chain_settle) */
     uint32_t chain_seq0;
+    uint32_t tape_len;         /* CHAIN with explicit moves: `moves` is a tape int32[tape_len][n][4], the visit at distance d from
+                                  chain_seq0 plays tick d of it (0: `moves` is one tick's Move[4] array or nullptr) */
+    uint64_t chain_wait_limit; /* how long a wavefront waits for the visit before its own, in ticks of the 100 MHz wall clock */
 #if defined(POM_DIAG)
     long long* diag; /* POM_PH_N accumulators per wavefront, diagnostic build only */
 #endif
@@ -532,7 +535,10 @@ __device__ __forceinline__ int pom_policy_wave(Store& st, const PomPolicyEnv& E,
  * its own stores have arrived.  A launch then no longer lasts as long as its slowest wavefront: the next launch's
  * wavefronts start on the tiles that are ready. */
 extern "C" __device__ uint64_t pom_dispatch_id(void) __asm("llvm.amdgcn.dispatch.id"); /* the AQL packet's index in its queue */
-enum { POM_CHAIN_SPIN_LIMIT = 400000 }; /* polls of ~0.3 us before a wavefront gives up (it must never hang the device) */
+/* how long a wavefront waits for the visit before its own before it gives up (it must never hang the device): wall-clock time, so
+ * that a holder descheduled for a while (several processes time-slicing one GPU, a debugger) is waited for; a give-up poisons the
+ * tile and the host replays its ticks after the next join — slow, never wrong (pom_runtime.h chain_settle) */
+enum { POM_CHAIN_WAIT_LIMIT_US = 2000000 };
 #ifndef POM_CHAIN_WORD_STRIDE
 #define POM_CHAIN_WORD_STRIDE 16 /* 64-bit words between the ticket words of neighbouring tiles: a 128-byte line each (10.28 - 10.30 us
                                     per step against 10.41 - 10.48 with the words packed: atomics of neighbouring tiles do not queue on one line) */
@@ -578,8 +584,8 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         chain_xcd &= 0xFu;
         const int64_t q = gridDim.x / 8;
         tile_local = (int64_t)chain_xcd * q + blockIdx.x / 8;
-        if (chain_xcd >= 8u) { /* not the machine this was written for: nothing is stepped */
-            if (lane == 0) atomicOr(p.chain_err, 2u);
+        if (chain_xcd >= 8u) { /* not the machine this was written for: nothing is stepped, no ticket is drawn (the verify pass reports it) */
+            if (lane == 0) __hip_atomic_fetch_or(p.chain_err, (uint32_t)POM_CHAIN_E_XCD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
         if (POM_WPB == 1 && p.block0 + tile_local >= p.block_end) return; /* a workgroup of the padding */
@@ -622,6 +628,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     /* the launch's first tick: asked for BEFORE the record, so that waiting for it (in-order vmcnt) does not wait for the record */
     uint32_t tick0 = CHAIN ? p.tick0 : p.tick0 + *p.tick_base; /* (graphs replay sub-batch launches, never chained ones) */
     unsigned long long chain_done = 0; /* what this wavefront adds to the tile's word when its stores have arrived */
+    int32_t chain_dist = 0;            /* CHAIN: how many visits after the call's first visit this one is */
 #if defined(POM_CHAIN_DIAG)
     long long chain_t0 = 0, chain_t1 = 0, chain_t2 = 0, chain_rt0 = 0;
     int chain_polls = 0;
@@ -640,26 +647,44 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         const uint32_t visit = (uint32_t)(w >> POM_CHAIN_TICKET_SHIFT);
         /* which tick: the call's first tick + how far this visit is from the call's first visit — a signed distance: launches of
          * two calls may be in flight together, and a wavefront of the later call can draw a ticket of the earlier one */
-        tick0 += pom_chain_visit_distance(visit, p.chain_seq0);
+        chain_dist = (int32_t)pom_chain_visit_distance(visit, p.chain_seq0);
+        tick0 += (uint32_t)chain_dist;
 #if defined(POM_CHAIN_DIAG)
         chain_t1 = (long long)__builtin_readcyclecounter();
 #endif
-        /* stored visits == this visit's number: its turn.  (More can only be seen after a visit has failed and been counted
-         * regardless, below: then nobody waits any more.) */
+        /* stored visits == this visit's number: its turn.  Until then poll — for as long as the wall clock allows; a poisoned tile
+         * (somebody before this visit could not play) is nobody's turn any more */
         int polls = 0;
-        while ((int32_t)pom_chain_visit_distance((uint32_t)w & POM_CHAIN_COUNT_MASK, visit) < 0 && ++polls <= POM_CHAIN_SPIN_LIMIT) { /* wave-uniform */
-            __builtin_amdgcn_s_sleep(1);
-            w = __hip_atomic_load(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool timed_out = false;
+        if (!((uint32_t)w & POM_CHAIN_POISON) && (int32_t)pom_chain_visit_distance((uint32_t)w & POM_CHAIN_COUNT_MASK, visit) < 0) { /* wave-uniform */
+            const uint64_t t_wait0 = wall_clock64();
+            for (;;) {
+                __builtin_amdgcn_s_sleep(1);
+                w = __hip_atomic_load(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
+                polls++;
+                if (((uint32_t)w & POM_CHAIN_POISON) || (int32_t)pom_chain_visit_distance((uint32_t)w & POM_CHAIN_COUNT_MASK, visit) >= 0) break;
+                if (wall_clock64() - t_wait0 >= p.chain_wait_limit) {
+                    timed_out = true;
+                    break;
+                }
+            }
         }
+        (void)polls;
         const uint32_t was_on = (uint32_t)(w >> 32) & 0xFu;
-        const bool gave_up = ((uint32_t)w & POM_CHAIN_COUNT_MASK) != visit;
-        if (gave_up || (was_on != 0u && was_on != xcd)) {
-            /* the visit before this one never arrived, or it was stored through another XCD's L2: nothing is stepped, the
-             * host finds the flag and reports the call as failed (the batch is then in an undefined state).  The visit is still
-             * counted as stored, so that the tile's later visitors do not each wait their limit out. */
-            if (lane == 0) {
-                atomicOr(p.chain_err, gave_up ? 1u : 2u);
-                __hip_atomic_fetch_add(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool poisoned = ((uint32_t)w & POM_CHAIN_POISON) != 0;
+        const bool wrong_xcd = was_on != 0u && was_on != xcd;
+        const bool off_tape = p.tape_len != 0u && (uint32_t)chain_dist >= p.tape_len;
+        if (poisoned || timed_out || wrong_xcd || off_tape) {
+            /* The visit before this one never arrived in time, or it was stored through another XCD's L2 (what this L2 holds of
+             * the tile may be stale), or the ticket lies outside the move tape (launches of two tape calls in flight together:
+             * the host joins between them, so never).  Nothing is stepped and NOTHING IS COUNTED: the tile is poisoned, every
+             * later visitor leaves it alone, its stored count stays at the ticks it really played, and the host — which finds
+             * the flag after the next join — replays the rest with ordinary launches (chain_settle, pom_runtime.h). */
+            if (lane == 0 && !poisoned) {
+                __hip_atomic_fetch_or(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, (unsigned long long)POM_CHAIN_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_or(p.chain_err, (uint32_t)(timed_out ? POM_CHAIN_E_TIMEOUT : wrong_xcd ? POM_CHAIN_E_XCD : POM_CHAIN_E_TAPE), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
             }
             return;
         }
@@ -685,7 +710,8 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     constexpr bool TAKES_MOVES = SINGLE || G == 1;
     if (!POLICY) {
         if (TAKES_MOVES && p.moves) {
-            if (valid) moves0 = reinterpret_cast<const int4*>(p.moves)[e];
+            /* chained: tick `chain_dist` of the caller's move tape (pom_batch_step_device_many) */
+            if (valid) moves0 = reinterpret_cast<const int4*>(p.moves)[(CHAIN ? (int64_t)chain_dist * p.n : (int64_t)0) + e];
         } else {
             if (G == 4 && !SINGLE) { /* several ticks per launch: the draw is made where it is used, nothing to carry */
             } else if (G == 4) draw0 = pom_rng_draw_half(p.seed, env_key, tick0, member >> 1); /* lane m needs agent m's 16 bits only */
@@ -982,14 +1008,24 @@ __global__ void pom_chain_probe_kernel(uint32_t* xcd_of_block)
     if (threadIdx.x == 0) xcd_of_block[blockIdx.x] = x & 0xFu;
 }
 
-/* chained launches, after a join: every tile must have been visited exactly `visits` times and every visit stored (a
- * workgroup -> XCD assignment that is not the round-robin the tile choice assumes would show here) */
-__global__ void pom_chain_verify_kernel(const unsigned long long* tile_seq, int64_t tiles, uint32_t visits, uint32_t* err)
+/* chained launches, after a join: every tile must have drawn exactly `visits` tickets, and have stored as many visits — or be
+ * poisoned (a visitor could not play: POM_CHAIN_POISON), in which case (tile, visits really stored) goes onto the list the host
+ * replays from (chain_settle).  aux[0]: the POM_CHAIN_E_* flags, aux[1]: length of the list, list: aux + 2, two dwords per entry. */
+__global__ void pom_chain_verify_kernel(const unsigned long long* tile_seq, int64_t tiles, uint32_t visits, uint32_t* aux)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tiles) return;
     const unsigned long long w = tile_seq[t * POM_CHAIN_WORD_STRIDE];
-    if (((uint32_t)w & POM_CHAIN_COUNT_MASK) != visits || (uint32_t)(w >> POM_CHAIN_TICKET_SHIFT) != visits) atomicOr(err, 4u);
+    const uint32_t stored = (uint32_t)w & POM_CHAIN_COUNT_MASK;
+    if ((uint32_t)(w >> POM_CHAIN_TICKET_SHIFT) != visits) atomicOr(aux, (uint32_t)POM_CHAIN_E_UNEVEN);
+    if ((uint32_t)w & POM_CHAIN_POISON) {
+        const uint32_t k = atomicAdd(aux + 1, 1u);
+        aux[2 + 2 * k] = (uint32_t)t;
+        aux[3 + 2 * k] = stored;
+        if (stored >= visits) atomicOr(aux, (uint32_t)POM_CHAIN_E_UNEVEN); /* poisoned means: at least one visit not played */
+    } else if (stored != visits) {
+        atomicOr(aux, (uint32_t)POM_CHAIN_E_UNEVEN);
+    }
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -175,8 +175,13 @@ POM_HD void pom_unpack_state(const uint32_t* rec, int64_t stride, int32_t* st)
 
 /* Chained launches (pom_chain.h): the tile words count visits in 28-bit fields (tickets in bits 63..36, stored visits in 27..0) and
  * are zeroed before either reaches 2^27.  A visit's distance from the first visit of the call whose launch it rides in is SIGNED:
- * launches of two calls can be in flight together, and a wavefront of the later call may draw a ticket of the earlier one. */
-enum { POM_CHAIN_TICKET_SHIFT = 36, POM_CHAIN_COUNT_MASK = 0x0FFFFFFF };
+ * launches of two calls can be in flight together, and a wavefront of the later call may draw a ticket of the earlier one.
+ * Bit 28 (POM_CHAIN_POISON): a visitor could not play its tick (it waited out its time limit for the visit before it, or found
+ * the tile stored through another XCD's L2).  Nobody steps a poisoned tile: its stored count stays at the number of ticks it
+ * really played, and the host replays the rest after the next join (pom_runtime.h chain_settle). */
+enum { POM_CHAIN_TICKET_SHIFT = 36, POM_CHAIN_COUNT_MASK = 0x0FFFFFFF, POM_CHAIN_POISON = 0x10000000 };
+/* failure flags of chained launches (a device word, read back by chain_settle) */
+enum { POM_CHAIN_E_TIMEOUT = 1, POM_CHAIN_E_XCD = 2, POM_CHAIN_E_UNEVEN = 4, POM_CHAIN_E_TAPE = 8 };
 POM_HD uint32_t pom_chain_visit_distance(uint32_t visit, uint32_t first_visit_of_call)
 {
     return (uint32_t)((int32_t)((visit - first_visit_of_call) << 4) >> 4);

@@ -102,6 +102,14 @@ enum { POM_KIND_SPLIT = 1, POM_KIND_CHAIN = 2 };
 static int fork_parts(PomBatch* h, int kind = POM_KIND_SPLIT);
 static int join_parts(PomBatch* h);
 static int ensure_sub_streams(PomBatch* h, int parts);
+static int chain_settle(PomBatch* h);
+/* before anything but another chained call reads or changes the batch: the chained launches are joined and checked, tiles that
+ * could not be played in the chain are caught up (chain_settle), then the sub-streams are joined into the caller's stream */
+static int quiesce(PomBatch* h)
+{
+    if (int rc = chain_settle(h)) return rc;
+    return join_parts(h);
+}
 
 static int check_range(const PomBatch* h, int64_t first, int64_t count)
 {
@@ -202,6 +210,11 @@ static int fill_params(PomBatch* h, StepParams& p, const int32_t* moves_dev, uin
     p.board_seed = h->board_seed;
     p.fresh = h->fresh;
     p.block0 = p.block_end = 0;
+    p.tile_seq = nullptr;
+    p.chain_err = nullptr;
+    p.chain_seq0 = 0;
+    p.tape_len = 0;
+    p.chain_wait_limit = 0;
 #if defined(POM_DIAG)
     if (!h->diag) {
         HIPCHK(hipMalloc((void**)&h->diag, (size_t)h->n_waves * POM_PH_N * 8));
@@ -259,6 +272,7 @@ static hipError_t dispatch_step(const PomBatch* h, const StepParams& p, hipStrea
 static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int dist, int ticks, bool policy = false, bool one_launch = false)
 {
     StepParams p;
+    if (int rc = chain_settle(h)) return rc; /* an ordinary launch after chained ones: every tile must stand on the tick the host thinks it does */
     if (int rc = fill_params(h, p, moves_dev, seed, dist, ticks)) return rc;
     const int64_t tiles = h->n_pad / h->epw;
     const int parts = one_launch ? 1 : h->parts;
@@ -501,6 +515,7 @@ static int launch_many_streams(PomBatch* h, const StepParams& p0, int launches, 
     StepParams p = p0;
     const int64_t tiles = h->n_pad / h->epw;
     const int parts = h->parts;
+    if (int rc = chain_settle(h)) return rc;
     if (int rc = fork_parts(h)) return rc;
     hipError_t err = hipSuccess;
     auto part_launch = [&](int k, const StepParams& base, int count) { /* `count` launches of part k from this thread */
@@ -584,80 +599,149 @@ static bool runs_chain(const PomBatch* h, bool policy, int ticks_per_launch)
     (void)policy; /* every one-tick instantiation of the quad shape has its chained twin */
     return h->issue_mode == POM_ISSUE_CHAIN && h->quad && h->chain_parts > 1 && ticks_per_launch == 1 && !(h->chain.tried && !h->chain.ok);
 }
-/* the kernel's failure flags (pinned memory): looked at by every call that joins or launches */
-static int chain_check(PomBatch* h)
+static const PomStepKernel* chain_kernels(bool chained)
 {
-    PomChain* c = &h->chain;
-    if (!c->err_host) return POM_OK;
-    const uint32_t flags = *reinterpret_cast<volatile uint32_t*>(c->err_host);
-    if (!flags) return POM_OK;
-    *c->err_host = 0;
-    c->ok = false; /* no further chained launches on this handle */
-    snprintf(g_err, sizeof g_err, "a chained launch failed (%s%s%s): the batch is in an undefined state — upload again or destroy it",
-             (flags & 1u) ? "a wavefront gave up waiting for its tile" : "", (flags & 2u) ? " a tile changed its XCD" : "",
-             (flags & 4u) ? " the tiles were not visited evenly" : "");
-    return POM_E_HIP;
+    static const PomStepKernel chained_k[8] = {
+        pom_step_kernel<16, 4, false, false, false, true, true>, pom_step_kernel<16, 4, false, false, true, true, true>,
+        pom_step_kernel<16, 4, false, true, false, true, true>,  pom_step_kernel<16, 4, false, true, true, true, true>,
+        pom_step_kernel<16, 4, true, false, false, true, true>,  pom_step_kernel<16, 4, true, false, true, true, true>,
+        pom_step_kernel<16, 4, true, true, false, true, true>,   pom_step_kernel<16, 4, true, true, true, true, true>};
+    static const PomStepKernel plain_k[8] = {
+        pom_step_kernel<16, 4, false, false, false, true>, pom_step_kernel<16, 4, false, false, true, true>,
+        pom_step_kernel<16, 4, false, true, false, true>,  pom_step_kernel<16, 4, false, true, true, true>,
+        pom_step_kernel<16, 4, true, false, false, true>,  pom_step_kernel<16, 4, true, false, true, true>,
+        pom_step_kernel<16, 4, true, true, false, true>,   pom_step_kernel<16, 4, true, true, true, true>};
+    return chained ? chained_k : plain_k;
 }
-/* after a join, on the caller's stream: were all tiles visited equally often?  (the answer arrives with the next synchronize) */
-static int chain_verify(PomBatch* h)
+
+/* The check behind chained launches, and the recovery (pom_chain.h).  Joins the streams, lists the tiles some visitor could not
+ * play (poisoned: their records stand on the last tick they really played), waits for the answer, and plays the missing ticks of
+ * each such tile again — ordinary one-tile, one-tick launches of the twin kernel without the chain, with the parameters the
+ * chained call was launched with (the log), on the caller's stream.  Afterwards every tile stands on the tick the host thinks it
+ * does.  Costs one synchronisation of the caller's stream; free while there have been no chained launches since the last one. */
+static int chain_settle(PomBatch* h)
 {
     PomChain* c = &h->chain;
     if (!c->unverified || !c->ok) return POM_OK;
-    const int64_t tiles = h->n_pad / h->epw;
-    pom_chain_verify_kernel<<<dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, h->stream>>>(c->tile_seq, tiles, c->visits, c->err_dev);
+    if (int jr = join_parts(h)) return jr;
+    const int64_t tiles = c->tiles;
+    HIPCHK(hipMemsetAsync(c->aux + 1, 0, 4, h->stream));
+    pom_chain_verify_kernel<<<dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, h->stream>>>(c->tile_seq, tiles, c->visits, c->aux);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->aux_host, c->aux, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     c->unverified = false;
+    c->stat_settles++;
+    const uint32_t flags = c->aux_host[0], bad = c->aux_host[1];
+    if (!flags && !bad) {
+        c->log.clear();
+        return POM_OK;
+    }
+    HIPCHK(hipMemsetAsync(c->aux, 0, 4, h->stream));
+    if ((flags & POM_CHAIN_E_UNEVEN) || bad > (uint32_t)tiles) { /* not a tile left behind: launches that did not cover the tiles as assumed */
+        c->ok = false;
+        c->log.clear();
+        snprintf(g_err, sizeof g_err, "chained launches did not visit every tile once (flags %u): the batch is in an undefined state — upload again "
+                 "or destroy it; the handle launches sub-batches from here on", flags);
+        return POM_E_HIP;
+    }
+    std::vector<uint32_t> list((size_t)2 * bad);
+    if (bad) HIPCHK(hipMemcpy(list.data(), c->aux + 2, (size_t)bad * 8, hipMemcpyDeviceToHost));
+    if (getenv("POM_CHAIN_VERBOSE"))
+        fprintf(stderr, "pom: chained launches left %u tile(s) behind (flags %u: %s%s%s); replaying their ticks\n", bad, flags,
+                (flags & POM_CHAIN_E_TIMEOUT) ? "a wavefront waited out its limit " : "", (flags & POM_CHAIN_E_XCD) ? "a tile changed its XCD " : "",
+                (flags & POM_CHAIN_E_TAPE) ? "a ticket outside the move tape" : "");
+    const PomStepKernel* plain = chain_kernels(false);
+    for (uint32_t k = 0; k < bad; k++) {
+        const uint32_t tile = list[2 * k], stored = list[2 * k + 1];
+        for (uint32_t v = stored; v != c->visits; v++) {
+            const PomChainCall* call = nullptr;
+            for (const PomChainCall& e : c->log)
+                if (v - e.visit0 < e.launches) call = &e;
+            if (!call) { /* cannot happen: every chained launch since the last settle is in the log */
+                c->ok = false;
+                c->log.clear();
+                snprintf(g_err, sizeof g_err, "a tile left behind by chained launches cannot be replayed: the batch is in an undefined state");
+                return POM_E_HIP;
+            }
+            StepParams q = call->p;
+            const uint32_t d = v - q.chain_seq0; /* visits after the call's first */
+            q.block0 = tile;
+            q.block_end = (int64_t)tile + 1;
+            q.ticks = 1;
+            q.tick0 += d;
+            q.tick_base = h->tick_words + PomBatch::MAX_PARTS;
+            if (q.moves) q.moves += (int64_t)d * q.n * 4;
+            q.tile_seq = nullptr;
+            q.chain_err = nullptr;
+            q.chain_seq0 = 0;
+            q.tape_len = 0;
+            const PomStepKernel kernel = plain[(runs_fresh(h) ? 4 : 0) | (call->policy ? 2 : 0) | (runs_at_end(h) ? 1 : 0)];
+            void* args[1] = {&q};
+            HIPCHK(hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), dim3(1), dim3(64 * POM_WPB), args, 0, h->stream, nullptr, nullptr, 0));
+            c->stat_ticks_replayed++;
+        }
+        c->stat_tiles_recovered++;
+    }
+    /* the words start over: every tile is level again */
+    HIPCHK(hipMemsetAsync(c->tile_seq, 0, (size_t)tiles * 8 * POM_CHAIN_WORD_STRIDE, h->stream));
+    c->visits = 0;
+    c->log.clear();
+    if (flags & (POM_CHAIN_E_XCD | POM_CHAIN_E_TAPE)) c->ok = false; /* structural, not a matter of timing: no more chained launches on this handle */
     return POM_OK;
 }
+
+/* POM_ISSUE_CHAIN (pom_chain.h): `launches` one-tick launches, each over the WHOLE batch, dealt round-robin to the handle's
+ * streams; the tiles' ticket words order the ticks.  p0.moves != nullptr: a move tape of `launches` ticks.  *used = false: not
+ * available for this handle, nothing was launched, the caller takes the ordinary path. */
 static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bool policy, bool* used)
 {
     *used = false;
     PomChain* c = &h->chain;
     const int64_t tiles = h->n_pad / h->epw;
-    if (!c->tried) { /* the words are zeroed on the caller's stream: the sub-streams must be forked after that, not before */
+    if (!c->tried) { /* a handle that was not created for chained launches (pom_batch_set_streams made them possible later) */
         if (int jr = join_parts(h)) return jr;
-    }
-    if (!chain_setup(c, tiles, h->stream)) {
-        if (getenv("POM_CHAIN_VERBOSE"))
+        if (!chain_setup(c, tiles, h->stream) && getenv("POM_CHAIN_VERBOSE"))
             fprintf(stderr, "pom: chained launches are not available on this device (allocation failed or the workgroup -> XCD probe did not find the "
                             "eight-XCD round-robin); launching sub-batches\n");
-        return POM_OK;
     }
-    if (int rc = chain_check(h)) return rc;
+    if (!c->ok) return POM_OK;
     /* the fields of the tile words must not run into each other: after 2^27 visits (20 minutes of stepping) the words start over.
-     * (POM_CHAIN_RESET_AT: a smaller number, so that tests get to see it happen) */
+     * (POM_CHAIN_RESET_AT: a smaller number, so that tests get to see it happen).  The log of calls is bounded the same way. */
     static const uint64_t reset_at = getenv("POM_CHAIN_RESET_AT") ? (uint64_t)atoll(getenv("POM_CHAIN_RESET_AT")) : (uint64_t)(1u << 27);
-    if ((uint64_t)c->visits + (uint64_t)launches >= (reset_at < (1u << 27) && reset_at > 0 ? reset_at : (uint64_t)(1u << 27))) {
+    if ((uint64_t)c->visits + (uint64_t)launches >= (reset_at < (1u << 27) && reset_at > 0 ? reset_at : (uint64_t)(1u << 27)) || c->log.size() >= 256) {
+        if (int sr = chain_settle(h)) return sr;
+        if (!c->ok) return POM_OK;
         if (int jr = join_parts(h)) return jr;
         HIPCHK(hipMemsetAsync(c->tile_seq, 0, (size_t)tiles * 8 * POM_CHAIN_WORD_STRIDE, h->stream));
         c->visits = 0;
     }
-    static const PomStepKernel chained[8] = {
-        pom_step_kernel<16, 4, false, false, false, true, true>, pom_step_kernel<16, 4, false, false, true, true, true>,
-        pom_step_kernel<16, 4, false, true, false, true, true>,  pom_step_kernel<16, 4, false, true, true, true, true>,
-        pom_step_kernel<16, 4, true, false, false, true, true>,  pom_step_kernel<16, 4, true, false, true, true, true>,
-        pom_step_kernel<16, 4, true, true, false, true, true>,   pom_step_kernel<16, 4, true, true, true, true, true>};
     StepParams p = p0; /* the same for every launch of the call: which tick a wavefront plays follows from its ticket */
     p.block0 = 0;
     p.block_end = tiles;
     p.ticks = 1;
     p.tile_seq = c->tile_seq;
-    p.chain_err = c->err_dev;
+    p.chain_err = c->aux;
     p.chain_seq0 = c->visits;
-    const PomStepKernel kernel = chained[(runs_fresh(h) ? 4 : 0) | (policy ? 2 : 0) | (runs_at_end(h) ? 1 : 0)];
+    p.tape_len = p.moves ? (uint32_t)launches : 0u;
+    p.chain_wait_limit = c->wait_limit;
+    const PomStepKernel kernel = chain_kernels(true)[(runs_fresh(h) ? 4 : 0) | (policy ? 2 : 0) | (runs_at_end(h) ? 1 : 0)];
     /* Launches in flight together must be interchangeable — "the j-th visitor of a tile plays the tile's j-th tick" holds only
      * if every launch would play that tick the same way: the same kernel, seed, move distribution, mode ... and the same offset
      * between ticks and visits.  A call that differs in any of that from the chained launches still in flight waits for them
-     * (tests/test_gpu_chain.py: random sequences of calls with a seed of their own each). */
-    {
-        StepParams key = p;
-        key.tick0 = p.tick0 - p.chain_seq0;
-        key.chain_seq0 = 0;
-        if (h->forked && h->last_kind == POM_KIND_CHAIN && (kernel != c->last_kernel || memcmp(&key, &c->last_key, sizeof key) != 0))
-            if (int jr = join_parts(h)) return jr;
-        c->last_key = key;
-        c->last_kernel = kernel;
-    }
+     * (tests/test_gpu_chain.py: random sequences of calls with a seed of their own each).  A move tape belongs to its call: the
+     * launches of a tape call never overlap another call's (and the tape was written on the caller's stream: the fork below
+     * orders this call's launches behind it). */
+    StepParams key = p;
+    key.tick0 = p.tick0 - p.chain_seq0;
+    key.chain_seq0 = 0;
+    const bool continues = !p.moves && kernel == c->last_kernel && memcmp(&key, &c->last_key, sizeof key) == 0;
+    if (h->forked && h->last_kind == POM_KIND_CHAIN && !continues)
+        if (int jr = join_parts(h)) return jr;
+    if (p.moves && h->forked)
+        if (int jr = join_parts(h)) return jr;
+    c->last_key = key;
+    c->last_kernel = kernel;
     if (int rc = fork_parts(h, POM_KIND_CHAIN)) return rc;
     const dim3 grid((unsigned)(((tiles + POM_WPB - 1) / POM_WPB + 7) / 8 * 8)); /* a multiple of 8: every XCD gets as many workgroups as it has tiles */
     /* how many streams: a third launch in flight pays once the pipeline runs (65,536 envs, per step: 400-tick call 9.1 us on
@@ -665,18 +749,42 @@ static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bo
      * 16.8 / 15.2; scripts/experiments/chain/call_length.py).  Any mix is fine: the tickets order the ticks, not the streams. */
     const int use = !h->chain_auto ? h->chain_parts : launches >= POM_CHAIN_LONG_CALL ? 3 : 2;
     h->chain_last_use = use;
-    for (int k = 0; k < launches; k++) {
+    int issued = 0;
+    hipError_t err = hipSuccess;
+    for (; issued < launches; issued++) {
         const int part = (int)(c->turn++ % (uint32_t)use);
         hipStream_t st = part < h->main_part ? h->stream : h->sub[part];
         const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
         hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
         StepParams q = p;
         void* args[1] = {&q};
-        HIPCHK(hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, dim3(64 * POM_WPB), args, 0, st, ev0, ev1, 0));
+        err = hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, dim3(64 * POM_WPB), args, 0, st, ev0, ev1, 0);
+        if (err != hipSuccess) break;
         if (prof) h->prof_n++;
     }
-    c->visits += (uint32_t)launches;
-    c->unverified = true;
+    /* what was issued is accounted for even if a launch failed half-way: the tiles' words, the log and the host's tick agree */
+    if (issued > 0) {
+        if (continues && !c->log.empty() && c->log.back().visit0 + c->log.back().launches == c->visits && c->log.back().policy == policy) {
+            c->log.back().launches += (uint32_t)issued; /* the same play goes on: one entry */
+        } else {
+            PomChainCall e;
+            e.visit0 = c->visits;
+            e.launches = (uint32_t)issued;
+            e.p = p;
+            e.policy = policy;
+            c->log.push_back(e);
+        }
+        c->visits += (uint32_t)issued;
+        c->stat_launches += issued;
+        c->unverified = true;
+        h->tick += (uint64_t)issued;
+    }
+    if (err != hipSuccess) {
+        snprintf(g_err, sizeof g_err, "pom_step_kernel launch: %s (%d of the call's %d ticks were queued and will be played; the rest were not)",
+                 hipGetErrorString(err), issued, launches);
+        *used = true;
+        return POM_E_HIP;
+    }
     *used = true;
     return POM_OK;
 }
@@ -692,11 +800,9 @@ static int launch_many(PomBatch* h, uint64_t seed, int dist, int launches, int t
         if (int rc = fill_params(h, p, nullptr, seed, dist, 1)) return rc;
         bool used = false;
         if (int rc = launch_many_chain(h, p, launches, policy, &used)) return rc;
-        if (used) {
-            h->tick += (uint64_t)launches;
-            return POM_OK;
-        }
+        if (used) return POM_OK; /* (the tick was advanced by what was queued) */
     }
+    if (int rc = chain_settle(h)) return rc;
     if (h->issue_mode == POM_ISSUE_GRAPH && chunk >= 2 && launches >= chunk && !h->profiling) {
         StepParams p;
         memset(&p, 0, sizeof p); /* the cache compares the bytes */
@@ -740,6 +846,7 @@ static int launch_many(PomBatch* h, uint64_t seed, int dist, int launches, int t
 
 static int launch_policy(PomBatch* h, uint64_t seed)
 {
+    if (int rc = chain_settle(h)) return rc;
     if (int rc = ensure_agent_mem(h)) return rc;
     PolicyParams p;
     p.state = h->state;

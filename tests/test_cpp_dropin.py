@@ -53,6 +53,17 @@ def test_reference_style_code_compiles_against_the_drop_in_header(dropin_exe):
     assert os.path.exists(dropin_exe)
 
 
+def test_reference_general_vectors_on_the_drop_in_fixed_queue(hip_lib):
+    """unit_test/bboard/general_test.cpp:8-61 ("[general]": FixedQueue fill / PopElem / RemoveAt with the ring starting at 0, 5, 2)
+    against include/pom_bboard.hpp's FixedQueue, the one drop-in agents compile against; pure host code, runs without a GPU"""
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "general_test")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "general_test.cpp"), "-o", exe] + LINK, check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "general ok" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.skipif(not have_reference, reason="the reference tree only exists in the build container")
 def test_unmodified_reference_agents_and_main_compile_and_link_against_the_drop_in_header(hip_lib):
     """oracle/Makefile target `dropin` (also run by __graft_entry__.build()): src/agents/simple_agent.cpp, basic_agents.cpp,

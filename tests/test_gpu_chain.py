@@ -235,9 +235,10 @@ def test_random_api_sequences_chained_against_plain(hip_lib, auto_reset, fresh):
                 assert all(np.array_equal(ra[k], rb[k]) for k in ra), seq
 
 
-def test_full_size_chained_against_plain(hip_lib):
+def test_full_size_chained_against_plain(hip_lib, oracle):
     """65,536 envs (the headline's size: every wavefront slot of the chip taken by one launch, so launches really queue behind each
-    other): long and short chained calls, stress moves, the fused SimpleAgent kernel, against a twin that never chains."""
+    other): long and short chained calls, stress moves, the fused SimpleAgent kernel, against a twin that never chains — and two
+    slices of 2,048 envs against the oracle playing the same sequence of calls."""
     n = 65536
     start = pa.make_boards(n, seed=33, kind="stress")
     kw = dict(mode=MODE_ENV, auto_reset=True, max_steps=800)
@@ -251,6 +252,183 @@ def test_full_size_chained_against_plain(hip_lib):
             e.step_simple(6, 25)
             e.step_random(6, DIST_RANDOM, ticks=3)
         assert _same(a.get_state(), b.get_state())
+        for lo in (0, 40000):
+            cnt = 2048
+            ini = np.ascontiguousarray(start[lo:lo + cnt])
+            ref, mems = ini.copy(), np.zeros((cnt, 4, 16), dtype=np.int32)
+            oracle.run_random(ref, ini, 139, 5, lo, 0, DIST_STRESS, 800)
+            oracle.run_random(ref, ini, 45, 6, lo, 139, DIST_RANDOM, 800)
+            oracle.run_simple(ref, ini, mems, 25, 6, lo, 184, 800)
+            oracle.run_random(ref, ini, 3, 6, lo, 209, DIST_RANDOM, 800)
+            assert _same(a.get_state(lo, cnt), ref), lo
+            assert np.array_equal(a.policy_memory(lo, cnt), mems), lo
         assert np.array_equal(a.counters(), b.counters()) and np.array_equal(a.policy_memory(), b.policy_memory())
         sa, sb = a.status(), b.status()
         assert all(np.array_equal(sa[k], sb[k]) for k in sa)
+
+
+def _oracle_explicit(oracle, ref, start, status, moves, cap, at_end, last=None, term=None):
+    """one tick of Environment::Step with explicit moves on every env of `ref`, with the batch's auto-reset (tests/test_reset_modes.py)"""
+    n = ref.size
+    fin = np.zeros(n, int)
+    for i in range(n):
+        if not at_end and (status[i]["done"] or ref["timeStep"][i] >= cap):  # reset at the start of the next tick
+            ref[i] = start[i]
+            status[i] = dict(done=0, winner=-1, draw=0)
+        oracle.env_step(ref[i:i + 1], moves[i], status[i])
+        if at_end and (status[i]["done"] or ref["timeStep"][i] >= cap):
+            fin[i] = 1
+            if last is not None:
+                last["winner"][i], last["draw"][i] = status[i]["winner"], status[i]["draw"]
+                last["length"][i], last["alive"][i] = ref["timeStep"][i], ref["aliveAgents"][i]
+                term[i] = ref[i]
+            ref[i] = start[i]
+            status[i] = dict(done=0, winner=-1, draw=0)
+    return fin
+
+
+@pytest.mark.parametrize("at_end", [True, False])
+def test_move_tape_chained_against_the_oracle(hip_lib, oracle, at_end):
+    """pom_batch_step_device_many: K ticks of explicit Move[4] from a tape in device memory, issued as chained launches — every tick
+    played by the oracle with the same moves; states, restart marks, outcomes and terminal states after every call (calls of 1 .. 55
+    ticks, then forty calls of two: nearly every tick boundary is looked at)."""
+    import torch
+    n, cap = 400, 60
+    start = pa.make_boards(n, seed=41)
+    rng = np.random.default_rng(11)
+    ref = start.copy()
+    status = [dict(done=0, winner=-1, draw=0) for _ in range(n)]
+    last = dict(winner=np.full(n, -1), draw=np.zeros(n, int), length=np.zeros(n, int), alive=np.zeros(n, int))
+    term = np.zeros(n, dtype=start.dtype)
+    plan = [2, 3, 5, 8, 1, 13, 21, 34, 55] + [2] * 40
+    with BatchEnvironment(n, mode=MODE_ENV, auto_reset=RESET_AT_END if at_end else True, max_steps=cap, issue_mode=ISSUE_CHAIN) as env:
+        assert env.issue_info()[0] == "chain"
+        env.make_game(start)
+        played = 0
+        for k in plan:
+            tape = rng.integers(0, 6, size=(k, n, 4), dtype=np.int32)
+            dev = torch.from_numpy(tape).to("cuda")
+            env.step_device_many(dev)
+            fin = None
+            for t in range(k):
+                fin = _oracle_explicit(oracle, ref, start, status, tape[t], cap, at_end, last, term)
+            played += k
+            got = env.get_state()  # synchronises: the tape may go now
+            if at_end:
+                assert _same(got, ref), (played, k)
+                r = env.last_results()
+                assert r["finished"].tolist() == fin.tolist(), (played, k)
+                for key in ("winner", "draw", "length", "alive"):
+                    assert r[key].tolist() == last[key].tolist(), (played, key)
+            else:
+                assert _same(got, ref), (played, k)
+                st = env.status()
+                assert st["done"].tolist() == [int(s["done"] or ref["timeStep"][i] >= cap) for i, s in enumerate(status)], played
+        if at_end:
+            assert _same(env.get_terminal_state(), term)
+        assert env.counters()[CNT_STEPS] == n * played
+        stats = env.chain_stats()
+        assert stats["launches"] == sum(k for k in plan if k >= 2) and stats["tiles_recovered"] == 0, stats
+        with pytest.raises(ValueError):
+            env.step_device_many(torch.zeros((3, n, 3), dtype=torch.int32, device="cuda"))
+
+
+def test_move_tape_full_size_equals_one_launch_per_tick(hip_lib, oracle):
+    """65,536 envs: a 60-tick tape through chained launches against the same moves handed over tick by tick (pom_batch_step_device,
+    one plain launch per tick), and an oracle slice of 4,096 envs"""
+    import torch
+    n, k = 65536, 60
+    start = pa.make_boards(n, seed=5)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    tape = torch.randint(0, 6, (k, n, 4), dtype=torch.int32, device="cuda", generator=gen)
+    kw = dict(mode=MODE_ENV, auto_reset=RESET_AT_END, max_steps=800)
+    with BatchEnvironment(n, **kw) as a, BatchEnvironment(n, issue_mode=ISSUE_THREADS, streams=1, **kw) as b:
+        for e in (a, b):
+            e.make_game(start)
+        a.step_random(7, DIST_RANDOM, ticks=25)  # chained launches of another kind in flight when the tape call arrives
+        b.step_random(7, DIST_RANDOM, ticks=25)
+        a.step_device_many(tape)
+        for t in range(k):
+            b.step_device(tape[t])
+        ga, gb = a.get_state(), b.get_state()
+        assert _same(ga, gb)
+        assert np.array_equal(a.counters(), b.counters())
+        ra, rb = a.last_results(), b.last_results()
+        assert all(np.array_equal(ra[x], rb[x]) for x in ra)
+    # the oracle on a slice: random ticks first, then the tape (reset at the end of the finishing tick)
+    m = 4096
+    ref = np.ascontiguousarray(start[:m]).copy()
+    with BatchEnvironment(m, **kw) as c:
+        c.make_game(ref)
+        c.step_random(7, DIST_RANDOM, ticks=25)
+        mid = c.get_state()
+    ref = mid.copy()
+    status = [dict(done=0, winner=-1, draw=0) for _ in range(m)]
+    host_tape = tape[:, :m].cpu().numpy()
+    for t in range(k):
+        _oracle_explicit(oracle, ref, start[:m], status, host_tape[t], 800, True)
+    assert _same(ga[:m], ref)
+
+
+@pytest.mark.parametrize("wait_us", ["0", "6"])
+def test_forced_give_ups_are_replayed(hip_lib, wait_us):
+    """POM_CHAIN_WAIT_US=0 (and 6: only the slower predecessors are given up on, so chained and replayed ticks mix): a wavefront that
+    finds its tile not ready gives up at once and poisons the tile; nobody steps a poisoned
+    tile, and the next call that reads the batch replays the missing ticks from the log of chained calls.  Random moves, the fused
+    SimpleAgent kernel, a move tape and the end-of-tick reset; results must equal the oracle's and tiles must really have been left
+    behind (otherwise the test tests nothing)."""
+    code = r'''
+import numpy as np, sys, torch
+sys.path.insert(0, %r)
+import pomcpp_amd as pa
+from pomcpp_amd.batch import BatchEnvironment, MODE_ENV, ISSUE_CHAIN, RESET_AT_END, CNT_STEPS
+from tests.oracle_lib import Oracle
+from tests.test_gpu_chain import _oracle_explicit, _same
+ora = Oracle()
+n = 16384
+start = pa.make_boards(n, seed=4)
+recovered = 0
+# random moves + SimpleAgent, calls back to back, reads in between
+ref, mems = start.copy(), np.zeros((n, 4, 16), dtype=np.int32)
+env = BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800, streams=3, issue_mode=ISSUE_CHAIN)
+env.make_game(start)
+done = 0
+for ticks in (30, 45, 7):
+    env.step_random(8, 1, ticks=ticks)
+    ora.run_random(ref, start, ticks, 8, 0, done, 1, 800)
+    done += ticks
+assert _same(env.get_state(), ref)
+env.step_random(8, 1, ticks=12)
+env.step_simple(8, 20)
+env.step_random(9, 1, ticks=6)
+ora.run_random(ref, start, 12, 8, 0, done, 1, 800)
+ora.run_simple(ref, start, mems, 20, 8, 0, done + 12, 800)
+ora.run_random(ref, start, 6, 9, 0, done + 32, 1, 800)
+done += 38
+assert _same(env.get_state(), ref) and np.array_equal(env.policy_memory(), mems)
+assert env.counters()[CNT_STEPS] == n * done
+st = env.chain_stats()
+recovered += st["tiles_recovered"]
+assert st["ticks_replayed"] >= st["tiles_recovered"]
+env.close()
+# a move tape with the end-of-tick reset
+m, cap = 2048, 50
+s2 = np.ascontiguousarray(start[:m])
+ref = s2.copy()
+status = [dict(done=0, winner=-1, draw=0) for _ in range(m)]
+rng = np.random.default_rng(2)
+env = BatchEnvironment(m, mode=MODE_ENV, auto_reset=RESET_AT_END, max_steps=cap, streams=3, issue_mode=ISSUE_CHAIN)
+env.make_game(s2)
+for k in (40, 25):
+    tape = rng.integers(0, 6, size=(k, m, 4), dtype=np.int32)
+    env.step_device_many(torch.from_numpy(tape).to("cuda"))
+    for t in range(k):
+        _oracle_explicit(ora, ref, s2, status, tape[t], cap, True)
+    assert _same(env.get_state(), ref)
+recovered += env.chain_stats()["tiles_recovered"]
+env.close()
+assert recovered > 0, "no wavefront ever had to wait: nothing was tested"
+print("ok", recovered)
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, POM_CHAIN_WAIT_US=wait_us), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])

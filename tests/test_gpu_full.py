@@ -44,15 +44,20 @@ def test_full_size_is_deterministic_residency_invariant_and_matches_oracle_sampl
     assert _digest(finals[0][lo:lo + 4096]) == _digest(want)
 
 
-def test_262144_envs_step_counts_and_shard_equivalence(hip_lib):
-    """Config 4's size on one GPU: stepping the whole batch equals stepping its 4 shards with env_offset."""
-    n, ticks, seed = 262144, 12, 5
+def test_262144_envs_step_counts_and_shard_equivalence(hip_lib, oracle):
+    """Config 4's size on one GPU: stepping the whole batch equals stepping its 4 shards with env_offset, and two slices of it
+    (one in the middle, one across the last shard's boundary) equal the oracle."""
+    n, ticks, seed = 262144, 40, 5
     start = pa.make_boards(n, seed=3)
     with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800) as env:
         env.make_game(start)
         env.step_random(seed, DIST_RANDOM, ticks=ticks)
         whole = env.get_state()
         assert env.counters()[CNT_STEPS] == n * ticks
+    for lo, cnt in ((100000, 2048), (3 * (n // 4) - 1000, 2048)):
+        want = np.ascontiguousarray(start[lo:lo + cnt]).copy()
+        oracle.run_random(want, np.ascontiguousarray(start[lo:lo + cnt]), ticks, seed, lo, 0, DIST_RANDOM, 800)
+        assert _digest(whole[lo:lo + cnt]) == _digest(want), lo
     q = n // 4
     for k in (0, 3):
         with BatchEnvironment(q, mode=MODE_ENV, auto_reset=True, max_steps=800, env_offset=k * q) as env:
@@ -336,30 +341,55 @@ def test_issue_modes_give_identical_results(hip_lib, oracle, mode, streams):
         BatchEnvironment(64, issue_mode=7)
 
 
-def test_one_state_path_from_several_threads(hip_lib, oracle):
-    """pom_step is safe to call from several threads (it serialises them: one pinned page, one stream, a mutex) — the reference's
-    Step is re-entrant over distinct States (performance_test.cpp:71-94 steps one env per std::thread)."""
+def test_one_state_path_from_several_threads(hip_lib, oracle, tmp_path):
+    """pom_step is re-entrant over distinct States like the reference's Step (performance_test.cpp:71-94 steps one env per
+    std::thread): every calling thread has a pinned page and a stream of its own.  Eight native threads (tests/cpp/step_threads.cpp),
+    a State each: every final State equals the oracle's, and the threads overlap (together well above one thread's rate)."""
+    import json
+    import subprocess
+    import __graft_entry__ as g
+    exe = g.build_step_threads()
+    n_threads, ticks = 8, 400
+    states = pa.make_boards(n_threads, seed=40, kind="stress")
+    moves = np.random.default_rng(3).integers(0, 6, size=(n_threads, ticks, 4), dtype=np.int32)
+    (tmp_path / "s.bin").write_bytes(states.tobytes())
+    (tmp_path / "m.bin").write_bytes(moves.tobytes())
+    out = subprocess.run([exe, str(n_threads), str(ticks), str(tmp_path / "s.bin"), str(tmp_path / "m.bin")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+
+    def fnv(b):
+        h = 1469598103934665603
+        for x in b:
+            h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return "%016x" % h
+    for k in range(n_threads):
+        ref = np.ascontiguousarray(states[k:k + 1]).copy()
+        for t in range(ticks):
+            oracle.step(ref, moves[k, t])
+        ref["agents"]["pad"] = 0
+        assert r["digests"][k] == fnv(ref.tobytes()), k
+    assert r["calls_per_s_all_threads"] > 2.5 * r["calls_per_s_1_thread"], r
+    # the Python wrapper from Python threads (the GIL is released inside the call)
     import threading
     from pomcpp_amd.batch import step_one
-    n_threads, ticks = 6, 120
-    states = [pa.make_boards(1, seed=40 + k, kind="stress") for k in range(n_threads)]
-    refs = [s.copy() for s in states]
-    moves = [np.random.default_rng(k).integers(0, 6, size=(ticks, 4), dtype=np.int32) for k in range(n_threads)]
+    sts = [np.ascontiguousarray(states[k:k + 1]).copy() for k in range(4)]
+    refs = [s.copy() for s in sts]
     errors = []
 
     def play(k):
         try:
-            for t in range(ticks):
-                step_one(states[k], moves[k][t])
+            for t in range(60):
+                step_one(sts[k], moves[k, t])
         except Exception as exc:  # noqa: BLE001
             errors.append(exc)
-    th = [threading.Thread(target=play, args=(k,)) for k in range(n_threads)]
+    th = [threading.Thread(target=play, args=(k,)) for k in range(4)]
     for x in th:
         x.start()
     for x in th:
         x.join()
     assert not errors, errors
-    for k in range(n_threads):
-        for t in range(ticks):
-            oracle.step(refs[k], moves[k][t])
-        assert _digest(states[k]) == _digest(refs[k]), k
+    for k in range(4):
+        for t in range(60):
+            oracle.step(refs[k], moves[k, t])
+        assert _digest(sts[k]) == _digest(refs[k]), k
