@@ -794,67 +794,112 @@ int pom_batch_issue_info(PomBatch* h, int32_t* issue_mode, int32_t* streams)
 }
 
 /* pom_step / pom_env_step: a pinned, device-mapped page the kernel reads the State from and writes it back to
- * (pom_step_one_kernel), one launch per call, the host polling the kernel's last store.  The reference's Step is re-entrant over
- * distinct States and its performance test steps one env per std::thread (unit_test/bboard/performance_test.cpp:40-50,71-94):
- * every calling thread gets a context of its own — page, stream, sequence number — so that threads stepping their own States do
- * not wait for each other (device 0).  POM_ONE_SLOTS contexts; threads beyond that share (slot = thread number mod slots), which
- * is what the per-slot mutex is for. */
-enum { POM_ONE_SLOTS = 64 };
-struct PomOne {
-    std::mutex mu;
-    int32_t* io = nullptr;     /* host address of the page */
-    int32_t* io_dev = nullptr; /* the same page as the device sees it */
-    hipStream_t stream = nullptr;
-    uint32_t seq = 0;
-    bool ready = false;
+ * (pom_step_one_kernel), the host polling the kernel's last store.  The reference's Step is re-entrant over distinct States and
+ * its performance test steps one env per std::thread (unit_test/bboard/performance_test.cpp:40-50,71-94): every calling thread
+ * gets a slot of its own — a page and a sequence number — and posts its request there.  Launches are COMBINED: whichever
+ * thread gets hold of the launch lock launches one kernel for every request pending at that moment (a workgroup per request),
+ * the others find their page answered without having launched anything — the HIP runtime issues launches of one process one
+ * after the other (~5 us each), so a launch per call would cap eight threads at three times one thread's rate.  Device 0.
+ * POM_ONE_SLOTS slots; threads beyond that share (slot = thread number mod slots), which is what the per-slot mutex is for. */
+struct PomOneShared {
+    std::mutex init_mu, launch_mu;
+    std::mutex slot_mu[POM_ONE_SLOTS];
+    uint32_t seq[POM_ONE_SLOTS] = {};
+    int32_t* io = nullptr;     /* host address of the pages */
+    int32_t* io_dev = nullptr; /* the same pages as the device sees them */
+    enum { STREAMS = 4 };
+    hipStream_t stream[STREAMS] = {};
+    unsigned turn = 0;
+    std::atomic<uint64_t> pending{0};
+    std::atomic<uint64_t> failed{0}; /* requests whose launch failed (answered by the launching thread) */
+    std::atomic<bool> ready{false};
 };
-static PomOne g_one[POM_ONE_SLOTS];
+static PomOneShared g_one;
 static std::atomic<unsigned> g_one_threads{0};
+
+static int one_init(PomOneShared& o)
+{
+    std::lock_guard<std::mutex> g(o.init_mu);
+    if (o.ready.load()) return POM_OK;
+    HIPCHK(hipSetDevice(0));
+    const size_t bytes = (size_t)POM_ONE_SLOTS * POM_ONE_PAGE_DWORDS * 4;
+    if (!o.io) HIPCHK(hipHostMalloc((void**)&o.io, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void**)&o.io_dev, o.io, 0));
+    for (int k = 0; k < PomOneShared::STREAMS; k++)
+        if (!o.stream[k]) HIPCHK(hipStreamCreateWithFlags(&o.stream[k], hipStreamNonBlocking));
+    memset(o.io, 0, bytes);
+    o.ready.store(true);
+    return POM_OK;
+}
+
+/* launch_mu held: one kernel for every request posted so far */
+static void one_launch_pending(PomOneShared& o)
+{
+    const uint64_t mask = o.pending.exchange(0);
+    if (!mask) return;
+    StepOneParams p;
+    p.io_base = o.io_dev;
+    p.slots = mask;
+    (void)hipSetDevice(0);
+    pom_step_one_kernel<<<dim3((unsigned)__builtin_popcountll(mask)), dim3(64), 0, o.stream[o.turn++ % PomOneShared::STREAMS]>>>(p);
+    if (hipGetLastError() != hipSuccess) o.failed.fetch_or(mask); /* their owners report it */
+}
 
 static int step_one(void* state_1004, const int32_t moves[4], int32_t mode, int32_t max_steps, int32_t status4[4])
 {
     if (!state_1004 || !moves) return POM_E_ARG;
+    PomOneShared& o = g_one;
+    if (!o.ready.load())
+        if (int rc = one_init(o)) return rc;
     static thread_local int my_slot = -1;
     if (my_slot < 0) my_slot = (int)(g_one_threads.fetch_add(1) % POM_ONE_SLOTS);
-    PomOne& o = g_one[my_slot];
-    std::lock_guard<std::mutex> lock(o.mu);
-    HIPCHK(hipSetDevice(0));
-    if (!o.ready) {
-        if (!o.io) HIPCHK(hipHostMalloc((void**)&o.io, 4096, hipHostMallocMapped | hipHostMallocCoherent));
-        HIPCHK(hipHostGetDevicePointer((void**)&o.io_dev, o.io, 0));
-        if (!o.stream) HIPCHK(hipStreamCreateWithFlags(&o.stream, hipStreamNonBlocking));
-        memset(o.io, 0, 4096);
-        o.ready = true;
-    }
-    memcpy(o.io, state_1004, POM_STATE_BYTES);
-    memcpy(o.io + POM_ONE_MOVES, moves, 16);
-    StepOneParams p;
-    p.io = o.io_dev;
-    p.mode = mode;
-    p.max_steps = max_steps;
-    p.seq = ++o.seq ? o.seq : ++o.seq; /* never 0: the page starts zeroed */
-    pom_step_one_kernel<<<dim3(1), dim3(64), 0, o.stream>>>(p);
-    HIPCHK(hipGetLastError());
-    /* the kernel's last store is the sequence word; spin on it for a moment (a blocking wait costs more than the tick), then
-     * wait the ordinary way — which is also where a failed launch surfaces */
-    volatile uint32_t* seq_word = reinterpret_cast<volatile uint32_t*>(o.io) + POM_ONE_SEQ;
-    const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
-    while (*seq_word != p.seq && std::chrono::steady_clock::now() < until) {
-    }
-    if (*seq_word != p.seq) {
-        HIPCHK(hipStreamSynchronize(o.stream));
-        if (*seq_word != p.seq) {
-            snprintf(g_err, sizeof g_err, "pom_step: the kernel finished without reporting");
+    const uint64_t bit = 1ull << my_slot;
+    std::lock_guard<std::mutex> lock(o.slot_mu[my_slot]);
+    int32_t* io = o.io + (size_t)my_slot * POM_ONE_PAGE_DWORDS;
+    const uint32_t seq = ++o.seq[my_slot] ? o.seq[my_slot] : ++o.seq[my_slot]; /* never 0: the page starts zeroed */
+    memcpy(io, state_1004, POM_STATE_BYTES);
+    memcpy(io + POM_ONE_MOVES, moves, 16);
+    io[POM_ONE_MODE] = mode;
+    io[POM_ONE_MAX_STEPS] = max_steps;
+    io[POM_ONE_REQ] = (int32_t)seq;
+    o.pending.fetch_or(bit, std::memory_order_release); /* posted: the page is complete */
+    /* until the page is answered: launch what is pending whenever the launch lock is free (my own request, unless somebody
+     * else's launch has taken it along), and watch the sequence word — the kernel's last store */
+    volatile uint32_t* seq_word = reinterpret_cast<volatile uint32_t*>(io) + POM_ONE_SEQ;
+    const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(5);
+    bool synced = false;
+    for (;;) {
+        if (*seq_word == seq) break;
+        if (o.launch_mu.try_lock()) {
+            one_launch_pending(o);
+            o.launch_mu.unlock();
+        }
+        if (o.failed.load() & bit) {
+            o.failed.fetch_and(~bit);
+            snprintf(g_err, sizeof g_err, "pom_step: the kernel launch failed");
             return POM_E_HIP;
+        }
+        for (int spin = 0; spin < 64 && *seq_word != seq; spin++) {
+        }
+        if (*seq_word != seq && std::chrono::steady_clock::now() > until) {
+            if (synced) {
+                snprintf(g_err, sizeof g_err, "pom_step: the kernel finished without reporting");
+                return POM_E_HIP;
+            }
+            /* not within milliseconds: wait the ordinary way — which is also where a device error surfaces */
+            std::lock_guard<std::mutex> g(o.launch_mu);
+            one_launch_pending(o);
+            for (int k = 0; k < PomOneShared::STREAMS; k++) HIPCHK(hipStreamSynchronize(o.stream[k]));
+            synced = true;
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    if (o.io[POM_ONE_BAD]) {
+    if (io[POM_ONE_BAD]) {
         snprintf(g_err, sizeof g_err, "pom_step: the State holds a value outside the representable game states (it was left as it is)");
         return POM_E_UNREPRESENTABLE;
     }
-    memcpy(state_1004, o.io + POM_ONE_OUT, POM_STATE_BYTES);
-    if (status4) memcpy(status4, o.io + POM_ONE_STATUS, 16);
+    memcpy(state_1004, io + POM_ONE_OUT, POM_STATE_BYTES);
+    if (status4) memcpy(status4, io + POM_ONE_STATUS, 16);
     return POM_OK;
 }
 

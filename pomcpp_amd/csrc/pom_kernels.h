@@ -1420,21 +1420,32 @@ __global__ void pom_unpack_kernel(const uint32_t* __restrict__ state, int64_t fi
  *   dwords 256..506  out: the State after the tick               508..511  out: done, winner, draw, ubflags
  *   dword  512       out: 1 if the State is outside the representable game states (nothing else is written then)
  *   dword  513       out: `seq`, written LAST (system-scope release): the host polls it
+ *   dwords 514..516  in:  mode, max_steps, seq of this request
  * One wavefront: all 64 lanes fetch, pack (pom_pack_state's fields, a dword per lane), the quad of lanes 0..3 plays the tick with
  * the same PomStepper as pom_step_kernel, all lanes unpack and write back.
  * ------------------------------------------------------------------------------------------- */
 struct StepOneParams {
-    int32_t* io;
-    int32_t mode, max_steps;
-    uint32_t seq;
+    int32_t* io_base;  /* POM_ONE_SLOTS pages of POM_ONE_PAGE_DWORDS dwords each */
+    uint64_t slots;    /* bit s: slot s holds a request; workgroup b serves the b-th set bit */
 };
-enum { POM_ONE_MOVES = 252, POM_ONE_OUT = 256, POM_ONE_STATUS = 508, POM_ONE_BAD = 512, POM_ONE_SEQ = 513, POM_ONE_DWORDS = 514 };
+/* a slot's page: the layout above, then the request's own parameters — one launch serves whatever requests are pending, each
+ * with its own mode (pom_step / pom_env_step), bound and sequence number */
+enum { POM_ONE_MOVES = 252, POM_ONE_OUT = 256, POM_ONE_STATUS = 508, POM_ONE_BAD = 512, POM_ONE_SEQ = 513, POM_ONE_MODE = 514,
+       POM_ONE_MAX_STEPS = 515, POM_ONE_REQ = 516, POM_ONE_PAGE_DWORDS = 1024, POM_ONE_SLOTS = 64 };
 
-__global__ __launch_bounds__(64) void pom_step_one_kernel(StepOneParams p)
+__global__ __launch_bounds__(64) void pom_step_one_kernel(StepOneParams q)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tile[LDS_ROWS * 16];
     __shared__ int32_t aos[256];
     const int lane = threadIdx.x;
+    /* which slot: the blockIdx-th set bit of the request mask (wave-uniform) */
+    uint64_t slot_bits = q.slots;
+    for (unsigned b = 0; b < blockIdx.x; b++) slot_bits &= slot_bits - 1;
+    struct { int32_t* io; int32_t mode, max_steps; uint32_t seq; } p;
+    p.io = q.io_base + (int64_t)(__ffsll((unsigned long long)slot_bits) - 1) * POM_ONE_PAGE_DWORDS;
+    p.mode = p.io[POM_ONE_MODE];
+    p.max_steps = p.io[POM_ONE_MAX_STEPS];
+    p.seq = (uint32_t)p.io[POM_ONE_REQ];
 #pragma unroll
     for (int k = 0; k < 4; k++) aos[lane + 64 * k] = p.io[lane + 64 * k]; /* State + Move[4]: four 256-B reads of host memory */
     for (int k = lane; k < LDS_ROWS * 16; k += 64) tile[k] = 0u;           /* columns 1..15 stay blank and are never stepped */

@@ -343,13 +343,14 @@ def test_issue_modes_give_identical_results(hip_lib, oracle, mode, streams):
 
 def test_one_state_path_from_several_threads(hip_lib, oracle, tmp_path):
     """pom_step is re-entrant over distinct States like the reference's Step (performance_test.cpp:71-94 steps one env per
-    std::thread): every calling thread has a pinned page and a stream of its own.  Eight native threads (tests/cpp/step_threads.cpp),
-    a State each: every final State equals the oracle's, and the threads overlap (together well above one thread's rate)."""
+    std::thread): every calling thread has a pinned page of its own and launches are combined (one kernel serves every request
+    pending at that moment).  Eight native threads (tests/cpp/step_threads.cpp), a State each: every final State equals the
+    oracle's, and the threads overlap (together well above one thread's rate)."""
     import json
     import subprocess
     import __graft_entry__ as g
     exe = g.build_step_threads()
-    n_threads, ticks = 8, 400
+    n_threads, ticks = 8, 1500
     states = pa.make_boards(n_threads, seed=40, kind="stress")
     moves = np.random.default_rng(3).integers(0, 6, size=(n_threads, ticks, 4), dtype=np.int32)
     (tmp_path / "s.bin").write_bytes(states.tobytes())
@@ -369,7 +370,7 @@ def test_one_state_path_from_several_threads(hip_lib, oracle, tmp_path):
             oracle.step(ref, moves[k, t])
         ref["agents"]["pad"] = 0
         assert r["digests"][k] == fnv(ref.tobytes()), k
-    assert r["calls_per_s_all_threads"] > 2.5 * r["calls_per_s_1_thread"], r
+    assert r["calls_per_s_all_threads"] > 3.0 * r["calls_per_s_1_thread"], r
     # the Python wrapper from Python threads (the GIL is released inside the call)
     import threading
     from pomcpp_amd.batch import step_one
