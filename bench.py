@@ -568,8 +568,25 @@ def worker(args) -> None:
         e3.sync()
         ms_tape = ev6.elapsed_time(ev7) / n_tape
         tape_stats = e3.chain_stats()
+        # an RL tick: explicit moves in, the uint8 global planes + attributes of the resulting state out — as two launches
+        # (pom_batch_step_device, pom_batch_observe) and as one (pom_batch_step_device_observe: the observation is written while the tile
+        # is still in LDS)
+        planes, a_at, e_at = e3.observe()
+        ms_obs = {}
+        for fused in (False, True):
+            for rep in range(2):  # the second pass is the measurement
+                ev6.record(stream)
+                for t in range(n_x):
+                    if fused:
+                        e3.step_device_observe(mv_dev[t % 8], out=planes, attrs=False)
+                    else:
+                        e3.step_device(mv_dev[t % 8].data_ptr())
+                        e3.observe(out=planes, attrs=False)
+                ev7.record(stream)
+                e3.sync()
+            ms_obs[fused] = ev6.elapsed_time(ev7) / n_x
         e3.close()
-        del tape
+        del tape, planes, a_at, e_at
         # Throughput mode: ticks_per_launch = T > 1 keeps the record in LDS for T ticks (synthetic move stream only) —
         # NOT the canonical roofline run (a step there is one HBM round trip per tick); reported on its own, per tick
         for name, n_o, t_o in (("throughput_T4_65536_envs", 65536, 4), ("throughput_T16_65536_envs", 65536, 16),
@@ -629,6 +646,10 @@ def worker(args) -> None:
             "chain_tiles_recovered": tape_stats["tiles_recovered"],
             "note": "pom_batch_step_device_many with auto_reset = POM_RESET_AT_END: a 200-tick Move[4] tape in device memory, chained launches "
                     "(one launch over all tiles per tick on rotating streams, the tile's ticket picks the tape's tick)"}
+        other["step_plus_observation_65536_envs"] = {
+            "one_launch_us": ms_obs[True] * 1e3, "two_launches_us": ms_obs[False] * 1e3, "value": plan["n_envs"] / (ms_obs[True] * 1e-3),
+            "unit": "env-steps/s (each with its uint8 [16][11][11] observation written)",
+            "note": "pom_batch_step_device_observe against pom_batch_step_device + pom_batch_observe, explicit moves, POM_RESET_AT_END"}
         other["explicit_moves_device_65536_envs"] = {
             "value": plan["n_envs"] / (ms_x * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_x, "steps": n_x,
             "note": "pom_batch_step_device with auto_reset = POM_RESET_AT_END: Move[4] from device memory, one launch per tick on the caller's stream"}

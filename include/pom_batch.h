@@ -238,6 +238,12 @@ enum { POM_OBS_U8 = 0, POM_OBS_F16 = 1, POM_OBS_F32 = 2 };
 enum { POM_OBS_PLANES = 16, POM_OBS_AGENT_ATTRS = 8, POM_OBS_ENV_ATTRS = 4 };
 int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_agent, int32_t* agent_attrs_dev,
                       int32_t* env_attrs_dev);
+/* pom_batch_step_device followed by pom_batch_observe in ONE launch: the kernel that plays the tick writes the observation of the
+ * state it leaves behind while the tile is still in LDS (one read of the records and one launch per RL tick instead of two of
+ * each; with POM_RESET_AT_END an env that has just finished shows its next start state, as pom_batch_observe would).  Same
+ * outputs, bit for bit, as the two calls. */
+int pom_batch_step_device_observe(PomBatch* h, const int32_t* moves_dev, void* planes_dev, int32_t dtype, int32_t per_agent,
+                                  int32_t* agent_attrs_dev, int32_t* env_attrs_dev);
 
 /* bboard::Step (include/bboard.hpp:668, src/bboard/step.cpp:9-284) for a single host State on the GPU (device 0): the literal
  * drop-in.  One launch per call: the kernel reads the State and Move[4] from a pinned page, plays the tick and writes the State

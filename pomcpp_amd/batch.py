@@ -82,6 +82,8 @@ def load_library() -> C.CDLL:
     lib.pom_batch_size.argtypes = [P]
     lib.pom_batch_size.restype = I64
     lib.pom_batch_observe.argtypes = [P, VP, I32, I32, VP, VP]
+    if not os.environ.get("POM_LIB") or hasattr(lib, "pom_batch_step_device_observe"):
+        lib.pom_batch_step_device_observe.argtypes = [P, VP, VP, I32, I32, VP, VP]
     lib.pom_batch_stream.argtypes = [P, C.POINTER(C.c_void_p)]
     lib.pom_batch_moves_device.argtypes = [P, C.POINTER(C.POINTER(C.c_int32))]
     lib.pom_batch_generate.argtypes = [P, U64]
@@ -331,7 +333,11 @@ class BatchEnvironment:
         return self.status()["winner"]
 
     # ---- observation export ---------------------------------------------------------
-    def observe(self, per_agent: bool = False, dtype: str = "uint8", attrs: bool = True, out=None):
+    def step_device_observe(self, moves, per_agent: bool = False, dtype: str = "uint8", attrs: bool = True, out=None):
+        """step_device(moves) and observe(...) as ONE launch (pom_batch_step_device_observe): returns what observe() would."""
+        return self.observe(per_agent=per_agent, dtype=dtype, attrs=attrs, out=out, _step_moves=moves)
+
+    def observe(self, per_agent: bool = False, dtype: str = "uint8", attrs: bool = True, out=None, _step_moves=None):
         """Planes of every env as torch tensors on the handle's device, written by one kernel on the handle's stream
         (pom_batch_observe; plane list in include/pom_batch.h).  Returns (planes, agent_attrs, env_attrs): planes
         [n,16,11,11] or [n,4,16,11,11]; agent_attrs int32 [n,4,8]; env_attrs int32 [n,4] (None, None if attrs=False).
@@ -353,9 +359,16 @@ class BatchEnvironment:
         mine, theirs = torch.cuda.ExternalStream(self.stream_handle(), device=dev), torch.cuda.current_stream(dev)
         if mine.cuda_stream != theirs.cuda_stream:
             mine.wait_stream(theirs)
-        _check(self._lib, self._lib.pom_batch_observe(self._h, out.data_ptr(), code, int(per_agent),
-                                                      a_attrs.data_ptr() if attrs else None,
-                                                      e_attrs.data_ptr() if attrs else None))
+        if _step_moves is not None:
+            if tuple(_step_moves.shape) != (self.n, 4) or "int32" not in str(_step_moves.dtype) or not _step_moves.is_contiguous():
+                raise ValueError(f"moves must be a contiguous int32[{self.n}, 4] device tensor")
+            _check(self._lib, self._lib.pom_batch_step_device_observe(self._h, _step_moves.data_ptr(), out.data_ptr(), code, int(per_agent),
+                                                                      a_attrs.data_ptr() if attrs else None,
+                                                                      e_attrs.data_ptr() if attrs else None))
+        else:
+            _check(self._lib, self._lib.pom_batch_observe(self._h, out.data_ptr(), code, int(per_agent),
+                                                          a_attrs.data_ptr() if attrs else None,
+                                                          e_attrs.data_ptr() if attrs else None))
         if mine.cuda_stream != theirs.cuda_stream:
             theirs.wait_stream(mine)
         return out, a_attrs, e_attrs

@@ -528,6 +528,26 @@ int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_
     return POM_OK;
 }
 
+int pom_batch_step_device_observe(PomBatch* h, const int32_t* moves_dev, void* planes_dev, int32_t dtype, int32_t per_agent,
+                                  int32_t* agent_attrs_dev, int32_t* env_attrs_dev)
+{
+    if (!h || !moves_dev || !planes_dev || dtype < POM_OBS_U8 || dtype > POM_OBS_F32) return POM_E_ARG;
+    const int64_t esz = dtype == POM_OBS_U8 ? 1 : dtype == POM_OBS_F16 ? 2 : 4;
+    if (((uintptr_t)planes_dev & (4 * esz - 1)) || ((uintptr_t)agent_attrs_dev & 15) || ((uintptr_t)env_attrs_dev & 15) ||
+        (dtype == POM_OBS_U8 && !per_agent && ((uintptr_t)planes_dev & 15)))
+    {
+        snprintf(g_err, sizeof g_err, "pom_batch_step_device_observe: output pointers must be 16-byte aligned");
+        return POM_E_ARG;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->quad) { /* the one-lane-per-env shapes have no fused twin: the two launches */
+        if (int rc = pom_batch_step_device(h, moves_dev)) return rc;
+        return pom_batch_observe(h, planes_dev, dtype, per_agent, agent_attrs_dev, env_attrs_dev);
+    }
+    const PomObserveOut obs = {planes_dev, agent_attrs_dev, env_attrs_dev, dtype, per_agent ? 1 : 0};
+    return launch_step(h, moves_dev, 0, 0, 1, false, true, &obs);
+}
+
 int pom_batch_generate(PomBatch* h, uint64_t board_seed)
 {
     if (!h) return POM_E_ARG;

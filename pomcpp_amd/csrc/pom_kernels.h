@@ -129,6 +129,12 @@ struct StepParams {
     uint32_t tape_len;         /* CHAIN with explicit moves: `moves` is a tape int32[tape_len][n][4], the visit at distance d from
                                   chain_seq0 plays tick d of it (0: `moves` is one tick's Move[4] array or nullptr) */
     uint64_t chain_wait_limit; /* how long a wavefront waits for the visit before its own, in ticks of the 100 MHz wall clock */
+    /* OBS instantiation (pom_batch_step_device_observe): the planes / attributes of the state the tick leaves behind, written by
+     * the same launch while the tile is still in LDS (pom_batch.h pom_batch_observe for the layout) */
+    void* obs_planes;
+    int32_t* obs_agent_attrs;
+    int32_t* obs_env_attrs;
+    int32_t obs_dtype, obs_per_agent;
 #if defined(POM_DIAG)
     long long* diag; /* POM_PH_N accumulators per wavefront, diagnostic build only */
 #endif
@@ -512,6 +518,195 @@ __device__ __forceinline__ int pom_policy_wave(Store& st, const PomPolicyEnv& E,
     return mv;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Observation export (row f4, pom_batch.h pom_batch_observe).  A wavefront takes a tile of 16 envs into LDS as the tick does,
+ * then env by env: zero a 1936-byte staging area, scatter one byte per cell / bomb (each cell sets exactly one
+ * of the planes 0..11), and stream the area out — for uint8 global views a straight 16-byte copy, fully coalesced; other
+ * element types and the per-agent plane order take runs of 4 bytes through a byte funnel, convert and store 4 elements.  HBM-write-bound: 1936 B x elements per env.
+ * ------------------------------------------------------------------------------------------- */
+#ifndef POM_OBS_PASS_ENVS
+#define POM_OBS_PASS_ENVS 1 /* envs staged at a time: 1 keeps the wavefront at 9 KB of LDS (17 per CU); 4 needed 15 KB and ran 25 % slower */
+#endif
+enum { OBS_ENV_BYTES = POM_OBS_PLANES * POM_CELLS, OBS_PASS_ENVS = POM_OBS_PASS_ENVS };
+static_assert(OBS_ENV_BYTES % 16 == 0, "an env's planes are a whole number of 16-byte stores");
+
+struct ObserveParams {
+    const uint32_t* state;
+    int64_t n, n_pad, block0;
+    void* planes;
+    int32_t* agent_attrs;
+    int32_t* env_attrs;
+    int32_t dtype, per_agent;
+};
+
+__device__ __forceinline__ int obs_plane_of(int code) /* which of the planes 0..11 a cell code sets, -1 = none (fog, ...) */
+{
+    if (code == 0) return 0;
+    if (code == 1) return 1;
+    if (pc_is_wood(code)) return 2;
+    if (code == POM_C_BOMB) return 3;
+    if (pc_is_flame(code)) return 4;
+    if (pc_is_powerup(code)) return code - 1; /* 6, 7, 8 -> 5, 6, 7 */
+    if (pc_is_agent(code)) return 8 + (code & 3);
+    return -1;
+}
+
+/* four staged bytes starting at byte offset `b` of the staging area (any alignment): two aligned dwords and a byte funnel */
+__device__ __forceinline__ uint32_t obs_bytes4(const uint32_t* stage_w, int b)
+{
+    const uint32_t lo = stage_w[b >> 2], hi = stage_w[(b >> 2) + 1];
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(b & 3));
+}
+template <class T>
+__device__ __forceinline__ void obs_store4(T* dst, uint32_t bytes);
+template <>
+__device__ __forceinline__ void obs_store4<uint8_t>(uint8_t* dst, uint32_t bytes) { *reinterpret_cast<uint32_t*>(dst) = bytes; }
+template <>
+__device__ __forceinline__ void obs_store4<_Float16>(_Float16* dst, uint32_t bytes)
+{
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<half4*>(dst) = half4{(_Float16)(float)(bytes & 0xFF), (_Float16)(float)((bytes >> 8) & 0xFF),
+                                           (_Float16)(float)((bytes >> 16) & 0xFF), (_Float16)(float)(bytes >> 24)};
+}
+template <>
+__device__ __forceinline__ void obs_store4<float>(float* dst, uint32_t bytes)
+{
+    *reinterpret_cast<float4*>(dst) = make_float4((float)(bytes & 0xFF), (float)((bytes >> 8) & 0xFF), (float)((bytes >> 16) & 0xFF),
+                                                  (float)(bytes >> 24));
+}
+
+/* the generic way out of the staging area: element type T, `views` plane orders per env.  A lane takes 4 consecutive output
+ * elements per round (one aligned 4 / 8 / 16-byte store): their source bytes are consecutive in the staging area unless the
+ * group crosses a plane boundary (planes are 121 bytes, and the four agent planes are permuted per view), so it fetches the
+ * run starting at its first element and the run ending at its last one and splices them at the boundary.  Plane and offset
+ * advance incrementally (64 lanes x 4 elements = 2 planes + 14 per round): no division in the loop. */
+template <class T>
+__device__ __forceinline__ void obs_gather_out(const ObserveParams& p, const uint32_t* stage_w, int64_t e0, int lane)
+{
+    const int views = p.per_agent ? 4 : 1;
+    T* out = reinterpret_cast<T*>(p.planes);
+    for (int ei = 0; ei < OBS_PASS_ENVS && e0 + ei < p.n; ei++) {
+        for (int a = 0; a < views; a++) {
+            T* dst = out + ((e0 + ei) * views + a) * (int64_t)OBS_ENV_BYTES;
+            int pl = (4 * lane) / POM_CELLS, off = 4 * lane - pl * POM_CELLS; /* of the group's first element */
+            POM_NOUNROLL
+            for (int el = 4 * lane; el < OBS_ENV_BYTES; el += 256) {
+                const int src0 = (pl >= 8 && pl < 12) ? 8 + ((pl - 8 + a) & 3) : pl;
+                const int pn = pl + 1, src1 = (pn >= 8 && pn < 12) ? 8 + ((pn - 8 + a) & 3) : pn;
+                const int room = POM_CELLS - off; /* elements left in this plane, >= 1 */
+                const uint32_t head = obs_bytes4(stage_w, ei * OBS_ENV_BYTES + src0 * POM_CELLS + off);
+                /* the next plane's first bytes, placed where they belong in the group (only read when the group crosses) */
+                const uint32_t tail = obs_bytes4(stage_w, ei * OBS_ENV_BYTES + (room < 4 ? src1 * POM_CELLS - room : src0 * POM_CELLS + off));
+                const uint32_t keep = room >= 4 ? 0xFFFFFFFFu : (1u << (8 * room)) - 1u;
+                obs_store4<T>(dst + el, (head & keep) | (tail & ~keep));
+                off += 256 - 2 * POM_CELLS; /* 256 = 2 x 121 + 14 */
+                pl += 2;
+                if (off >= POM_CELLS) {
+                    off -= POM_CELLS;
+                    pl++;
+                }
+            }
+        }
+    }
+}
+
+/* the planes and attributes of one tile's 16 envs, from the tile as it lies in LDS ([row][16] dwords); `stage`: OBS_STAGE_VECS
+ * uint4 of LDS.  Called by the whole wavefront (one wavefront per workgroup: the barriers only order its own LDS traffic). */
+enum { OBS_STAGE_VECS = OBS_PASS_ENVS * OBS_ENV_BYTES / 16 + 1 }; /* + 16 B: the byte funnel reads one dword past a run */
+__device__ __forceinline__ void pom_observe_tile(const ObserveParams& p, const uint32_t* tile, uint4* stage, int64_t tile_id, int lane)
+{
+    uint8_t* stage_b = reinterpret_cast<uint8_t*>(stage);
+    const uint16_t* tile_h = reinterpret_cast<const uint16_t*>(tile);
+
+    for (int q = 0; q < 16 / OBS_PASS_ENVS; q++) {
+        const int64_t e0 = tile_id * 16 + q * OBS_PASS_ENVS;
+        if (e0 >= p.n) break;
+        constexpr int VECS = OBS_PASS_ENVS * OBS_ENV_BYTES / 16; /* 484 */
+#pragma unroll
+        for (int i = 0; i < (VECS + 63) / 64; i++)
+            if (lane + 64 * i < VECS) stage[lane + 64 * i] = make_uint4(0, 0, 0, 0);
+        __syncthreads(); /* one wavefront per workgroup: orders the phases' LDS traffic, costs no wait */
+        /* cells: one byte each into the plane its code names; flame cells also look their flame up */
+#pragma unroll
+        for (int i = 0; i < (OBS_PASS_ENVS * POM_CELLS + 63) / 64; i++) {
+            const int idx = lane + 64 * i;
+            if (idx >= OBS_PASS_ENVS * POM_CELLS) break;
+            const int ei = idx / POM_CELLS, c = idx - ei * POM_CELLS, ec = q * OBS_PASS_ENVS + ei;
+            const int code = tile_h[(c >> 1) * 32 + 2 * ec + (c & 1)];
+            const int pl = obs_plane_of(code);
+            uint8_t* o = stage_b + ei * OBS_ENV_BYTES + c;
+            if (pl >= 0) o[pl * POM_CELLS] = 1;
+            if (pl == 4) {
+                const int id = (code & 0x3FFF) >> 3;
+                const uint32_t m = tile[POM_REC_META * 16 + ec], m2 = tile[POM_REC_META2 * 16 + ec];
+                const int fIdx = (int)(m >> 24), fCnt = (int)(m2 & 0xFF);
+                POM_NOUNROLL
+                for (int k = 0; k < fCnt && k < POM_Q; k++) {
+                    const uint32_t f = tile[(POM_REC_FLAMES + wrap20(fIdx + k)) * 16 + ec];
+                    if ((int)(f & 0xFF) + POM_N * (int)((f >> 8) & 0xFF) == id) {
+                        const int tl = pom_sext8(f >> 16);
+                        o[15 * POM_CELLS] = (uint8_t)(tl < 0 ? 0 : tl);
+                        break;
+                    }
+                }
+            }
+        }
+        /* bombs: the first live bomb on a cell speaks for it */
+#pragma unroll
+        for (int i = 0; i < (OBS_PASS_ENVS * POM_Q + 63) / 64; i++) {
+            const int idx = lane + 64 * i;
+            if (idx >= OBS_PASS_ENVS * POM_Q) break;
+            const int ei = idx / POM_Q, k = idx - ei * POM_Q, ec = q * OBS_PASS_ENVS + ei;
+            const uint32_t m = tile[POM_REC_META * 16 + ec];
+            const int bIdx = (int)((m >> 8) & 0xFF), bCnt = (int)((m >> 16) & 0xFF);
+            if (k >= bCnt) continue;
+            const int b = (int)tile[(POM_REC_BOMBS + wrap20(bIdx + k)) * 16 + ec];
+            int first = 1;
+            POM_NOUNROLL
+            for (int j = 0; j < k; j++) first &= pb_pos((int)tile[(POM_REC_BOMBS + wrap20(bIdx + j)) * 16 + ec]) != pb_pos(b);
+            if (!first || pb_x(b) >= POM_N || pb_y(b) >= POM_N) continue;
+            uint8_t* o = stage_b + ei * OBS_ENV_BYTES + pb_y(b) * POM_N + pb_x(b);
+            o[12 * POM_CELLS] = (uint8_t)pb_strength(b);
+            o[13 * POM_CELLS] = (uint8_t)pb_time(b);
+            o[14 * POM_CELLS] = (uint8_t)pb_dir(b);
+        }
+        /* out */
+        __syncthreads();
+        if (p.dtype == POM_OBS_U8 && !p.per_agent) {
+            uint4* out = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(p.planes) + e0 * OBS_ENV_BYTES);
+#pragma unroll
+            for (int i = 0; i < (VECS + 63) / 64; i++) {
+                const int idx = lane + 64 * i;
+                if (idx < VECS && e0 + idx / (OBS_ENV_BYTES / 16) < p.n) out[idx] = stage[idx];
+            }
+        } else if (p.dtype == POM_OBS_U8) {
+            obs_gather_out<uint8_t>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
+        } else if (p.dtype == POM_OBS_F16) {
+            obs_gather_out<_Float16>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
+        } else {
+            obs_gather_out<float>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
+        }
+        __syncthreads();
+    }
+    /* attributes: lane -> (env lane/4, agent lane%4), 32 contiguous bytes each */
+    const int ec = lane >> 2, id = lane & 3;
+    const int64_t e = tile_id * 16 + ec;
+    if (e < p.n && p.agent_attrs) {
+        const uint32_t a0 = tile[(POM_REC_AGENTS + 2 * id) * 16 + ec], a1 = tile[(POM_REC_AGENTS + 2 * id + 1) * 16 + ec];
+        const int bc = pom_sext8(a0 >> 16), mx = pom_sext16(a1);
+        int4* o = reinterpret_cast<int4*>(p.agent_attrs + (e * 4 + id) * POM_OBS_AGENT_ATTRS);
+        o[0] = make_int4((int)(a0 & 0xFF), (int)((a0 >> 8) & 0xFF), (int)!((a0 >> 25) & 1), mx - bc);
+        o[1] = make_int4(bc, mx, (int)(a1 >> 16), (int)((a0 >> 24) & 1));
+    }
+    if (lane < 16 && tile_id * 16 + lane < p.n && p.env_attrs) {
+        const uint32_t m = tile[POM_REC_META * 16 + lane], st = (tile[POM_REC_META2 * 16 + lane] >> 8) & 0xFF;
+        const int status = (int)((st & POM_ST_DONE) ? 1 : 0) | (int)((st & POM_ST_DRAW) ? 2 : 0) | (int)((st & POM_ST_TIMEOUT) ? 4 : 0) |
+                           (int)((st & POM_ST_RESTARTED) ? 8 : 0);
+        reinterpret_cast<int4*>(p.env_attrs)[tile_id * 16 + lane] =
+            make_int4((int)tile[POM_REC_TIMESTEP * 16 + lane], pom_sext8(m), status, (int)((st >> POM_ST_WINNER_SHIFT) & 7) - 1);
+    }
+}
+
 /* occupancy target of the quad kernel: 4 wavefronts per SIMD = 16 per CU = every one of 65,536 envs' wavefronts resident at
  * once.  The kernel needs 120-128 VGPRs; the target keeps the compiler from drifting past 128 (which would drop a whole
  * round's worth of wavefronts to a second round) — at the price of a spill or two if it ever has to.  History: an early
@@ -551,10 +746,13 @@ __device__ __forceinline__ uint32_t pom_load_shared(const uint32_t* ptr)
     return CHAIN ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
 }
 
-template <int EPW, int G, bool FRESH, bool POLICY = false, bool ATEND = false, bool SINGLE = false, bool CHAIN = false>
+/* OBS: the launch also writes the observation of the state it leaves behind (pom_observe_tile) — an RL tick is then one launch
+ * and one read of the record instead of two of each. */
+template <int EPW, int G, bool FRESH, bool POLICY = false, bool ATEND = false, bool SINGLE = false, bool CHAIN = false, bool OBS = false>
 __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW == 32 ? 2 : 1)) void pom_step_kernel(StepParams p)
 {
     static_assert(!CHAIN || SINGLE, "chained launches play one tick each");
+    static_assert(!OBS || (SINGLE && !CHAIN && !POLICY && POM_WPB == 1), "the fused observation exists for the one-tick explicit-move shape");
     static_assert(!SINGLE || G == 4, "the one-tick instantiation exists for the quad shape");
     static_assert(G == 1 || (G == 4 && EPW == 16), "a quad per env needs 16 envs per wavefront");
     static_assert(!POLICY || G == 4, "the policy runs one agent per lane of the quad");
@@ -562,7 +760,10 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     /* POLICY: the danger map (32 rows of bytes) and the cell sets (12 rows) live where the tick keeps its bomb destinations
      * and explosion frames (26 rows) — the policy of a tick is over before its tick begins.  156 rows = 9,984 B: 16
      * wavefronts per CU, i.e. all of 65,536 envs resident at once. */
-    constexpr int ROWS = POLICY ? POM_REC_DWORDS + 44 : LDS_ROWS;
+    /* OBS: the staging area of one env's planes (1,936 + 16 B = 31 rows) lies over the same scratch rows — the tick is over when
+     * the observation begins: 143 rows = 9,152 B, still 16 wavefronts per CU */
+    constexpr int OBS_ROWS = (OBS_STAGE_VECS * 16 + EPW * 4 - 1) / (EPW * 4);
+    constexpr int ROWS = POLICY ? POM_REC_DWORDS + 44 : OBS ? POM_REC_DWORDS + (OBS_ROWS > 26 ? OBS_ROWS : 26) : LDS_ROWS;
     static_assert(ROWS >= LDS_ROWS, "the tick's scratch rows fit under the overlay");
     __shared__ __attribute__((aligned(16))) uint32_t tiles_[POM_WPB][ROWS * EPW];
     uint32_t* const tile = tiles_[POM_WPB == 1 ? 0 : threadIdx.x >> 6];
@@ -954,6 +1155,22 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     } else {
         store_tile<EPW>(col_d, POM_TILE_ENVS, tile, sub, el);
     }
+    if (OBS) {
+        /* the observation of what the tick left in the tile, while the record's stores are on their way (they have been read out
+         * of LDS into registers; the staging area lies behind the record rows) */
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ObserveParams op;
+        op.state = nullptr;
+        op.n = p.n;
+        op.n_pad = p.n_pad;
+        op.block0 = 0;
+        op.planes = p.obs_planes;
+        op.agent_attrs = p.obs_agent_attrs;
+        op.env_attrs = p.obs_env_attrs;
+        op.dtype = p.obs_dtype;
+        op.per_agent = p.obs_per_agent;
+        pom_observe_tile(op, tile, reinterpret_cast<uint4*>(tile + POM_REC_DWORDS * EPW), tile_id, lane);
+    }
     if (CHAIN) { /* the record's stores have been acknowledged by the L2 before the word that hands the tile on is written */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, chain_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1153,104 +1370,11 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
 #endif
 }
 
-/* ------------------------------------------------------------------------------------------------
- * Observation export (row f4, pom_batch.h pom_batch_observe).  A wavefront takes a tile of 16 envs into LDS as the tick does,
- * then env by env: zero a 1936-byte staging area, scatter one byte per cell / bomb (each cell sets exactly one
- * of the planes 0..11), and stream the area out — for uint8 global views a straight 16-byte copy, fully coalesced; other
- * element types and the per-agent plane order take runs of 4 bytes through a byte funnel, convert and store 4 elements.  HBM-write-bound: 1936 B x elements per env.
- * ------------------------------------------------------------------------------------------- */
-#ifndef POM_OBS_PASS_ENVS
-#define POM_OBS_PASS_ENVS 1 /* envs staged at a time: 1 keeps the wavefront at 9 KB of LDS (17 per CU); 4 needed 15 KB and ran 25 % slower */
-#endif
-enum { OBS_ENV_BYTES = POM_OBS_PLANES * POM_CELLS, OBS_PASS_ENVS = POM_OBS_PASS_ENVS };
-static_assert(OBS_ENV_BYTES % 16 == 0, "an env's planes are a whole number of 16-byte stores");
-
-struct ObserveParams {
-    const uint32_t* state;
-    int64_t n, n_pad, block0;
-    void* planes;
-    int32_t* agent_attrs;
-    int32_t* env_attrs;
-    int32_t dtype, per_agent;
-};
-
-__device__ __forceinline__ int obs_plane_of(int code) /* which of the planes 0..11 a cell code sets, -1 = none (fog, ...) */
-{
-    if (code == 0) return 0;
-    if (code == 1) return 1;
-    if (pc_is_wood(code)) return 2;
-    if (code == POM_C_BOMB) return 3;
-    if (pc_is_flame(code)) return 4;
-    if (pc_is_powerup(code)) return code - 1; /* 6, 7, 8 -> 5, 6, 7 */
-    if (pc_is_agent(code)) return 8 + (code & 3);
-    return -1;
-}
-
-/* four staged bytes starting at byte offset `b` of the staging area (any alignment): two aligned dwords and a byte funnel */
-__device__ __forceinline__ uint32_t obs_bytes4(const uint32_t* stage_w, int b)
-{
-    const uint32_t lo = stage_w[b >> 2], hi = stage_w[(b >> 2) + 1];
-    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(b & 3));
-}
-template <class T>
-__device__ __forceinline__ void obs_store4(T* dst, uint32_t bytes);
-template <>
-__device__ __forceinline__ void obs_store4<uint8_t>(uint8_t* dst, uint32_t bytes) { *reinterpret_cast<uint32_t*>(dst) = bytes; }
-template <>
-__device__ __forceinline__ void obs_store4<_Float16>(_Float16* dst, uint32_t bytes)
-{
-    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-    *reinterpret_cast<half4*>(dst) = half4{(_Float16)(float)(bytes & 0xFF), (_Float16)(float)((bytes >> 8) & 0xFF),
-                                           (_Float16)(float)((bytes >> 16) & 0xFF), (_Float16)(float)(bytes >> 24)};
-}
-template <>
-__device__ __forceinline__ void obs_store4<float>(float* dst, uint32_t bytes)
-{
-    *reinterpret_cast<float4*>(dst) = make_float4((float)(bytes & 0xFF), (float)((bytes >> 8) & 0xFF), (float)((bytes >> 16) & 0xFF),
-                                                  (float)(bytes >> 24));
-}
-
-/* the generic way out of the staging area: element type T, `views` plane orders per env.  A lane takes 4 consecutive output
- * elements per round (one aligned 4 / 8 / 16-byte store): their source bytes are consecutive in the staging area unless the
- * group crosses a plane boundary (planes are 121 bytes, and the four agent planes are permuted per view), so it fetches the
- * run starting at its first element and the run ending at its last one and splices them at the boundary.  Plane and offset
- * advance incrementally (64 lanes x 4 elements = 2 planes + 14 per round): no division in the loop. */
-template <class T>
-__device__ __forceinline__ void obs_gather_out(const ObserveParams& p, const uint32_t* stage_w, int64_t e0, int lane)
-{
-    const int views = p.per_agent ? 4 : 1;
-    T* out = reinterpret_cast<T*>(p.planes);
-    for (int ei = 0; ei < OBS_PASS_ENVS && e0 + ei < p.n; ei++) {
-        for (int a = 0; a < views; a++) {
-            T* dst = out + ((e0 + ei) * views + a) * (int64_t)OBS_ENV_BYTES;
-            int pl = (4 * lane) / POM_CELLS, off = 4 * lane - pl * POM_CELLS; /* of the group's first element */
-            POM_NOUNROLL
-            for (int el = 4 * lane; el < OBS_ENV_BYTES; el += 256) {
-                const int src0 = (pl >= 8 && pl < 12) ? 8 + ((pl - 8 + a) & 3) : pl;
-                const int pn = pl + 1, src1 = (pn >= 8 && pn < 12) ? 8 + ((pn - 8 + a) & 3) : pn;
-                const int room = POM_CELLS - off; /* elements left in this plane, >= 1 */
-                const uint32_t head = obs_bytes4(stage_w, ei * OBS_ENV_BYTES + src0 * POM_CELLS + off);
-                /* the next plane's first bytes, placed where they belong in the group (only read when the group crosses) */
-                const uint32_t tail = obs_bytes4(stage_w, ei * OBS_ENV_BYTES + (room < 4 ? src1 * POM_CELLS - room : src0 * POM_CELLS + off));
-                const uint32_t keep = room >= 4 ? 0xFFFFFFFFu : (1u << (8 * room)) - 1u;
-                obs_store4<T>(dst + el, (head & keep) | (tail & ~keep));
-                off += 256 - 2 * POM_CELLS; /* 256 = 2 x 121 + 14 */
-                pl += 2;
-                if (off >= POM_CELLS) {
-                    off -= POM_CELLS;
-                    pl++;
-                }
-            }
-        }
-    }
-}
-
 __global__ __launch_bounds__(64) void pom_observe_kernel(ObserveParams p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tile[POM_REC_DWORDS * 16];
-    __shared__ uint4 stage[OBS_PASS_ENVS * OBS_ENV_BYTES / 16 + 1]; /* + 16 B: the byte funnel reads one dword past a run */
+    __shared__ uint4 stage[OBS_STAGE_VECS];
     const int lane = threadIdx.x;
-    const int64_t np = p.n_pad;
     int64_t tile_local;
     {
         const int64_t b = blockIdx.x, nb = gridDim.x, q = nb / 8, r = nb % 8, x = b % 8;
@@ -1259,96 +1383,7 @@ __global__ __launch_bounds__(64) void pom_observe_kernel(ObserveParams p)
     const int64_t tile_id = p.block0 + tile_local;
     load_tile16_x4(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint8_t* stage_b = reinterpret_cast<uint8_t*>(stage);
-    const uint16_t* tile_h = reinterpret_cast<const uint16_t*>(tile);
-
-    for (int q = 0; q < 16 / OBS_PASS_ENVS; q++) {
-        const int64_t e0 = tile_id * 16 + q * OBS_PASS_ENVS;
-        if (e0 >= p.n) break;
-        constexpr int VECS = OBS_PASS_ENVS * OBS_ENV_BYTES / 16; /* 484 */
-#pragma unroll
-        for (int i = 0; i < (VECS + 63) / 64; i++)
-            if (lane + 64 * i < VECS) stage[lane + 64 * i] = make_uint4(0, 0, 0, 0);
-        __syncthreads(); /* one wavefront per workgroup: orders the phases' LDS traffic, costs no wait */
-        /* cells: one byte each into the plane its code names; flame cells also look their flame up */
-#pragma unroll
-        for (int i = 0; i < (OBS_PASS_ENVS * POM_CELLS + 63) / 64; i++) {
-            const int idx = lane + 64 * i;
-            if (idx >= OBS_PASS_ENVS * POM_CELLS) break;
-            const int ei = idx / POM_CELLS, c = idx - ei * POM_CELLS, ec = q * OBS_PASS_ENVS + ei;
-            const int code = tile_h[(c >> 1) * 32 + 2 * ec + (c & 1)];
-            const int pl = obs_plane_of(code);
-            uint8_t* o = stage_b + ei * OBS_ENV_BYTES + c;
-            if (pl >= 0) o[pl * POM_CELLS] = 1;
-            if (pl == 4) {
-                const int id = (code & 0x3FFF) >> 3;
-                const uint32_t m = tile[POM_REC_META * 16 + ec], m2 = tile[POM_REC_META2 * 16 + ec];
-                const int fIdx = (int)(m >> 24), fCnt = (int)(m2 & 0xFF);
-                POM_NOUNROLL
-                for (int k = 0; k < fCnt && k < POM_Q; k++) {
-                    const uint32_t f = tile[(POM_REC_FLAMES + wrap20(fIdx + k)) * 16 + ec];
-                    if ((int)(f & 0xFF) + POM_N * (int)((f >> 8) & 0xFF) == id) {
-                        const int tl = pom_sext8(f >> 16);
-                        o[15 * POM_CELLS] = (uint8_t)(tl < 0 ? 0 : tl);
-                        break;
-                    }
-                }
-            }
-        }
-        /* bombs: the first live bomb on a cell speaks for it */
-#pragma unroll
-        for (int i = 0; i < (OBS_PASS_ENVS * POM_Q + 63) / 64; i++) {
-            const int idx = lane + 64 * i;
-            if (idx >= OBS_PASS_ENVS * POM_Q) break;
-            const int ei = idx / POM_Q, k = idx - ei * POM_Q, ec = q * OBS_PASS_ENVS + ei;
-            const uint32_t m = tile[POM_REC_META * 16 + ec];
-            const int bIdx = (int)((m >> 8) & 0xFF), bCnt = (int)((m >> 16) & 0xFF);
-            if (k >= bCnt) continue;
-            const int b = (int)tile[(POM_REC_BOMBS + wrap20(bIdx + k)) * 16 + ec];
-            int first = 1;
-            POM_NOUNROLL
-            for (int j = 0; j < k; j++) first &= pb_pos((int)tile[(POM_REC_BOMBS + wrap20(bIdx + j)) * 16 + ec]) != pb_pos(b);
-            if (!first || pb_x(b) >= POM_N || pb_y(b) >= POM_N) continue;
-            uint8_t* o = stage_b + ei * OBS_ENV_BYTES + pb_y(b) * POM_N + pb_x(b);
-            o[12 * POM_CELLS] = (uint8_t)pb_strength(b);
-            o[13 * POM_CELLS] = (uint8_t)pb_time(b);
-            o[14 * POM_CELLS] = (uint8_t)pb_dir(b);
-        }
-        /* out */
-        __syncthreads();
-        if (p.dtype == POM_OBS_U8 && !p.per_agent) {
-            uint4* out = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(p.planes) + e0 * OBS_ENV_BYTES);
-#pragma unroll
-            for (int i = 0; i < (VECS + 63) / 64; i++) {
-                const int idx = lane + 64 * i;
-                if (idx < VECS && e0 + idx / (OBS_ENV_BYTES / 16) < p.n) out[idx] = stage[idx];
-            }
-        } else if (p.dtype == POM_OBS_U8) {
-            obs_gather_out<uint8_t>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
-        } else if (p.dtype == POM_OBS_F16) {
-            obs_gather_out<_Float16>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
-        } else {
-            obs_gather_out<float>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
-        }
-        __syncthreads();
-    }
-    /* attributes: lane -> (env lane/4, agent lane%4), 32 contiguous bytes each */
-    const int ec = lane >> 2, id = lane & 3;
-    const int64_t e = tile_id * 16 + ec;
-    if (e < p.n && p.agent_attrs) {
-        const uint32_t a0 = tile[(POM_REC_AGENTS + 2 * id) * 16 + ec], a1 = tile[(POM_REC_AGENTS + 2 * id + 1) * 16 + ec];
-        const int bc = pom_sext8(a0 >> 16), mx = pom_sext16(a1);
-        int4* o = reinterpret_cast<int4*>(p.agent_attrs + (e * 4 + id) * POM_OBS_AGENT_ATTRS);
-        o[0] = make_int4((int)(a0 & 0xFF), (int)((a0 >> 8) & 0xFF), (int)!((a0 >> 25) & 1), mx - bc);
-        o[1] = make_int4(bc, mx, (int)(a1 >> 16), (int)((a0 >> 24) & 1));
-    }
-    if (lane < 16 && tile_id * 16 + lane < p.n && p.env_attrs) {
-        const uint32_t m = tile[POM_REC_META * 16 + lane], st = (tile[POM_REC_META2 * 16 + lane] >> 8) & 0xFF;
-        const int status = (int)((st & POM_ST_DONE) ? 1 : 0) | (int)((st & POM_ST_DRAW) ? 2 : 0) | (int)((st & POM_ST_TIMEOUT) ? 4 : 0) |
-                           (int)((st & POM_ST_RESTARTED) ? 8 : 0);
-        reinterpret_cast<int4*>(p.env_attrs)[tile_id * 16 + lane] =
-            make_int4((int)tile[POM_REC_TIMESTEP * 16 + lane], pom_sext8(m), status, (int)((st >> POM_ST_WINNER_SHIFT) & 7) - 1);
-    }
+    pom_observe_tile(p, tile, stage, tile_id, lane);
 }
 
 /* every env's first board (episode 0) into its state and snapshot columns, through an LDS tile so that the records leave in

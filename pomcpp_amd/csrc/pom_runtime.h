@@ -215,6 +215,9 @@ static int fill_params(PomBatch* h, StepParams& p, const int32_t* moves_dev, uin
     p.chain_seq0 = 0;
     p.tape_len = 0;
     p.chain_wait_limit = 0;
+    p.obs_planes = nullptr;
+    p.obs_agent_attrs = p.obs_env_attrs = nullptr;
+    p.obs_dtype = p.obs_per_agent = 0;
 #if defined(POM_DIAG)
     if (!h->diag) {
         HIPCHK(hipMalloc((void**)&h->diag, (size_t)h->n_waves * POM_PH_N * 8));
@@ -257,23 +260,47 @@ static const void* step_kernel_for(const PomBatch* h, bool policy, bool one_tick
     return reinterpret_cast<const void*>(k);
 }
 
+/* the one-tick kernel that also writes the observation of the state it leaves behind (explicit moves, quad shape) */
+static const void* step_observe_kernel_for(const PomBatch* h)
+{
+    static const PomStepKernel k[4] = {
+        pom_step_kernel<16, 4, false, false, false, true, false, true>, pom_step_kernel<16, 4, false, false, true, true, false, true>,
+        pom_step_kernel<16, 4, true, false, false, true, false, true>,  pom_step_kernel<16, 4, true, false, true, true, false, true>};
+    return reinterpret_cast<const void*>(k[(runs_fresh(h) ? 2 : 0) | (runs_at_end(h) ? 1 : 0)]);
+}
+
 /* one dispatch of the step kernel the handle is configured for, over tiles [p.block0, p.block_end) */
 static hipError_t dispatch_step(const PomBatch* h, const StepParams& p, hipStream_t st, bool policy, hipEvent_t ev0, hipEvent_t ev1)
 {
     const dim3 grid((unsigned)((p.block_end - p.block0 + POM_WPB - 1) / POM_WPB));
     StepParams q = p;
     void* args[1] = {&q};
-    return hipExtLaunchKernel(step_kernel_for(h, policy, p.ticks == 1), grid, dim3(64 * POM_WPB), args, 0, st, ev0, ev1, 0);
+    const void* kernel = p.obs_planes ? step_observe_kernel_for(h) : step_kernel_for(h, policy, p.ticks == 1);
+    return hipExtLaunchKernel(kernel, grid, dim3(64 * POM_WPB), args, 0, st, ev0, ev1, 0);
 }
 
 /* `one_launch`: the whole batch in ONE launch on the caller's stream.  For steps that have to be joined with the caller's stream
  * every tick (explicit moves): forking into sub-streams and joining them again costs more than the overlap gains
  * (65,536 envs, MI355X: 23.3 us per step as one launch, 43.8 as two, 60.2 as three; profiles/r02a_explicit_streams.txt). */
-static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int dist, int ticks, bool policy = false, bool one_launch = false)
+struct PomObserveOut { /* pom_batch_step_device_observe: where the fused kernel writes the observation */
+    void* planes;
+    int32_t* agent_attrs;
+    int32_t* env_attrs;
+    int32_t dtype, per_agent;
+};
+static int launch_step(PomBatch* h, const int32_t* moves_dev, uint64_t seed, int dist, int ticks, bool policy = false, bool one_launch = false,
+                       const PomObserveOut* obs = nullptr)
 {
     StepParams p;
     if (int rc = chain_settle(h)) return rc; /* an ordinary launch after chained ones: every tile must stand on the tick the host thinks it does */
     if (int rc = fill_params(h, p, moves_dev, seed, dist, ticks)) return rc;
+    if (obs) {
+        p.obs_planes = obs->planes;
+        p.obs_agent_attrs = obs->agent_attrs;
+        p.obs_env_attrs = obs->env_attrs;
+        p.obs_dtype = obs->dtype;
+        p.obs_per_agent = obs->per_agent;
+    }
     const int64_t tiles = h->n_pad / h->epw;
     const int parts = one_launch ? 1 : h->parts;
     int rc = one_launch ? join_parts(h) : fork_parts(h);

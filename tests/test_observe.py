@@ -124,3 +124,45 @@ def test_bad_arguments_are_refused(hip_lib):
     with pytest.raises(ValueError):
         env.observe(dtype="int64")
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("at_end,fresh", [(True, False), (False, False), (True, True)])
+@pytest.mark.parametrize("per_agent,dtype", [(False, "uint8"), (True, "uint8"), (False, "float32"), (True, "float16")])
+def test_step_and_observation_in_one_launch(hip_lib, oracle, at_end, fresh, per_agent, dtype):
+    """pom_batch_step_device_observe: the launch that plays the tick writes the observation of the state it leaves behind.  Every
+    tick: planes and attributes against the numpy restatement applied to the downloaded state, and the state itself against a
+    twin handle stepped by pom_batch_step_device (itself checked against the oracle every tick in tests/test_reset_modes.py);
+    with the reset at the end of the tick finished envs show their next start state, marked restarted."""
+    import torch
+    from pomcpp_amd.batch import BatchEnvironment, MODE_ENV, RESET_AT_END
+    ob = _oracle()
+    n, cap = 1000 + 13, 40
+    kw = dict(mode=MODE_ENV, auto_reset=RESET_AT_END if at_end else True, max_steps=cap, fresh_boards=fresh, board_seed=5)
+    rng = np.random.default_rng(4)
+    with BatchEnvironment(n, **kw) as env, BatchEnvironment(n, **kw) as twin:
+        for e in (env, twin):
+            if fresh:
+                e.generate(5)
+            else:
+                e.make_game(pa.make_boards(n, seed=8, kind="stress"))
+        restarted_seen = 0
+        for t in range(70):
+            mv = torch.from_numpy(rng.integers(0, 6, size=(n, 4), dtype=np.int32)).to("cuda")
+            got, attrs, eattrs = env.step_device_observe(mv, per_agent=per_agent, dtype=dtype)
+            twin.step_device(mv)
+            states = env.get_state()
+            assert states.tobytes() == twin.get_state().tobytes(), t
+            want, want_attrs, want_env = ob.observe(states, per_agent=per_agent, dtype=getattr(np, dtype))
+            assert np.array_equal(got.cpu().numpy(), want), t
+            assert np.array_equal(attrs.cpu().numpy(), want_attrs), t
+            e = eattrs.cpu().numpy()
+            st = env.status()
+            assert np.array_equal(e[:, :2], want_env), t
+            assert np.array_equal(e[:, 2] & 1, st["done"]) and np.array_equal(e[:, 3], st["winner"]), t
+            if at_end:
+                fin = env.last_results()["finished"]
+                assert np.array_equal((e[:, 2] >> 3) & 1, fin), t
+                restarted_seen += int(fin.sum())
+        assert not at_end or restarted_seen > n // 2
+        assert np.array_equal(env.counters(), twin.counters())
