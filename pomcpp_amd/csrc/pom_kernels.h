@@ -677,7 +677,7 @@ __device__ __forceinline__ void pom_observe_tile(const ObserveParams& p, const u
 #pragma unroll
             for (int i = 0; i < (VECS + 63) / 64; i++) {
                 const int idx = lane + 64 * i;
-                if (idx < VECS && e0 + idx / (OBS_ENV_BYTES / 16) < p.n) out[idx] = stage[idx];
+                if (idx < VECS && e0 + idx / (OBS_ENV_BYTES / 16) < p.n) out[idx] = stage[idx]; /* (non-temporal stores: 45 us against 40 fused) */
             }
         } else if (p.dtype == POM_OBS_U8) {
             obs_gather_out<uint8_t>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
