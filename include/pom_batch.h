@@ -208,6 +208,13 @@ int pom_batch_issue_info(PomBatch* h, int32_t* issue_mode, int32_t* streams);
  * out[2] tiles that a check found left behind by a wavefront that could not play them, out[3] ticks replayed for those tiles */
 int pom_batch_chain_stats(PomBatch* h, int64_t out[4]);
 
+/* Self-test of the hand-off chained launches rest on, without the game: `launches` launches over `tiles` 7-KB records on `streams`
+ * streams; every visit checks that its record is exactly what the visit before it left (all 1,792 dwords) and rewrites it.
+ * out[0] records a visit found stale or torn (must be 0), out[1] dwords that differed, out[2] visits played, out[3] visits
+ * expected, out[4] tiles whose final record / ticket word is not what `launches` clean visits leave, out[5] POM_CHAIN_E_* flags
+ * raised.  POM_E_HIP where the device does not offer chained launches. */
+int pom_chain_litmus(int32_t device, int64_t tiles, int32_t launches, int32_t streams, int64_t out[6]);
+
 /* the hipStream_t the handle's work is ordered on (the one given at creation, or the library's own), so that a caller can
  * order its own device work against steps and observations with events instead of pom_batch_sync */
 int pom_batch_stream(PomBatch* h, void** stream);

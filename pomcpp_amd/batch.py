@@ -120,6 +120,8 @@ def load_library() -> C.CDLL:
     if not os.environ.get("POM_LIB") or hasattr(lib, "pom_batch_issue_info"):
         lib.pom_batch_issue_info.argtypes = [P, C.POINTER(I32), C.POINTER(I32)]
     lib.pom_batch_device_view.argtypes = [P, C.POINTER(VP), C.POINTER(I64), C.POINTER(I32)]
+    if not os.environ.get("POM_LIB") or hasattr(lib, "pom_chain_litmus"):
+        lib.pom_chain_litmus.argtypes = [I32, I64, I32, I32, VP]
     lib.pom_step.argtypes = [VP, VP]
     if not os.environ.get("POM_LIB") or hasattr(lib, "pom_env_step"):
         lib.pom_env_step.argtypes = [VP, VP, I32, VP, VP, VP, VP]
@@ -130,6 +132,15 @@ def load_library() -> C.CDLL:
 def _check(lib, rc: int) -> None:
     if rc != 0:
         raise PomError(rc, lib.pom_last_error().decode(errors="replace"))
+
+
+def chain_litmus(tiles: int, launches: int, streams: int, device: int = 0) -> dict:
+    """pom_chain_litmus: the hand-off of chained launches tested by itself (every visit checks the whole record the visit before
+    left)"""
+    lib = load_library()
+    out = np.zeros(6, dtype=np.int64)
+    _check(lib, lib.pom_chain_litmus(device, tiles, launches, streams, out.ctypes.data))
+    return dict(zip(("bad_records", "bad_dwords", "visits", "visits_expected", "tiles_wrong", "flags"), (int(v) for v in out)))
 
 
 def step_one(state: np.ndarray, moves) -> None:

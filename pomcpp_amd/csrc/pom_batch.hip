@@ -357,6 +357,100 @@ int pom_batch_chain_stats(PomBatch* h, int64_t out[4])
     return POM_OK;
 }
 
+/* self-test of the chained launches' hand-off, without the game (pom_kernels.h pom_chain_litmus_kernel): `launches` launches over
+ * `tiles` records round-robin over `streams` streams; out[0] records found stale or torn, out[1] dwords that differed, out[2]
+ * visits played, out[3] visits expected, out[4] tiles whose final record or word is not what `launches` clean visits leave,
+ * out[5] the kernels' failure flags (POM_CHAIN_E_*; a give-up leaves its tile behind: counted in out[4]) */
+int pom_chain_litmus(int32_t device, int64_t tiles, int32_t launches, int32_t streams, int64_t out[6])
+{
+    if (!out || tiles < 8 || tiles > (1 << 22) || launches < 1 || launches > (1 << 20) || streams < 1 || streams > PomBatch::MAX_PARTS) return POM_E_ARG;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return POM_E_HIP;
+    HIPCHK(hipSetDevice(device));
+    PomChain c;
+    hipStream_t st[PomBatch::MAX_PARTS] = {};
+    uint32_t* data = nullptr;
+    unsigned long long* res = nullptr;
+    int rc = POM_OK;
+    auto cleanup = [&] {
+        for (int k = 0; k < streams; k++)
+            if (st[k]) {
+                (void)hipStreamSynchronize(st[k]);
+                (void)hipStreamDestroy(st[k]);
+            }
+        chain_destroy(&c);
+        (void)hipFree(data);
+        (void)hipFree(res);
+    };
+    for (int k = 0; k < streams && rc == POM_OK; k++)
+        if (hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking) != hipSuccess) rc = POM_E_HIP;
+    if (rc == POM_OK && !chain_setup(&c, tiles, st[0])) {
+        snprintf(g_err, sizeof g_err, "pom_chain_litmus: chained launches are not available on this device");
+        rc = POM_E_HIP;
+    }
+    const size_t bytes = (size_t)tiles * POM_TILE_DWORDS * 4;
+    if (rc == POM_OK && (hipMalloc((void**)&data, bytes) != hipSuccess || hipMalloc((void**)&res, 64) != hipSuccess)) rc = POM_E_NOMEM;
+    if (rc != POM_OK) {
+        cleanup();
+        return rc;
+    }
+    /* visit 0 expects 0 ^ tag: fill the records accordingly (on the host: this is a test) */
+    {
+        std::vector<uint32_t> init((size_t)tiles * POM_TILE_DWORDS);
+        for (int64_t t = 0; t < tiles; t++)
+            for (int k = 0; k < POM_TILE_DWORDS; k++) init[(size_t)t * POM_TILE_DWORDS + k] = (uint32_t)t * 2654435761u + (uint32_t)k;
+        if (hipMemcpy(data, init.data(), bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemset(res, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            cleanup();
+            return POM_E_HIP;
+        }
+    }
+    LitmusParams p;
+    p.data = data;
+    p.tile_seq = c.tile_seq;
+    p.err = c.aux;
+    p.out = res;
+    p.tiles = tiles;
+    p.chain_seq0 = 0;
+    p.wait_limit = c.wait_limit;
+    const dim3 grid((unsigned)((tiles + 7) / 8 * 8));
+    for (int k = 0; k < launches && rc == POM_OK; k++) {
+        pom_chain_litmus_kernel<<<grid, dim3(64), 0, st[k % streams]>>>(p);
+        if (hipGetLastError() != hipSuccess) rc = POM_E_HIP;
+    }
+    for (int k = 0; k < streams; k++)
+        if (hipStreamSynchronize(st[k]) != hipSuccess) rc = POM_E_HIP;
+    if (rc == POM_OK) {
+        unsigned long long r3[3] = {0, 0, 0};
+        uint32_t flags = 0;
+        std::vector<uint32_t> fin((size_t)tiles * POM_TILE_DWORDS);
+        std::vector<unsigned long long> words((size_t)tiles * POM_CHAIN_WORD_STRIDE);
+        if (hipMemcpy(r3, res, 24, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&flags, c.aux, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(fin.data(), data, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(words.data(), c.tile_seq, words.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = POM_E_HIP;
+        } else {
+            int64_t wrong = 0;
+            for (int64_t t = 0; t < tiles; t++) {
+                const unsigned long long w = words[(size_t)t * POM_CHAIN_WORD_STRIDE];
+                bool ok = ((uint32_t)w & POM_CHAIN_COUNT_MASK) == (uint32_t)launches && (uint32_t)(w >> POM_CHAIN_TICKET_SHIFT) == (uint32_t)launches &&
+                          !((uint32_t)w & POM_CHAIN_POISON);
+                for (int k = 0; k < POM_TILE_DWORDS && ok; k++)
+                    ok = fin[(size_t)t * POM_TILE_DWORDS + k] == ((uint32_t)launches ^ ((uint32_t)t * 2654435761u + (uint32_t)k));
+                wrong += !ok;
+            }
+            out[0] = (int64_t)r3[0];
+            out[1] = (int64_t)r3[1];
+            out[2] = (int64_t)r3[2];
+            out[3] = tiles * (int64_t)launches;
+            out[4] = wrong;
+            out[5] = (int64_t)flags;
+        }
+    }
+    cleanup();
+    return rc;
+}
+
 int pom_batch_step(PomBatch* h, const int32_t* moves_host)
 {
     if (!h || !moves_host) return POM_E_ARG;

@@ -739,6 +739,98 @@ enum { POM_CHAIN_WAIT_LIMIT_US = 2000000 };
                                     per step against 10.41 - 10.48 with the words packed: atomics of neighbouring tiles do not queue on one line) */
 #endif
 
+/* ---- a chained launch's visit of a tile (pom_chain.h): the hand-off both the CHAIN instantiations of pom_step_kernel and the
+ * hand-off litmus (pom_chain_litmus_kernel) go through ------------------------------------------------------------------------- */
+struct PomChainVisit {
+    int32_t dist = 0;            /* how many visits after the launch's chain_seq0 this one is: picks the tick (and the tape's tick) */
+    unsigned long long done = 0; /* what the wavefront adds to the tile's word when its stores have arrived */
+#if defined(POM_CHAIN_DIAG)
+    long long t0 = 0, t1 = 0, t2 = 0, rt0 = 0;
+    int polls = 0;
+    uint32_t visit = 0;
+#endif
+};
+/* which XCD this workgroup runs on (0..7; >= 8: not the machine this was written for) */
+__device__ __forceinline__ uint32_t pom_chain_xcd()
+{
+    uint32_t x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 0xFu;
+}
+/* Take a ticket for the tile's word and wait for the visit before it.  true: the tile is this wavefront's to play — its record, as
+ * the previous visit stored it, may be loaded NOW (past the vector cache: sc1).  false: nothing may be touched (the tile is, or
+ * has just been, poisoned; the flag word says why). */
+__device__ __forceinline__ bool pom_chain_enter(unsigned long long* word, uint32_t chain_xcd, uint32_t chain_seq0, uint32_t tape_len, uint64_t wait_limit,
+                                                uint32_t* err, int lane, PomChainVisit& v)
+{
+    const uint32_t xcd = chain_xcd + 1u;
+#if defined(POM_CHAIN_DIAG)
+    v.t0 = (long long)__builtin_readcyclecounter();
+    v.rt0 = (long long)wall_clock64();
+#endif
+    /* take a ticket: the old value says which visit of the tile this is — and, mostly, that the visit before it is stored */
+    unsigned long long w = 0;
+    if (lane == 0) w = __hip_atomic_fetch_add(word, 1ull << POM_CHAIN_TICKET_SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
+    const uint32_t visit = (uint32_t)(w >> POM_CHAIN_TICKET_SHIFT);
+    /* which tick: the call's first tick + how far this visit is from the call's first visit — a signed distance: launches of
+     * two calls may be in flight together, and a wavefront of the later call can draw a ticket of the earlier one */
+    v.dist = (int32_t)pom_chain_visit_distance(visit, chain_seq0);
+#if defined(POM_CHAIN_DIAG)
+    v.t1 = (long long)__builtin_readcyclecounter();
+#endif
+    /* stored visits == this visit's number: its turn.  Until then poll — for as long as the wall clock allows; a poisoned tile
+     * (somebody before this visit could not play) is nobody's turn any more */
+    int polls = 0;
+    bool timed_out = false;
+    if (!((uint32_t)w & POM_CHAIN_POISON) && (int32_t)pom_chain_visit_distance((uint32_t)w & POM_CHAIN_COUNT_MASK, visit) < 0) { /* wave-uniform */
+        const uint64_t t_wait0 = wall_clock64();
+        for (;;) {
+            __builtin_amdgcn_s_sleep(1);
+            w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
+            polls++;
+            if (((uint32_t)w & POM_CHAIN_POISON) || (int32_t)pom_chain_visit_distance((uint32_t)w & POM_CHAIN_COUNT_MASK, visit) >= 0) break;
+            if (wall_clock64() - t_wait0 >= wait_limit) {
+                timed_out = true;
+                break;
+            }
+        }
+    }
+    (void)polls;
+    const uint32_t was_on = (uint32_t)(w >> 32) & 0xFu;
+    const bool poisoned = ((uint32_t)w & POM_CHAIN_POISON) != 0;
+    const bool wrong_xcd = was_on != 0u && was_on != xcd;
+    const bool off_tape = tape_len != 0u && (uint32_t)v.dist >= tape_len;
+    if (poisoned || timed_out || wrong_xcd || off_tape) {
+        /* The visit before this one never arrived in time, or it was stored through another XCD's L2 (what this L2 holds of
+         * the tile may be stale), or the ticket lies outside the move tape (launches of two tape calls in flight together:
+         * the host joins between them, so never).  Nothing is stepped and NOTHING IS COUNTED: the tile is poisoned, every
+         * later visitor leaves it alone, its stored count stays at the ticks it really played, and the host — which finds
+         * the flag after the next join — replays the rest with ordinary launches (chain_settle, pom_runtime.h). */
+        if (lane == 0 && !poisoned) {
+            __hip_atomic_fetch_or(word, (unsigned long long)POM_CHAIN_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_or(err, (uint32_t)(timed_out ? POM_CHAIN_E_TIMEOUT : wrong_xcd ? POM_CHAIN_E_XCD : POM_CHAIN_E_TAPE), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return false;
+    }
+#if defined(POM_CHAIN_DIAG)
+    v.t2 = (long long)__builtin_readcyclecounter();
+    v.polls = polls;
+    v.visit = visit;
+#endif
+    v.done = 1ull + ((unsigned long long)(xcd - was_on) << 32);
+    return true;
+}
+/* Hand the tile on: called after the record's stores have been ISSUED; waits until the L2 has acknowledged them, then counts the
+ * visit as stored (which is what the next visitor polls for). */
+__device__ __forceinline__ void pom_chain_leave(unsigned long long* word, int lane, const PomChainVisit& v)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(word, v.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 /* a dword that a wavefront of an earlier, still unfinished launch may have written (chained launches): past this CU's vector cache */
 template <bool CHAIN>
 __device__ __forceinline__ uint32_t pom_load_shared(const uint32_t* ptr)
@@ -781,8 +873,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         /* the XCD the workgroup IS on decides its tile (launches of different queues start their round-robin at different
          * XCDs): XCD x plays tiles x * q .. x * q + q - 1, its k-th workgroup (workgroup ids x0, x0 + 8, ...) the k-th of them.
          * The grid is padded to a multiple of 8 workgroups. */
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(chain_xcd));
-        chain_xcd &= 0xFu;
+        chain_xcd = pom_chain_xcd();
         const int64_t q = gridDim.x / 8;
         tile_local = (int64_t)chain_xcd * q + blockIdx.x / 8;
         if (chain_xcd >= 8u) { /* not the machine this was written for: nothing is stepped, no ticket is drawn (the verify pass reports it) */
@@ -828,73 +919,11 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
 
     /* the launch's first tick: asked for BEFORE the record, so that waiting for it (in-order vmcnt) does not wait for the record */
     uint32_t tick0 = CHAIN ? p.tick0 : p.tick0 + *p.tick_base; /* (graphs replay sub-batch launches, never chained ones) */
-    unsigned long long chain_done = 0; /* what this wavefront adds to the tile's word when its stores have arrived */
-    int32_t chain_dist = 0;            /* CHAIN: how many visits after the call's first visit this one is */
-#if defined(POM_CHAIN_DIAG)
-    long long chain_t0 = 0, chain_t1 = 0, chain_t2 = 0, chain_rt0 = 0;
-    int chain_polls = 0;
-    uint32_t chain_visit = 0;
-#endif
+    PomChainVisit cv; /* CHAIN: this wavefront's visit of its tile */
     if (CHAIN) {
-        const uint32_t xcd = chain_xcd + 1u;
-#if defined(POM_CHAIN_DIAG)
-        chain_t0 = (long long)__builtin_readcyclecounter();
-        chain_rt0 = (long long)wall_clock64();
-#endif
-        /* take a ticket: the old value says which visit of the tile this is — and, mostly, that the visit before it is stored */
-        unsigned long long w = 0;
-        if (lane == 0) w = __hip_atomic_fetch_add(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, 1ull << POM_CHAIN_TICKET_SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
-        const uint32_t visit = (uint32_t)(w >> POM_CHAIN_TICKET_SHIFT);
-        /* which tick: the call's first tick + how far this visit is from the call's first visit — a signed distance: launches of
-         * two calls may be in flight together, and a wavefront of the later call can draw a ticket of the earlier one */
-        chain_dist = (int32_t)pom_chain_visit_distance(visit, p.chain_seq0);
-        tick0 += (uint32_t)chain_dist;
-#if defined(POM_CHAIN_DIAG)
-        chain_t1 = (long long)__builtin_readcyclecounter();
-#endif
-        /* stored visits == this visit's number: its turn.  Until then poll — for as long as the wall clock allows; a poisoned tile
-         * (somebody before this visit could not play) is nobody's turn any more */
-        int polls = 0;
-        bool timed_out = false;
-        if (!((uint32_t)w & POM_CHAIN_POISON) && (int32_t)pom_chain_visit_distance((uint32_t)w & POM_CHAIN_COUNT_MASK, visit) < 0) { /* wave-uniform */
-            const uint64_t t_wait0 = wall_clock64();
-            for (;;) {
-                __builtin_amdgcn_s_sleep(1);
-                w = __hip_atomic_load(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
-                polls++;
-                if (((uint32_t)w & POM_CHAIN_POISON) || (int32_t)pom_chain_visit_distance((uint32_t)w & POM_CHAIN_COUNT_MASK, visit) >= 0) break;
-                if (wall_clock64() - t_wait0 >= p.chain_wait_limit) {
-                    timed_out = true;
-                    break;
-                }
-            }
-        }
-        (void)polls;
-        const uint32_t was_on = (uint32_t)(w >> 32) & 0xFu;
-        const bool poisoned = ((uint32_t)w & POM_CHAIN_POISON) != 0;
-        const bool wrong_xcd = was_on != 0u && was_on != xcd;
-        const bool off_tape = p.tape_len != 0u && (uint32_t)chain_dist >= p.tape_len;
-        if (poisoned || timed_out || wrong_xcd || off_tape) {
-            /* The visit before this one never arrived in time, or it was stored through another XCD's L2 (what this L2 holds of
-             * the tile may be stale), or the ticket lies outside the move tape (launches of two tape calls in flight together:
-             * the host joins between them, so never).  Nothing is stepped and NOTHING IS COUNTED: the tile is poisoned, every
-             * later visitor leaves it alone, its stored count stays at the ticks it really played, and the host — which finds
-             * the flag after the next join — replays the rest with ordinary launches (chain_settle, pom_runtime.h). */
-            if (lane == 0 && !poisoned) {
-                __hip_atomic_fetch_or(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, (unsigned long long)POM_CHAIN_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_or(p.chain_err, (uint32_t)(timed_out ? POM_CHAIN_E_TIMEOUT : wrong_xcd ? POM_CHAIN_E_XCD : POM_CHAIN_E_TAPE), __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
-        }
-#if defined(POM_CHAIN_DIAG)
-        chain_t2 = (long long)__builtin_readcyclecounter();
-        chain_polls = polls;
-        chain_visit = visit;
-#endif
-        chain_done = 1ull + ((unsigned long long)(xcd - was_on) << 32);
+        unsigned long long* const word = p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE;
+        if (!pom_chain_enter(word, chain_xcd, p.chain_seq0, p.tape_len, p.chain_wait_limit, p.chain_err, lane, cv)) return;
+        tick0 += (uint32_t)cv.dist;
         /* the loads below are issued after the word has been seen: the record they fetch is the stored one */
         load_tile16_x4<POM_REC_DWORDS, 16>(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane);
     } else if (EPW == 16) load_tile16_x4(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane); /* 16-byte pieces, 7 instructions of 1 KB */
@@ -912,7 +941,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     if (!POLICY) {
         if (TAKES_MOVES && p.moves) {
             /* chained: tick `chain_dist` of the caller's move tape (pom_batch_step_device_many) */
-            if (valid) moves0 = reinterpret_cast<const int4*>(p.moves)[(CHAIN ? (int64_t)chain_dist * p.n : (int64_t)0) + e];
+            if (valid) moves0 = reinterpret_cast<const int4*>(p.moves)[(CHAIN ? (int64_t)cv.dist * p.n : (int64_t)0) + e];
         } else {
             if (G == 4 && !SINGLE) { /* several ticks per launch: the draw is made where it is used, nothing to carry */
             } else if (G == 4) draw0 = pom_rng_draw_half(p.seed, env_key, tick0, member >> 1); /* lane m needs agent m's 16 bits only */
@@ -1172,17 +1201,16 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         pom_observe_tile(op, tile, reinterpret_cast<uint4*>(tile + POM_REC_DWORDS * EPW), tile_id, lane);
     }
     if (CHAIN) { /* the record's stores have been acknowledged by the L2 before the word that hands the tile on is written */
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, chain_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pom_chain_leave(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, lane, cv);
 #if defined(POM_CHAIN_DIAG)
         if (lane == 0) { /* per tile, summed over launches: cycles to the ticket, cycles polling, cycles in all, polls */
             unsigned long long* d = p.tile_seq + (p.block_end - p.block0) * POM_CHAIN_WORD_STRIDE + 68 * tile_id;
-            d[4 + 2 * (chain_visit & 31)] = (unsigned long long)chain_rt0; /* the last 32 visits: start and end on the 100 MHz clock */
-            d[5 + 2 * (chain_visit & 31)] = (unsigned long long)wall_clock64();
-            d[0] += (unsigned long long)(chain_t1 - chain_t0);
-            d[1] += (unsigned long long)(chain_t2 - chain_t1);
-            d[2] += (unsigned long long)((long long)__builtin_readcyclecounter() - chain_t0);
-            d[3] += (unsigned long long)chain_polls;
+            d[4 + 2 * (cv.visit & 31)] = (unsigned long long)cv.rt0; /* the last 32 visits: start and end on the 100 MHz clock */
+            d[5 + 2 * (cv.visit & 31)] = (unsigned long long)wall_clock64();
+            d[0] += (unsigned long long)(cv.t1 - cv.t0);
+            d[1] += (unsigned long long)(cv.t2 - cv.t1);
+            d[2] += (unsigned long long)((long long)__builtin_readcyclecounter() - cv.t0);
+            d[3] += (unsigned long long)cv.polls;
         }
 #endif
     }
@@ -1213,6 +1241,54 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         if (c_episodes) __hip_atomic_fetch_add(&wc[POM_CNT_EPISODES], (unsigned long long)c_episodes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c_resets) __hip_atomic_fetch_add(&wc[POM_CNT_RESETS], (unsigned long long)c_resets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c_ub) __hip_atomic_fetch_add(&wc[POM_CNT_UB_TICKS], (unsigned long long)c_ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+/* The hand-off by itself (pom_chain_litmus, tests): the same tile choice, ticket, wait, sc1 DMA load, non-temporal store and
+ * publication as the CHAIN step kernels, with a "tick" whose result gives every stale or torn read away — visit v of a tile must
+ * find ALL 1,792 dwords of the record equal to v (the j-th dword XOR-tagged with its index, so that a record of another tile or a
+ * shifted piece cannot pass either) and leaves them at v + 1.  out[0]: records that were not what the visit before left (counted
+ * per wavefront), out[1]: dwords that differed, out[2]: visits played. */
+struct LitmusParams {
+    uint32_t* data;              /* tiles x POM_TILE_DWORDS */
+    unsigned long long* tile_seq;
+    uint32_t* err;
+    unsigned long long* out;
+    int64_t tiles;
+    uint32_t chain_seq0;
+    uint64_t wait_limit;
+};
+__global__ __launch_bounds__(64) void pom_chain_litmus_kernel(LitmusParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[POM_REC_DWORDS * 16];
+    const int lane = threadIdx.x;
+    const uint32_t xcd = pom_chain_xcd();
+    if (xcd >= 8u) return;
+    const int64_t tile_id = (int64_t)xcd * (gridDim.x / 8) + blockIdx.x / 8;
+    if (tile_id >= p.tiles) return;
+    unsigned long long* const word = p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE;
+    PomChainVisit cv;
+    if (!pom_chain_enter(word, xcd, p.chain_seq0, 0u, p.wait_limit, p.err, lane, cv)) return;
+    load_tile16_x4<POM_REC_DWORDS, 16>(p.data + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t expect = p.chain_seq0 + (uint32_t)cv.dist; /* = this visit's number: as many visits are stored */
+    const uint32_t tag = (uint32_t)tile_id * 2654435761u;
+    int bad = 0;
+#pragma unroll 4
+    for (int k = lane; k < POM_TILE_DWORDS; k += 64) {
+        bad += tile[k] != (expect ^ (tag + (uint32_t)k));
+        tile[k] = (expect + 1u) ^ (tag + (uint32_t)k);
+    }
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    store_tile16_x4<true>(p.data + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane);
+    pom_chain_leave(word, lane, cv);
+    if (lane == 0) {
+        if (bad) {
+            atomicAdd(p.out + 0, 1ull);
+            atomicAdd(p.out + 1, (unsigned long long)bad);
+        }
+        atomicAdd(p.out + 2, 1ull);
     }
 }
 

@@ -432,3 +432,21 @@ print("ok", recovered)
 ''' % ROOT
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, POM_CHAIN_WAIT_US=wait_us), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("streams", [2, 3, 4])
+def test_hand_off_litmus(hip_lib, streams):
+    """The hand-off by itself (pom_chain_litmus): 4,096 records, 300 launches on 2 - 4 streams = 1.2 M hand-offs, every visit checking
+    all 1,792 dwords of its record against what the visit before left (tagged per tile and dword: a stale, torn or foreign record
+    cannot pass) — while another handle steps 65,536 envs with chained launches of its own on the same device."""
+    from pomcpp_amd.batch import chain_litmus
+    with BatchEnvironment(65536, mode=MODE_ENV, auto_reset=True, max_steps=800) as other:
+        other.make_game(pa.make_boards(65536, seed=2))
+        other.step_random(3, DIST_RANDOM, ticks=400)  # queued: runs while the litmus does
+        r = chain_litmus(4096, 300, streams)
+        other.sync()
+        assert other.chain_stats()["tiles_recovered"] == 0
+    assert r["visits"] == r["visits_expected"] == 4096 * 300, r
+    assert r["bad_records"] == 0 and r["bad_dwords"] == 0 and r["tiles_wrong"] == 0 and r["flags"] == 0, r
+    small = chain_litmus(64, 2000, streams)  # few tiles, long chains: every launch waits for the one before on nearly every tile
+    assert small["visits"] == 64 * 2000 and small["bad_records"] == 0 and small["tiles_wrong"] == 0 and small["flags"] == 0, small
