@@ -50,7 +50,7 @@ if ROOT not in sys.path:
 ALGO_BYTES_PER_STEP = 2024  # 1004 B State read + 1004 B State write + 16 B Move[4]  (SURVEY.md §8d): the contract figure
 PACKED_BYTES_PER_STEP = 2 * 448  # what the device record moves per env-step: 112 dwords read + written (pom_packed.h)
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_JSON = os.path.join("profiles", "r03_traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r04_traffic.json")
 ENVS_SINGLE_GPU, ENVS_PER_GPU_SHARDED = 65536, 32768  # BASELINE: 64k envs at one GPU; config 4 = 262,144 envs = 8 x 32,768
 
 
