@@ -274,6 +274,55 @@ POM_HD uint32_t pom_window_word(int k, int sx, int sy, int radius)
     return k == 3 ? w & 0x01FFFFFFu : w;
 }
 
+/* safe_directions() + sort_directions() (strategy.cpp:203-226, strategy.hpp:130-152) as ONE table look-up.  What the two do to the
+ * move queue is a function of which of the four steps RIGHT, LEFT, DOWN, UP are safe (they are queued in that order) and which of
+ * them lead onto a recent position ("hit"): SortDirections' loop — RemoveAt(i), then AddElem of what NOW sits at i (sic), at most
+ * four removals, the bound fixed at the original count — only ever reads and writes the slots the safe steps were queued into.
+ * 256 entries, built at compile time by running that very loop: bits 0..11 the queue's slots 0..3 (3 bits each; slots past the
+ * number of safe steps are not touched and read 0 here), bits 12..14 the count.  (As a loop over lane-varying queues the sort
+ * cost a wavefront its longest queue's 6 - 8 iterations: ~250 VALU of the fused SimpleAgent kernel's 4.3 k.) */
+struct PomSortTable {
+    uint16_t e[256];
+};
+constexpr PomSortTable pom_make_sort_table()
+{
+    PomSortTable t{};
+    for (int safe = 0; safe < 16; safe++) {
+        for (int hit = 0; hit < 16; hit++) {
+            int q[4] = {0, 0, 0, 0}, cnt = 0;
+            const int dirs[4] = {POM_MOVE_RIGHT, POM_MOVE_LEFT, POM_MOVE_DOWN, POM_MOVE_UP};
+            for (int k = 0; k < 4; k++)
+                if ((safe >> k) & 1) {
+                    q[cnt & 3] = dirs[k];
+                    cnt++;
+                }
+            const int moves = cnt;
+            int removes = 0;
+            for (int i = 0; i < moves && removes < 4; i++) {
+                const int mv = q[i & 3];
+                const int k = mv == POM_MOVE_RIGHT ? 0 : mv == POM_MOVE_LEFT ? 1 : mv == POM_MOVE_DOWN ? 2 : 3;
+                if ((hit >> k) & 1) {
+                    for (int j = i + 1; j < cnt; j++) q[(j - 1) & 3] = q[j & 3]; /* RemoveAt(i) */
+                    cnt--;
+                    q[cnt & 3] = q[i & 3]; /* AddElem(queue[i]): what now sits at i, not what was removed */
+                    cnt++;
+                    i--;
+                    removes++;
+                }
+            }
+            int bits = cnt << 12;
+            for (int k = 0; k < moves; k++) bits |= q[k] << (3 * k);
+            t.e[safe | (hit << 4)] = (uint16_t)bits;
+        }
+    }
+    return t;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ const PomSortTable pom_sort_table = pom_make_sort_table();
+#else
+static const PomSortTable pom_sort_table = pom_make_sort_table();
+#endif
+
 template <class P>
 struct PomSimplePolicy {
     P& p;
@@ -468,11 +517,33 @@ struct PomSimplePolicy {
             if (i < rp_count() / 2) ok &= rp_key(i) == rp_key(i + 2);
         return ok;
     }
+    /* is (x, y) one of the recent positions — on all four bytes of m0 at once: 0x80 in every byte that holds a live entry (slots
+     * index .. index + count - 1, cyclically) and an exact zero-byte test of m0 ^ key-in-every-byte */
+    POM_HD int is_recent(int x, int y, uint32_t live) const
+    {
+        const uint32_t v = m0 ^ ((uint32_t)pos_key(x, y) * 0x01010101u);
+        const uint32_t zero = ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);
+        return (zero & live) != 0u;
+    }
     POM_HD int one_safe_step(int draw) /* the common tail of _Decide and _MoveSafeOneSpace, simple_agent.cpp:37-48,105-121 */
     {
+#if defined(POM_SORT_LOOP) /* the literal form: queue the safe steps, then SortDirections' loop */
         mq_set_count(0);
         safe_directions();
         sort_directions();
+#else
+        const int r = step_is_safe(sx + 1, sy), l = step_is_safe(sx - 1, sy), d = step_is_safe(sx, sy + 1), u = step_is_safe(sx, sy - 1);
+        const int rc = rp_count(), rsh = 8 * rp_index();
+        const uint32_t live0 = rc >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * rc)) - 1u));
+        const uint32_t live = (live0 << rsh) | (rsh ? live0 >> (32 - rsh) : 0u);
+        const int idx = r | (l << 1) | (d << 2) | (u << 3) | (is_recent(sx + 1, sy, live) << 4) | (is_recent(sx - 1, sy, live) << 5) |
+                        (is_recent(sx, sy + 1, live) << 6) | (is_recent(sx, sy - 1, live) << 7);
+        const uint32_t e = pom_sort_table.e[idx];
+        const int queued = r + l + d + u;
+        const uint32_t keep = (0xFFFu << (3 * queued)) & 0xFFFu; /* the slots behind the queued steps keep what they held */
+        const uint32_t q = (((m1 >> 5) & 0xFFFu) & keep) | (e & 0xFFFu);
+        m1 = (m1 & ~((0xFFFu << 5) | (7u << 17))) | (q << 5) | ((e >> 12) << 17);
+#endif
         if (mq_count() == 0) return POM_MOVE_IDLE;
         return mq_at(draw % 2);
     }
