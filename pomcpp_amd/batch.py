@@ -177,6 +177,7 @@ class BatchEnvironment:
         self._lib = load_library()
         self._h = C.c_void_p()
         self._views = []  # weak references to tensors that alias the handle's device memory (moves_tensor)
+        self._tapes = []  # move tapes handed to step_device_many, kept alive until the handle has been synchronised
         self.n = int(n_envs)
         self.device = int(device)
         o = _Options(C.sizeof(_Options), device, stream, mode, int(auto_reset), max_steps, env_offset, envs_per_wave, streams,
@@ -188,8 +189,9 @@ class BatchEnvironment:
             raise RuntimeError("close(): a tensor returned by moves_tensor() still views this handle's device memory; "
                                "delete it first")
         if getattr(self, "_h", None) is not None and self._h:
-            self._lib.pom_batch_destroy(self._h)
+            self._lib.pom_batch_destroy(self._h)  # waits for everything queued
             self._h = C.c_void_p()
+            self._tapes = []
 
     def __del__(self):
         try:
@@ -226,6 +228,7 @@ class BatchEnvironment:
         count = self.n - first if count is None else count
         out = np.zeros(count, dtype=STATE_DTYPE)
         _check(self._lib, self._lib.pom_batch_download(self._h, out.ctypes.data, first, count))
+        self._tapes.clear()  # the call has synchronised the handle: nothing reads a tape any more
         return out
 
     download = get_state
@@ -254,8 +257,20 @@ class BatchEnvironment:
             dev = getattr(moves, "device", None)
             if dev is not None and (getattr(dev, "type", "cuda") != "cuda" or getattr(dev, "index", self.device) not in (None, self.device)):
                 raise ValueError(f"moves live on {dev}, the batch on device {self.device}")
+            self._after_torch(moves)
             moves = moves.data_ptr()
         _check(self._lib, self._lib.pom_batch_step_device(self._h, int(moves)))
+
+    def _after_torch(self, tensor) -> None:
+        """order the handle's stream behind torch's current stream: a tensor the caller has just produced there is complete
+        before the step that reads it begins (no-op if both are the same stream)"""
+        if "torch" not in sys.modules or not hasattr(tensor, "is_cuda"):
+            return
+        import torch
+        dev = torch.device("cuda", self.device)
+        mine, theirs = torch.cuda.ExternalStream(self.stream_handle(), device=dev), torch.cuda.current_stream(dev)
+        if mine.cuda_stream != theirs.cuda_stream:
+            mine.wait_stream(theirs)
 
     def step_device_many(self, moves, ticks: Optional[int] = None) -> None:
         """K ticks with explicit moves from a tape in device memory: a tensor int32[K, n, 4] on this handle's device (or the raw
@@ -272,6 +287,10 @@ class BatchEnvironment:
             if dev is not None and (getattr(dev, "type", "cuda") != "cuda" or getattr(dev, "index", self.device) not in (None, self.device)):
                 raise ValueError(f"moves live on {dev}, the batch on device {self.device}")
             ticks = shape[0]
+            # the tape is read asynchronously and must stay unchanged until the handle has been synchronised: keep the tensor (and
+            # with it its memory) alive until then, whatever the caller does with its own reference
+            self._tapes.append(moves)
+            self._after_torch(moves)
             moves = moves.data_ptr()
         if ticks is None:
             raise ValueError("a raw device address needs `ticks`")
@@ -314,6 +333,7 @@ class BatchEnvironment:
         names = ["done", "winner", "draw", "alive", "time_step", "ubflags"]
         arrs = [np.zeros(count, dtype=np.int32) for _ in names]
         _check(self._lib, self._lib.pom_batch_status(self._h, first, count, *[a.ctypes.data for a in arrs]))
+        self._tapes.clear()
         out = dict(zip(names, arrs))
         out["ubflags"] = out["ubflags"].view(np.uint32)
         return out
@@ -412,6 +432,7 @@ class BatchEnvironment:
     def counters(self) -> np.ndarray:
         out = np.zeros(4, dtype=np.int64)
         _check(self._lib, self._lib.pom_batch_counters(self._h, out.ctypes.data))
+        self._tapes.clear()
         return out
 
     def counters_into(self, dev_ptr: int) -> None:
@@ -422,6 +443,7 @@ class BatchEnvironment:
 
     def sync(self) -> None:
         _check(self._lib, self._lib.pom_batch_sync(self._h))
+        self._tapes.clear()
 
     def flush(self) -> None:
         """Make the handle's stream wait for all steps issued so far (host does not block)."""

@@ -43,7 +43,8 @@ for at_end in (False, True):
         if kind <= 1:  # a tape of random length
             k = int(rng.integers(1, 48))
             tape = torch.randint(0, 6, (k, N, 4), dtype=torch.int32, device="cuda")
-            env.step_device_many(tape)
+            torch.cuda.synchronize()  # the tape is written (torch's stream) before the handle's stream reads it
+            env.step_device_many(tape)  # (the wrapper keeps the tensor alive until the handle has been synchronised)
             host = tape[:, lo:lo + m].cpu().numpy()
             for t in range(k):
                 _oracle_explicit(ora, ref, ini, status, host[t], cap, at_end)
