@@ -143,3 +143,5 @@ def test_bench_launcher_runs_two_real_ranks_on_one_gpu(hip_lib):
     assert r["config"]["global_envs"] == 16384 and r["scaling"] == "weak" and "REHEARSAL" in r["data"]
     assert "all-reduce" in r["config"]["collective_in_timed_region"]  # issued between the region's barriers (bench.timed_region)
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 16384) < 1.0  # value = all ranks' env-steps over the slowest rank's time
+    base = r["config"]["single_gpu_base"]  # rank 0's shard stepped alone, in the same run: the like-for-like base of a scaling curve
+    assert base and base["value"] > 0 and base["steps"] == 12

@@ -174,3 +174,47 @@ def test_device_prep_equals_the_restated_helpers_on_random_positions(prep, oracl
             raw = _dest(oracle, s, m).reshape(4, 2).tolist()
             assert dest == raw == odest and n == on == 4 and roots == [0, 1, 2, 3] == ochain and dep == odep == [-1] * 4
     assert seen_contact > 1000
+
+
+@pytest.mark.gpu
+def test_gpu_step_on_the_step_utility_vectors_and_crowded_positions(hip_lib, oracle):
+    """The same vectors through the GPU: the reference's `[step utilities]` positions and moves (step_utility_test.cpp:38-173) and
+    6,000 crowded random positions (3 x 3 corner: switches, chains, cycles, dead agents in the way, two agents on one cell), each
+    stepped three ticks by the device tick (POM_MODE_RAW = bare bboard::Step) and by the oracle: every state and every UB flag."""
+    from pomcpp_amd.batch import BatchEnvironment, MODE_RAW
+    cases = [
+        ([(0, 0), (1, 0), (2, 0), (3, 0)], [Move.DOWN, Move.LEFT, Move.RIGHT, Move.UP], ()),
+        ([(0, 0), (1, 0), (2, 0), (3, 0)], [Move.RIGHT, Move.RIGHT, Move.LEFT, Move.LEFT], ()),
+        ([(0, 0), (1, 0), (8, 4), (9, 8)], [Move.RIGHT] * 3 + [Move.IDLE], ()),
+        ([(0, 0), (1, 0), (8, 8), (9, 8)], [Move.RIGHT] * 3 + [Move.IDLE], ()),
+        ([(0, 0), (1, 0), (2, 0), (3, 0)], [Move.RIGHT] * 4, ()),
+        ([(0, 0), (1, 0), (1, 1), (0, 1)], [Move.RIGHT, Move.DOWN, Move.LEFT, Move.UP], ()),
+        ([(0, 0), (1, 0), (1, 1), (0, 1)], [Move.RIGHT, Move.DOWN, Move.LEFT, Move.UP], (1,)),
+    ]
+    rng = np.random.default_rng(6)
+    for _ in range(6000):
+        pos = [tuple(int(v) for v in rng.integers(0, 3, size=2)) for _ in range(4)]
+        cases.append((pos, [int(v) for v in rng.integers(0, 6, size=4)], tuple(i for i in range(4) if rng.random() < 0.2)))
+    n = len(cases)
+    states = S.new_states(n)
+    moves = np.zeros((3, n, 4), dtype=np.int32)
+    for k, (pos, mv, dead) in enumerate(cases):
+        for i, (x, y) in enumerate(pos):
+            S.put_agent(states[k], x, y, i)
+        if dead:
+            S.kill(states[k], *dead)
+        moves[0, k] = mv
+    moves[1:] = rng.integers(0, 6, size=(2, n, 4))
+    ref = states.copy()
+    seen = np.zeros(n, dtype=np.uint32)  # the record's flags are sticky: everything raised since the upload
+    with BatchEnvironment(n, mode=MODE_RAW) as env:
+        env.make_game(states)
+        for t in range(3):
+            env.step(moves[t])
+            seen |= oracle.step_batch(ref, moves[t])
+            got = env.get_state()
+            want = ref.copy()
+            want["agents"]["pad"] = 0
+            assert got.tobytes() == want.tobytes(), t
+            assert np.array_equal(env.status()["ubflags"], seen), t
+    assert (seen & 1).sum() > 20  # lost agents (SURVEY Q-UB1) do occur in crowded corners
