@@ -436,6 +436,9 @@ public:
     // Environment::Step with four agents::SimpleAgent per game, policy and tick both on the device (include/agents.hpp:55-76)
     void StepSimpleAgents(uint64_t seed, int ticks = 1) { pom_check(pom_batch_step_simple(h_, seed, ticks)); }
     void Step(const Move* moves /* [n][AGENT_COUNT] */) { pom_check(pom_batch_step(h_, reinterpret_cast<const int32_t*>(moves))); }
+    // `ticks` Steps whose moves are fixed in advance: a tape Move[ticks][n][AGENT_COUNT] in DEVICE memory (replays, open-loop
+    // rollouts), issued as chained launches; the tape must stay unchanged until the next call that reads results back
+    void StepTape(const Move* movesDev, int ticks) { pom_check(pom_batch_step_device_many(h_, reinterpret_cast<const int32_t*>(movesDev), ticks)); }
     // ask `agents` (shared by all games) for moves on the current states, then step: Environment::Step
     void Step(const std::array<Agent*, AGENT_COUNT>& agents)
     {
