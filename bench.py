@@ -685,17 +685,20 @@ def worker(args) -> None:
         eb.generate(args.seed)
         eb.step_random(args.seed, dist_id, ticks=300)
         eb.sync()
-        evA.record(stream)
-        eb.step_random(args.seed, dist_id, ticks=60)
-        eb.flush()
-        evB.record(stream)
-        eb.sync()
-        ms_big = evA.elapsed_time(evB) / 60
+        ms_big = None
+        for _ in range(3):  # the best of three 60-step segments (a GB of fresh allocations: the first segment can still be settling)
+            evA.record(stream)
+            eb.step_random(args.seed, dist_id, ticks=60)
+            eb.flush()
+            evB.record(stream)
+            eb.sync()
+            seg = evA.elapsed_time(evB) / 60
+            ms_big = seg if ms_big is None else min(ms_big, seg)
         big_issue = eb.issue_info()
         eb.close()
         moved_big = (traffic_65536 or PACKED_BYTES_PER_STEP * 65536) * (n_big // 65536)
         other["headline_1048576_envs"] = {
-            "value": n_big / (ms_big * 1e-3), "unit": "env-steps/s", "us_per_step": ms_big * 1e3, "steps": 60, "issue": big_issue[0],
+            "value": n_big / (ms_big * 1e-3), "unit": "env-steps/s", "us_per_step": ms_big * 1e3, "steps": 60, "best_of_segments": 3, "issue": big_issue[0],
             "bytes_per_step": moved_big, "achieved_GBps": moved_big / (ms_big * 1e-3) / 1e9, "frac": moved_big / (ms_big * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "cache_resident": False,
             "note": "1,048,576 envs: 470 MB of records, 4 x the memory-side cache — the fraction of the HBM peak proper; bytes = the "
