@@ -395,6 +395,7 @@ int pom_chain_litmus(int32_t device, int64_t tiles, int32_t launches, int32_t st
         cleanup();
         return rc;
     }
+    try { /* (host vectors below: nothing may throw across the C boundary) */
     /* visit 0 expects 0 ^ tag: fill the records accordingly (on the host: this is a test) */
     {
         std::vector<uint32_t> init((size_t)tiles * POM_TILE_DWORDS);
@@ -446,6 +447,9 @@ int pom_chain_litmus(int32_t device, int64_t tiles, int32_t launches, int32_t st
             out[4] = wrong;
             out[5] = (int64_t)flags;
         }
+    }
+    } catch (...) {
+        rc = POM_E_NOMEM;
     }
     cleanup();
     return rc;
@@ -993,8 +997,7 @@ static int step_one(void* state_1004, const int32_t moves[4], int32_t mode, int3
             snprintf(g_err, sizeof g_err, "pom_step: the kernel launch failed");
             return POM_E_HIP;
         }
-        for (int spin = 0; spin < 64 && *seq_word != seq; spin++) {
-        }
+        for (int spin = 0; spin < 64 && *seq_word != seq; spin++) __builtin_ia32_pause();
         if (*seq_word != seq && std::chrono::steady_clock::now() > until) {
             if (synced) {
                 snprintf(g_err, sizeof g_err, "pom_step: the kernel finished without reporting");

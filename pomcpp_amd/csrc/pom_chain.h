@@ -122,6 +122,12 @@ static bool chain_setup(PomChain* c, int64_t tiles, hipStream_t stream)
         chain_destroy(c); /* nothing is kept for a handle that will never chain */
         return false;
     }
+    try { /* the call log never grows past 256 entries (launch_many_chain settles first): reserved here, so that logging a call cannot throw */
+        c->log.reserve(260);
+    } catch (...) {
+        chain_destroy(c);
+        return false;
+    }
     c->ok = true;
     return true;
 }

@@ -672,8 +672,17 @@ static int chain_settle(PomBatch* h)
                  "or destroy it; the handle launches sub-batches from here on", flags);
         return POM_E_HIP;
     }
-    std::vector<uint32_t> list((size_t)2 * bad);
-    if (bad) HIPCHK(hipMemcpy(list.data(), c->aux + 2, (size_t)bad * 8, hipMemcpyDeviceToHost));
+    uint32_t* const list = new (std::nothrow) uint32_t[(size_t)2 * bad + 2]; /* (nothing may throw across the C boundary) */
+    if (!list) {
+        c->unverified = true; /* nothing has been replayed: the next call tries again */
+        snprintf(g_err, sizeof g_err, "out of host memory while catching up tiles left behind by chained launches");
+        return POM_E_NOMEM;
+    }
+    struct Free {
+        uint32_t* p;
+        ~Free() { delete[] p; }
+    } free_list{list};
+    if (bad) HIPCHK(hipMemcpy(list, c->aux + 2, (size_t)bad * 8, hipMemcpyDeviceToHost));
     if (getenv("POM_CHAIN_VERBOSE"))
         fprintf(stderr, "pom: chained launches left %u tile(s) behind (flags %u: %s%s%s); replaying their ticks\n", bad, flags,
                 (flags & POM_CHAIN_E_TIMEOUT) ? "a wavefront waited out its limit " : "", (flags & POM_CHAIN_E_XCD) ? "a tile changed its XCD " : "",
