@@ -1315,13 +1315,14 @@ struct PomStepper {
         POM_CUT(L, 40);
         if (L.bCnt > 0) {
             /* ResetBombFlags + FillBombDestPos, step_utility.cpp:331-337,146-152.  The same pass notes whether any
-             * bomb of this env is moving and whether two bombs share a cell (121-bit occupancy in 4 registers):
-             * if neither, loop B below cannot see a collision and collapses to one cell test per bomb. */
-            int moving = 0, shared = 0;
+             * bomb of this env is moving: if none is, loop B below collapses to one cell test per bomb.  (Two resting bombs
+             * on one cell — SURVEY Q8 — do "collide" in HasBombCollision, but ResolveBombCollision only sets directions that are
+             * IDLE already to IDLE, and the bombs of such a group that skip their cell test share their cell with one that
+             * makes it: without a moving bomb shared cells change nothing.  Rounds 1 - 3 tracked them in a 121-bit occupancy
+             * set: ~50 VALU per wavefront-tick for a distinction without a difference.) */
+            int moving = 0;
             int ripe = 0; /* some bomb's own cell shows PASSAGE or a flame: the only cells loop B's resting case acts on */
             uint32_t cand = 0; /* queue offsets of the resting bombs under an agent that walked onto them this tick */
-            uint32_t occ[4] = {0, 0, 0, 0};
-            int mine = 0;
             /* TickBombs' timer decrement (step_utility.cpp:226-231) is folded into this pass: nothing between here and TickBombs
              * reads a timer, and loops A / B only replace the position and direction fields of a word, which commutes with
              * `- (1 << 16)` as long as that does not borrow.  A bomb whose timer is already 0 (out-of-order timers)
@@ -1343,15 +1344,6 @@ struct PomStepper {
                 a.put_bdest(k, key);
                 moving |= pb_dir(b) != 0;
                 const int idx = pb_y(b) * POM_N + pb_x(b);
-                const int w = (idx >> 5) > 3 ? 3 : idx >> 5; /* a position off the board (no live bomb has one: upload checks) counts into the last word */
-                const uint32_t m = 1u << (idx & 31);
-                const uint32_t cur = pick4(w, occ);
-                shared |= (cur & m) != 0;
-                mine += (cur & m) == 0; /* |my cell set| */
-                occ[0] |= w == 0 ? m : 0u;
-                occ[1] |= w == 1 ? m : 0u;
-                occ[2] |= w == 2 ? m : 0u;
-                occ[3] |= w >= 3 ? m : 0u;
                 /* loop A, looked at in the same pass (only meaningful if nothing moves, see below): a resting bomb under an
                  * agent that walked onto it this tick means a bounce-back */
                 if (idx < POM_CELLS) {
@@ -1368,18 +1360,12 @@ struct PomStepper {
                 }
             }
             if (A::G > 1) {
-                /* one quad reduction for all the flags: cand (offsets 0..19) | ripe | late | shared | moving */
-                const uint32_t fl = (uint32_t)a.gor((int)(cand | ((uint32_t)ripe << 20) | ((uint32_t)late << 21) | ((uint32_t)shared << 22) |
-                                                          ((uint32_t)moving << 23)));
+                /* one quad reduction for all the flags: cand (offsets 0..19) | ripe | late | moving */
+                const uint32_t fl = (uint32_t)a.gor((int)(cand | ((uint32_t)ripe << 20) | ((uint32_t)late << 21) | ((uint32_t)moving << 23)));
                 cand = fl & 0xFFFFFu;
                 ripe = (int)((fl >> 20) & 1u);
                 late = (int)((fl >> 21) & 1u);
                 moving = (int)((fl >> 23) & 1u);
-                /* two lanes' bombs share a cell iff the lanes' cell sets overlap: |union| < sum of |set| */
-                int all = 0;
-#pragma unroll
-                for (int w = 0; w < 4; w++) all += __builtin_popcount((uint32_t)a.gor((int)occ[w]));
-                shared = (int)((fl >> 22) & 1u) | (a.gadd(mine) != all);
             }
             folded_ = 1;
             int touched = cand != 0; /* did anything after the pass get to write the queue?  (then its head is read again) */
@@ -1410,14 +1396,14 @@ struct PomStepper {
             POM_STAMP(L, POM_PH_BOMB_A);
             POM_CUT(L, 60);
             /* bomb loop B, step.cpp:230-278 */
-            touched |= moving | shared | ripe;
+            touched |= moving | ripe;
             /* While no bomb moves and no two share a cell, HasBombCollision is false for every bomb and each one "moves" onto its
              * own cell (step.cpp:243-272): PASSAGE there becomes BOMB, a flame detonates the bomb, anything else stays (a static
              * item makes the reference set the already idle bomb idle).  If the pass above saw neither passage nor flame under a
              * bomb, loop B has nothing to do (loop A in between only writes agent and BOMB items).  Otherwise look first: without
-             * a detonation the writes are independent and done in parallel; with one — as with moving bombs or shared cells — the
-             * queue is walked in order by the literal loop. */
-            int general = moving | shared;
+             * a detonation the writes are independent and done in parallel (two bombs on one cell write the same BOMB item);
+             * with one — as with moving bombs — the queue is walked in order by the literal loop. */
+            int general = moving;
             if (!general && ripe) {
                 int in_flame = 0;
                 POM_NOUNROLL
