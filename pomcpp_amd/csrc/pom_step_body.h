@@ -169,7 +169,7 @@ POM_HD int div11(int c) /* c / 11 for a cell index (exact for 0 <= c < 586): one
     return c / POM_N;
 #endif
 }
-POM_HD int oob(int x, int y) { return (unsigned)x >= (unsigned)POM_N || (unsigned)y >= (unsigned)POM_N; }
+POM_HD int oob(int x, int y) { return (int)((unsigned)x >= (unsigned)POM_N) | (int)((unsigned)y >= (unsigned)POM_N); } /* (| not ||: no branch) */
 
 /* displacement of a Move / Direction (step_utility.cpp:9-31): 1 up(-y) 2 down(+y) 3 left(-x) 4 right(+x) */
 POM_HD int mv_dx(int m) { return m == 4 ? 1 : m == 3 ? -1 : 0; }
@@ -1107,13 +1107,15 @@ struct PomStepper {
                 const int live = !ag_dead(av);
                 const int myrank = (int)((rankp >> (4 * m)) & 0xF), mydepth = (int)((depthp >> (4 * m)) & 0xF);
                 /* plants: PlantBombModifiedLife(x, y, m, 11), bboard.cpp:125-146 — independent of everybody's movement */
-                const int wants = live && mvm == POM_MOVE_BOMB && pom_sext8((uint32_t)av >> 16) < pom_sext16((uint32_t)a1v);
+                /* (bitwise & on 0 / 1 values here and below, not &&: on lane-varying operands hipcc turns the short-circuit forms into
+                 * nested exec-mask branches — a dozen scalar instructions and two jumps for three compares) */
+                const int wants = live & (int)(mvm == POM_MOVE_BOMB) & (int)(pom_sext8((uint32_t)av >> 16) < pom_sext16((uint32_t)a1v));
                 const int w_all = a.gor(wants << m);
                 int slot_off = 0; /* planters visited before me */
 #pragma unroll
                 for (int j = 0; j < 4; j++) slot_off += ((w_all >> j) & 1) & ((int)((rankp >> (4 * j)) & 0xF) < myrank);
-                const int fits = wants && L.bCnt + slot_off < POM_Q;
-                int ubm = (wants && !fits) ? POM_UB_QUEUE_OVERFLOW : 0;
+                const int fits = wants & (int)(L.bCnt + slot_off < POM_Q);
+                int ubm = (wants & !fits) ? POM_UB_QUEUE_OVERFLOW : 0;
                 int planted_moving = 0; /* PlantBomb leaves the slot's old direction nibble in place: the new bomb may move */
                 if (fits) {
                     const int slot = wrap20(L.bIdx + L.bCnt + slot_off);
@@ -1127,17 +1129,17 @@ struct PomStepper {
                     av = ag_bombcount_add(av, 1);
                 }
                 /* where the agent wants to go */
-                const int walks = live && mvm != POM_MOVE_IDLE && mvm != POM_MOVE_BOMB;
+                const int walks = live & (int)(mvm != POM_MOVE_IDLE) & (int)(mvm != POM_MOVE_BOMB);
                 const int x = ag_x(av), y = ag_y(av);
                 const int dkey = (dstp >> (8 * m)) & 0xFF;
                 const int ddx = (dkey & 0xF) - 1, ddy = (dkey >> 4) - 1;
-                const int goes = walks && !oob(ddx, ddy);
+                const int goes = walks & !oob(ddx, ddy);
                 const int dc = ddy * POM_N + ddx, oc = y * POM_N + x;
                 const int vacated = ((on_bomb >> m) & 1) ? POM_C_BOMB : POM_C_PASSAGE;
                 int died_sum = 0;
                 POM_NOUNROLL
                 for (int r = 0; r < rounds; r++) {
-                    const int act = goes && mydepth == r;
+                    const int act = goes & (int)(mydepth == r);
                     int item = 0, collide = 0, shows_me = 0;
                     if (act) { /* what is there now: everything the earlier rounds did has been written */
                         item = a.cell(dc);
@@ -1152,7 +1154,7 @@ struct PomStepper {
                      * planted just now inherited one.  Only asked when nobody waits for anybody (the shortcut below). */
                     int bombs_move = 1;
                     if (nroots == 4) {
-                        const int kicks = act && !pc_is_flame(item) && !collide && item == POM_C_BOMB && ag_kick(av);
+                        const int kicks = act & !pc_is_flame(item) & !collide & (int)(item == POM_C_BOMB) & ag_kick(av);
                         bombs_move = ((on_bomb >> 4) & 1) | a.gor(kicks | planted_moving);
                     }
                     int died = 0;
@@ -1349,13 +1351,12 @@ struct PomStepper {
                 if (idx < POM_CELLS) {
                     const int e = a.cell(idx);
                     ripe |= (e == POM_C_PASSAGE) | pc_is_flame(e);
-                    if (pc_is_static_block(e) || pc_is_agent(e)) {
+                    if (pc_is_static_block(e) | pc_is_agent(e)) {
                         const int ag = get_agent(pb_x(b), pb_y(b));
-                        if (ag > -1) {
-                            const int m2 = (mvp >> (4 * ag)) & 0xF;
-                            const int was = (oldp >> (8 * ag)) & 0xFF;
-                            if (m2 != POM_MOVE_IDLE && m2 != POM_MOVE_BOMB && pb_pos(b) != was) cand |= 1u << k;
-                        }
+                        const int ag3 = ag & 3; /* (ag == -1: agent 3's fields are read and the answer masked) */
+                        const int m2 = (mvp >> (4 * ag3)) & 0xF;
+                        const int was = (oldp >> (8 * ag3)) & 0xFF;
+                        cand |= (uint32_t)((int)(ag > -1) & (int)(m2 != POM_MOVE_IDLE) & (int)(m2 != POM_MOVE_BOMB) & (int)(pb_pos(b) != was)) << k;
                     }
                 }
             }
