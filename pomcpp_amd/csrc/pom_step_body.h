@@ -212,9 +212,9 @@ struct PomStepper {
         for (int i = 0; i < L.bCnt; i += 4) {
             const int b0 = bomb_at(i), b1 = bomb_at(i + 1), b2 = bomb_at(i + 2), b3 = bomb_at(i + 3);
             int r = -1;
-            r = (i + 3 < L.bCnt && pb_pos(b3) == pos) ? i + 3 : r;
-            r = (i + 2 < L.bCnt && pb_pos(b2) == pos) ? i + 2 : r;
-            r = (i + 1 < L.bCnt && pb_pos(b1) == pos) ? i + 1 : r;
+            r = ((int)(i + 3 < L.bCnt) & (int)(pb_pos(b3) == pos)) ? i + 3 : r;
+            r = ((int)(i + 2 < L.bCnt) & (int)(pb_pos(b2) == pos)) ? i + 2 : r;
+            r = ((int)(i + 1 < L.bCnt) & (int)(pb_pos(b1) == pos)) ? i + 1 : r;
             r = pb_pos(b0) == pos ? i : r;
             if (r >= 0) return r;
         }
@@ -227,7 +227,7 @@ struct PomStepper {
         int r = -1;
 #pragma unroll
         for (int i = 3; i >= 0; i--)
-            r = (!ag_dead(L.a0[i]) && (L.a0[i] & 0xFFFF) == want) ? i : r;
+            r = ((!ag_dead(L.a0[i])) & (int)((L.a0[i] & 0xFFFF) == want)) ? i : r;
         return r;
     }
 
@@ -387,7 +387,7 @@ struct PomStepper {
                 for (int i = 1; i <= lim; i++) {
                     const int c = ray_cell(c0, r, i);
                     const int e = a.cell(c);
-                    if (e == POM_C_BOMB || pc_is_agent(e)) {
+                    if ((int)(e == POM_C_BOMB) | pc_is_agent(e)) {
                         /* SpawnFlameItem explodes the first queued bomb on this cell, if there is one (bboard.cpp:30-40) */
                         const int cy = div11(c);
                         if (bomb_index_alone((c - cy * POM_N) | (cy << 4)) >= 0) {
@@ -727,7 +727,7 @@ struct PomStepper {
                 const int c0 = y * POM_N + x;
                 {
                     const int e = a.cell(c0);
-                    if (pc_is_flame(e) && ((e & 0x3FFF) >> 3) == sig) a.set_cell(c0, pc_flag_item(e & 3));
+                    if (pc_is_flame(e) & (int)(((e & 0x3FFF) >> 3) == sig)) a.set_cell(c0, pc_flag_item(e & 3));
                 }
                 POM_NOUNROLL
                 for (int r = a.sub(); r < 4; r += A::G) {
@@ -736,7 +736,7 @@ struct PomStepper {
                     for (int i = 1; i <= lim; i++) {
                         const int c = ray_cell(c0, r, i);
                         const int e = a.cell(c);
-                        if (pc_is_flame(e) && ((e & 0x3FFF) >> 3) == sig) a.put_cell(c, pc_flag_item(e & 3));
+                        if (pc_is_flame(e) & (int)(((e & 0x3FFF) >> 3) == sig)) a.put_cell(c, pc_flag_item(e & 3));
                     }
                 }
             }
@@ -856,7 +856,7 @@ struct PomStepper {
         int blocked = oob(tx, ty);
         if (!blocked) {
             const int e = a.cell(ty * POM_N + tx);
-            blocked = pc_is_static_block(e) || pc_is_agent(e);
+            blocked = pc_is_static_block(e) | pc_is_agent(e);
         }
         if (blocked) {
             set_bomb_at(k, pb_set(b, 0xF00000u, 0));
@@ -865,7 +865,7 @@ struct PomStepper {
                 const int m = (mvp >> (4 * ag)) & 0xF;
                 const int av = sel4(ag, L.a0);
                 const int was = (oldp >> (8 * ag)) & 0xFF;
-                if (m != POM_MOVE_IDLE && m != POM_MOVE_BOMB && (ag_x(av) | (ag_y(av) << 4)) != was) {
+                if ((int)(m != POM_MOVE_IDLE) & (int)(m != POM_MOVE_BOMB) & (int)((ag_x(av) | (ag_y(av) << 4)) != was)) {
                     chain_reversion(mvp, ag, bombs_move);
                     if (get_agent(bx, by) == -1) a.set_cell(by * POM_N + bx, POM_C_BOMB);
                 }
@@ -991,7 +991,7 @@ struct PomStepper {
         for (int i = 0; i < 4; i++) {
 #pragma unroll
             for (int j = i; j < 4; j++) {
-                if (dx[i] == px[j] && dy[i] == py[j] && dx[j] == px[i] && dy[j] == py[i]) {
+                if ((int)(dx[i] == px[j]) & (int)(dy[i] == py[j]) & (int)(dx[j] == px[i]) & (int)(dy[j] == py[i])) {
                     dx[i] = px[i]; dy[i] = py[i];
                     dx[j] = px[j]; dy[j] = py[j];
                 }
@@ -1005,7 +1005,7 @@ struct PomStepper {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (j == i) continue;
-                    if (is_root && !((deadmask >> j) & 1) && dx[i] == px[j] && dy[i] == py[j]) {
+                    if (is_root & !((deadmask >> j) & 1) & (int)(dx[i] == px[j]) & (int)(dy[i] == py[j])) {
                         dep = (dep & ~(0xFu << (4 * j))) | ((uint32_t)i << (4 * j));
                         is_root = 0;
                     }
