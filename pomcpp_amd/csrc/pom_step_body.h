@@ -1331,6 +1331,7 @@ struct PomStepper {
              * WOULD borrow into the fields above: it is left as it is, marked in the (just cleared, otherwise unused) moved
              * nibble, and decremented where the reference does it, after loop B (the cold pass below). */
             int late = 0;
+            uint32_t movers = 0; /* queue offsets of the bombs with a direction */
             POM_NOUNROLL
             for (int k = a.sub(); k < L.bCnt; k += A::G) { /* split: each lane its own slots, combined below */
                 int b = pb_set(bomb_at(k), 0xF000000u, 0);
@@ -1345,6 +1346,7 @@ struct PomStepper {
                 if (k == 0) top = b;
                 a.put_bdest(k, key);
                 moving |= pb_dir(b) != 0;
+                movers |= (uint32_t)(pb_dir(b) != 0) << k;
                 const int idx = pb_y(b) * POM_N + pb_x(b);
                 /* loop A, looked at in the same pass (only meaningful if nothing moves, see below): a resting bomb under an
                  * agent that walked onto it this tick means a bounce-back */
@@ -1367,6 +1369,7 @@ struct PomStepper {
                 ripe = (int)((fl >> 20) & 1u);
                 late = (int)((fl >> 21) & 1u);
                 moving = (int)((fl >> 23) & 1u);
+                movers = (uint32_t)a.gor((int)movers);
             }
             folded_ = 1;
             int touched = cand != 0; /* did anything after the pass get to write the queue?  (then its head is read again) */
@@ -1379,13 +1382,17 @@ struct PomStepper {
             POM_STAMP(L, POM_PH_BOMB_PASS);
             POM_CUT(L, 50);
             int next = 0; /* loop A is done for the offsets below `next` */
-            if (!moving) {
+            {
+                /* ... and with moving bombs in the queue the same holds for the RESTING ones: besides the noted set only the bombs
+                 * that have a direction can be blocked to any effect (round 4; until then a moving bomb anywhere in the queue
+                 * sent the loop over all of it) */
+                uint32_t todo = cand | movers;
                 irregular_ = 0;
                 POM_NOUNROLL
-                while (cand && !irregular_) {
-                    const int k = __builtin_ctz(cand);
-                    cand &= cand - 1u;
-                    loop_a_bomb(mvp, oldp, k, 0);
+                while (todo && !irregular_) {
+                    const int k = __builtin_ctz(todo);
+                    todo &= todo - 1u;
+                    loop_a_bomb(mvp, oldp, k, moving);
                     next = k + 1;
                 }
                 /* the argument above holds as long as every bounce was a plain step back; after any other (two agents on one
