@@ -585,8 +585,17 @@ def worker(args) -> None:
                 ev7.record(stream)
                 e3.sync()
             ms_obs[fused] = ev6.elapsed_time(ev7) / n_x
+        # ... and with the compact observation (POM_OBS_CODES: uint8 [5][11][11], 605 B per env instead of 1,936)
+        codes, _, _ = e3.observe(dtype="codes", attrs=False)
+        for rep in range(2):
+            ev6.record(stream)
+            for t in range(n_x):
+                e3.step_device_observe(mv_dev[t % 8], dtype="codes", out=codes, attrs=False)
+            ev7.record(stream)
+            e3.sync()
+        ms_obs["codes"] = ev6.elapsed_time(ev7) / n_x
         e3.close()
-        del tape, planes, a_at, e_at
+        del tape, planes, a_at, e_at, codes
         # Throughput mode: ticks_per_launch = T > 1 keeps the record in LDS for T ticks (synthetic move stream only) —
         # NOT the canonical roofline run (a step there is one HBM round trip per tick); reported on its own, per tick
         for name, n_o, t_o in (("throughput_T4_65536_envs", 65536, 4), ("throughput_T16_65536_envs", 65536, 16),
@@ -649,7 +658,9 @@ def worker(args) -> None:
         other["step_plus_observation_65536_envs"] = {
             "one_launch_us": ms_obs[True] * 1e3, "two_launches_us": ms_obs[False] * 1e3, "value": plan["n_envs"] / (ms_obs[True] * 1e-3),
             "unit": "env-steps/s (each with its uint8 [16][11][11] observation written)",
-            "note": "pom_batch_step_device_observe against pom_batch_step_device + pom_batch_observe, explicit moves, POM_RESET_AT_END"}
+            "one_launch_codes_us": ms_obs["codes"] * 1e3, "value_codes": plan["n_envs"] / (ms_obs["codes"] * 1e-3),
+            "note": "pom_batch_step_device_observe against pom_batch_step_device + pom_batch_observe, explicit moves, POM_RESET_AT_END; "
+                    "*_codes: the compact observation (POM_OBS_CODES, uint8 [5][11][11]) in the same launch"}
         other["explicit_moves_device_65536_envs"] = {
             "value": plan["n_envs"] / (ms_x * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_x, "steps": n_x,
             "note": "pom_batch_step_device with auto_reset = POM_RESET_AT_END: Move[4] from device memory, one launch per tick on the caller's stream"}

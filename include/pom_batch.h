@@ -240,9 +240,17 @@ int pom_batch_device_view(PomBatch* h, void** base, int64_t* n_pad, int32_t* rec
  *          bombStrength, canKick.   env_attrs (nullable): int32 [n][4] = timeStep, aliveAgents, status (1 done | 2 draw |
  *          4 timed out | 8 restarted: POM_RESET_AT_END put the env on this start state at the end of the last tick), winner
  *          (-1 = none) — the values pom_batch_status reports.
+ *
+ * POM_OBS_CODES — the compact form, uint8 [n][5][11][11], 605 bytes per env instead of 1,936 (the export is bound by the bytes it
+ * writes): for training loops that expand the board themselves (an embedding look-up on the cell code).  The five arrays are the
+ * ones a Pommerman observation carries:
+ *    0  board: the small numbers of the reference's Item enum (bboard.hpp:54-71) — 0 passage, 1 rigid, 2 wood (any flag), 3 bomb,
+ *       4 flames, 5 fog, 6 extra-bomb, 7 incr-range, 8 kick, 9 agent dummy, 10..13 agents 0..3; 255 for anything else
+ *    1 2 3  bomb strength, life, direction (planes 12, 13, 14 above)        4  flame life (plane 15 above)
+ * per_agent must be 0 (agents are named by id; agent_attrs says who is where).
  */
-enum { POM_OBS_U8 = 0, POM_OBS_F16 = 1, POM_OBS_F32 = 2 };
-enum { POM_OBS_PLANES = 16, POM_OBS_AGENT_ATTRS = 8, POM_OBS_ENV_ATTRS = 4 };
+enum { POM_OBS_U8 = 0, POM_OBS_F16 = 1, POM_OBS_F32 = 2, POM_OBS_CODES = 3 };
+enum { POM_OBS_PLANES = 16, POM_OBS_CODE_PLANES = 5, POM_OBS_AGENT_ATTRS = 8, POM_OBS_ENV_ATTRS = 4 };
 int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_agent, int32_t* agent_attrs_dev,
                       int32_t* env_attrs_dev);
 /* pom_batch_step_device followed by pom_batch_observe in ONE launch: the kernel that plays the tick writes the observation of the

@@ -71,3 +71,20 @@ def observe(states: np.ndarray, per_agent: bool = False, dtype=np.uint8):
             views[:, a] = pl[:, order]
         pl = views
     return pl.astype(dtype), attrs, np.stack([states["timeStep"], states["aliveAgents"]], axis=1).astype(np.int32)
+
+
+def observe_codes(states: np.ndarray) -> np.ndarray:
+    """the compact form (POM_OBS_CODES), uint8 [n,5,11,11]: the board as the small numbers of the Item enum (bboard.hpp:54-71),
+    then planes 12..15 of observe()"""
+    n = len(states)
+    board = states["board"].reshape(n, N, N).astype(np.int64)
+    out = np.full((n, 5, N, N), 255, dtype=np.int64)
+    for v in (0, 1, 3, 5, 6, 7, 8, 9):                    # PASSAGE RIGID BOMB FOG EXTRABOMB INCRRANGE KICK AGENTDUMMY
+        out[:, 0][board == v] = v
+    out[:, 0][(board >> 8) == 2] = 2                      # IS_WOOD :73-76
+    out[:, 0][(board >> 16) == 4] = 4                     # IS_FLAME :85-88
+    for i in range(4):
+        out[:, 0][board == AGENT0 + i] = 10 + i           # AGENT0.. :67-70
+    pl, _, _ = observe(states)
+    out[:, 1:5] = pl[:, 12:16]
+    return out.astype(np.uint8)

@@ -372,14 +372,18 @@ class BatchEnvironment:
         """Planes of every env as torch tensors on the handle's device, written by one kernel on the handle's stream
         (pom_batch_observe; plane list in include/pom_batch.h).  Returns (planes, agent_attrs, env_attrs): planes
         [n,16,11,11] or [n,4,16,11,11]; agent_attrs int32 [n,4,8]; env_attrs int32 [n,4] (None, None if attrs=False).
-        `out` reuses a planes tensor from an earlier call.  torch is only the owner of the device memory here."""
+        dtype "codes": the compact form, uint8 [n,5,11,11] = board codes 0..13, bomb strength / life / direction, flame life
+        (POM_OBS_CODES; no per-agent view).  `out` reuses a planes tensor from an earlier call.  torch is only the owner of the
+        device memory here."""
         import torch
-        kinds = {"uint8": (0, torch.uint8), "float16": (1, torch.float16), "float32": (2, torch.float32)}
+        kinds = {"uint8": (0, torch.uint8), "float16": (1, torch.float16), "float32": (2, torch.float32), "codes": (3, torch.uint8)}
         if dtype not in kinds:
             raise ValueError(f"dtype must be one of {sorted(kinds)}")
+        if dtype == "codes" and per_agent:
+            raise ValueError("the codes layout has no per-agent view")
         code, tdt = kinds[dtype]
         dev = torch.device("cuda", self.device)
-        shape = (self.n, 4, 16, 11, 11) if per_agent else (self.n, 16, 11, 11)
+        shape = (self.n, 5, 11, 11) if dtype == "codes" else (self.n, 4, 16, 11, 11) if per_agent else (self.n, 16, 11, 11)
         if out is None:
             out = torch.empty(shape, dtype=tdt, device=dev)
         elif tuple(out.shape) != shape or out.dtype != tdt or not out.is_contiguous() or out.device != dev:

@@ -598,17 +598,30 @@ int pom_batch_sync(PomBatch* h)
     return POM_OK;
 }
 
-int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_agent, int32_t* agent_attrs_dev,
-                      int32_t* env_attrs_dev)
+/* what both observation entry points ask of their arguments */
+static int observe_args(const char* who, const void* planes_dev, int32_t dtype, int32_t per_agent, const int32_t* agent_attrs_dev,
+                        const int32_t* env_attrs_dev)
 {
-    if (!h || !planes_dev || dtype < POM_OBS_U8 || dtype > POM_OBS_F32) return POM_E_ARG;
-    const int64_t esz = dtype == POM_OBS_U8 ? 1 : dtype == POM_OBS_F16 ? 2 : 4;
+    if (!planes_dev || dtype < POM_OBS_U8 || dtype > POM_OBS_CODES) return POM_E_ARG;
+    if (dtype == POM_OBS_CODES && per_agent) {
+        snprintf(g_err, sizeof g_err, "%s: POM_OBS_CODES names the agents by id (10..13), there is no per-agent view of it", who);
+        return POM_E_ARG;
+    }
+    const uintptr_t esz = dtype == POM_OBS_F16 ? 2 : dtype == POM_OBS_F32 ? 4 : 1;
     if (((uintptr_t)planes_dev & (4 * esz - 1)) || ((uintptr_t)agent_attrs_dev & 15) || ((uintptr_t)env_attrs_dev & 15) ||
         (dtype == POM_OBS_U8 && !per_agent && ((uintptr_t)planes_dev & 15)))
     {
-        snprintf(g_err, sizeof g_err, "pom_batch_observe: output pointers must be 16-byte aligned");
+        snprintf(g_err, sizeof g_err, "%s: output pointers must be 16-byte aligned", who);
         return POM_E_ARG;
     }
+    return POM_OK;
+}
+
+int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_agent, int32_t* agent_attrs_dev,
+                      int32_t* env_attrs_dev)
+{
+    if (!h) return POM_E_ARG;
+    if (int ar = observe_args("pom_batch_observe", planes_dev, dtype, per_agent, agent_attrs_dev, env_attrs_dev)) return ar;
     HIPCHK(hipSetDevice(h->device));
     if (int jr = join_parts(h)) return jr;
     ObserveParams p;
@@ -629,14 +642,8 @@ int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_
 int pom_batch_step_device_observe(PomBatch* h, const int32_t* moves_dev, void* planes_dev, int32_t dtype, int32_t per_agent,
                                   int32_t* agent_attrs_dev, int32_t* env_attrs_dev)
 {
-    if (!h || !moves_dev || !planes_dev || dtype < POM_OBS_U8 || dtype > POM_OBS_F32) return POM_E_ARG;
-    const int64_t esz = dtype == POM_OBS_U8 ? 1 : dtype == POM_OBS_F16 ? 2 : 4;
-    if (((uintptr_t)planes_dev & (4 * esz - 1)) || ((uintptr_t)agent_attrs_dev & 15) || ((uintptr_t)env_attrs_dev & 15) ||
-        (dtype == POM_OBS_U8 && !per_agent && ((uintptr_t)planes_dev & 15)))
-    {
-        snprintf(g_err, sizeof g_err, "pom_batch_step_device_observe: output pointers must be 16-byte aligned");
-        return POM_E_ARG;
-    }
+    if (!h || !moves_dev) return POM_E_ARG;
+    if (int ar = observe_args("pom_batch_step_device_observe", planes_dev, dtype, per_agent, agent_attrs_dev, env_attrs_dev)) return ar;
     HIPCHK(hipSetDevice(h->device));
     if (!h->quad) { /* the one-lane-per-env shapes have no fused twin: the two launches */
         if (int rc = pom_batch_step_device(h, moves_dev)) return rc;

@@ -612,72 +612,196 @@ __device__ __forceinline__ void obs_gather_out(const ObserveParams& p, const uin
 
 /* the planes and attributes of one tile's 16 envs, from the tile as it lies in LDS ([row][16] dwords); `stage`: OBS_STAGE_VECS
  * uint4 of LDS.  Called by the whole wavefront (one wavefront per workgroup: the barriers only order its own LDS traffic). */
-enum { OBS_STAGE_VECS = OBS_PASS_ENVS * OBS_ENV_BYTES / 16 + 1 }; /* + 16 B: the byte funnel reads one dword past a run */
-__device__ __forceinline__ void pom_observe_tile(const ObserveParams& p, const uint32_t* tile, uint4* stage, int64_t tile_id, int lane)
+enum {
+    OBS_CODE_PLANES = 5,                              /* POM_OBS_CODES: board codes, bomb strength / life / direction, flame life */
+    OBS_CODE_ENV_BYTES = OBS_CODE_PLANES * POM_CELLS, /* 605 */
+    OBS_CODE_PASS_ENVS = 4,                           /* 4 x 605 B = 605 dwords: a pass's output starts on a dword */
+    OBS_CODE_STAGE_VECS = (OBS_CODE_PASS_ENVS * OBS_CODE_ENV_BYTES + 15) / 16,
+    OBS_PLANE_STAGE_VECS = OBS_PASS_ENVS * OBS_ENV_BYTES / 16 + 1, /* + 16 B: the byte funnel reads one dword past a run */
+    OBS_STAGE_VECS = OBS_PLANE_STAGE_VECS > OBS_CODE_STAGE_VECS ? OBS_PLANE_STAGE_VECS : OBS_CODE_STAGE_VECS
+};
+static_assert(POM_OBS_CODE_PLANES == OBS_CODE_PLANES, "pom_batch.h");
+
+/* POM_OBS_CODES: what one cell shows as the small numbers of the reference's Item enum (bboard.hpp:54-71; the Python Pommerman
+ * board uses the same ones): 0 passage, 1 rigid, 2 wood (any flag), 3 bomb, 4 flames, 5 fog, 6 extra-bomb, 7 incr-range, 8 kick,
+ * 9 agent dummy, 10..13 agents 0..3; 255 for anything else */
+__device__ __forceinline__ int obs_code_of(int code)
 {
+    if (pc_is_agent(code)) return 10 + (code & 3);
+    if (pc_is_flame(code)) return 4;
+    if (pc_is_wood(code)) return 2;
+    return (code < 10 && code != 2 && code != 4) ? code : 255;
+}
+
+/* One pass of the export: E envs of the tile (q-th group of E) into the staging area — the 16 planes of an env (CODES = false,
+ * E = 1) or the five code planes of four envs (CODES = true).  "The first live bomb on a cell speaks for it" and "the first live
+ * flame spawned at a flame cell's FLAME_ID" (State::GetBomb's order, bboard.cpp:277-287; bboard.hpp:98-101) are answered without
+ * searching the queues per cell: a lane per queue slot writes its key (offset in the queue + 1) to its cell in a plane of the
+ * staging area that is not needed yet — the bombs into the strength plane, the flames into the bomb-direction plane — and lowers
+ * it until the smallest key of a cell has won; a flame cell then reads its flame with one look-up, a bomb slot that finds its own
+ * key is the first on its cell.  The flames' keys are wiped before the bombs write their three planes.  (Round 4; until then every
+ * flame cell walked the flame queue — a wavefront paid its longest queue on nearly every group of 64 cells, three quarters of the
+ * kernel's instructions.) */
+/* Between the phases of the export: "the other lanes' LDS writes so far are visible from here on".  One wavefront per workgroup and
+ * the LDS serves a wavefront's instructions in order, so the hardware has nothing to wait for; the compiler must not move LDS
+ * accesses across.  (Until round 4 this was __syncthreads(), whose s_waitcnt vmcnt(0) made every pass wait for its own global
+ * stores to be acknowledged: 16 passes x the store latency — three quarters of the wavefront's life, profiles/r04_observe_pmc.txt.) */
+__device__ __forceinline__ void obs_lds_order() { asm volatile("" ::: "memory"); }
+
+template <bool CODES>
+__device__ __forceinline__ void pom_observe_stage(const uint32_t* tile, uint4* stage, int q, int lane)
+{
+    constexpr int E = CODES ? (int)OBS_CODE_PASS_ENVS : (int)OBS_PASS_ENVS, EB = CODES ? (int)OBS_CODE_ENV_BYTES : (int)OBS_ENV_BYTES;
+    constexpr int P_STRENGTH = CODES ? 1 : 12, P_DIR = P_STRENGTH + 2, P_FLAME = P_STRENGTH + 3;
+    constexpr int VECS = (E * EB + 15) / 16, SLOT_IT = (E * POM_Q + 63) / 64;
+    static_assert((E & (E - 1)) == 0, "lanes per env");
+    static_assert(OBS_STAGE_VECS * 16 >= E * EB + 8, "eight bytes behind the planes take the writes of lanes that have nothing to write");
+    /* The phases below are written without branches where a lane-varying `if` would do (hipcc makes exec-mask forests of those, and
+     * the kernel is bound by the instructions it issues, scalar ones included): a lane with nothing to write writes to `dump`. */
+    const int dump = E * EB + (lane & 7);
     uint8_t* stage_b = reinterpret_cast<uint8_t*>(stage);
     const uint16_t* tile_h = reinterpret_cast<const uint16_t*>(tile);
+#pragma unroll
+    for (int i = 0; i < (VECS + 63) / 64; i++)
+        if (64 * i + 63 < VECS || lane + 64 * i < VECS) stage[lane + 64 * i] = make_uint4(0, 0, 0, 0);
+    obs_lds_order();
+    /* the queue slots' keys */
+    int key_f[SLOT_IT], key_b[SLOT_IT], bomb[SLOT_IT]; /* where a live slot's key goes (byte offset in the staging area; `dump`: not live) */
+#pragma unroll
+    for (int i = 0; i < SLOT_IT; i++) {
+        const int idx = lane + 64 * i;
+        const int ok = (64 * i + 63 < E * POM_Q) | (int)(idx < E * POM_Q);
+        const int ei = E == 1 ? 0 : (idx * 3277) >> 16 /* idx / 20 for idx < 128 */, k = idx - ei * POM_Q, ec = q * E + (ok ? ei : 0);
+        const uint32_t m = tile[POM_REC_META * 16 + ec], m2 = tile[POM_REC_META2 * 16 + ec];
+        const int bIdx = (int)((m >> 8) & 0xFF), bCnt = (int)((m >> 16) & 0xFF), fIdx = (int)(m >> 24), fCnt = (int)(m2 & 0xFF);
+        const int kk = ok ? k : 0;
+        const uint32_t f = tile[(POM_REC_FLAMES + wrap20(fIdx + kk)) * 16 + ec];
+        const int b = (int)tile[(POM_REC_BOMBS + wrap20(bIdx + kk)) * 16 + ec];
+        bomb[i] = b;
+        const int fc = (int)(f & 0xFF) + POM_N * (int)((f >> 8) & 0xFF);
+        key_f[i] = (ok & (int)(k < fCnt) & (int)(fc < POM_CELLS)) ? ei * EB + P_DIR * POM_CELLS + fc : dump;
+        key_b[i] = (ok & (int)(k < bCnt) & (int)(pb_x(b) < POM_N) & (int)(pb_y(b) < POM_N)) ? ei * EB + P_STRENGTH * POM_CELLS + pb_y(b) * POM_N + pb_x(b) : dump;
+        stage_b[key_f[i]] = (uint8_t)(k + 1);
+        stage_b[key_b[i]] = (uint8_t)(k + 1);
+    }
+    POM_NOUNROLL
+    for (;;) { /* several slots on one cell: one of their writes landed — the smaller keys write again until the smallest stands */
+        obs_lds_order();
+        int low_f[SLOT_IT], low_b[SLOT_IT], again = 0;
+#pragma unroll
+        for (int i = 0; i < SLOT_IT; i++) {
+            const int idx = lane + 64 * i;
+            const int key = idx - (E == 1 ? 0 : (idx * 3277) >> 16) * POM_Q + 1;
+            low_f[i] = (int)(key_f[i] != dump) & (int)(stage_b[key_f[i]] > key);
+            low_b[i] = (int)(key_b[i] != dump) & (int)(stage_b[key_b[i]] > key);
+            again |= low_f[i] | low_b[i];
+        }
+        if (!__any(again)) break; /* (the usual case: no two live slots on one cell) */
+        for (int i = 0; i < SLOT_IT; i++) { /* (one or two rounds: unrolled without being asked) */
+            const int idx = lane + 64 * i;
+            const int key = idx - (E == 1 ? 0 : (idx * 3277) >> 16) * POM_Q + 1;
+            stage_b[low_f[i] ? key_f[i] : dump] = (uint8_t)key;
+            stage_b[low_b[i] ? key_b[i] : dump] = (uint8_t)key;
+        }
+    }
+    obs_lds_order();
+    /* cells: a byte each into the plane its code names (or its code into the board plane); flame cells look their flame up.  A lane
+     * takes a dword of the board — two cells — of one env per round: lane -> (env of the pass, board row of the tile), so that every
+     * address is a base plus a constant */
+    {
+        constexpr int LPE = 64 / E, ROW_IT = (61 + LPE - 1) / LPE; /* lanes per env; rounds over the 61 board rows */
+        const int ei = E == 1 ? 0 : lane & (E - 1), j = E == 1 ? lane : lane / E, ec = q * E + ei;
+        const int fIdx = (int)(tile[POM_REC_META * 16 + ec] >> 24);
+        auto put = [&](int code, int c, int ok) { /* the cell's byte; returns whether the cell is a flame with a centre on the board */
+            /* codes below 16 by table: a nibble per code, 15 = none */
+            const int nib = (int)(((CODES ? 0xFFFFFF98765F3F10ull : 0xFFFFFFF765FF3F10ull) >> (4 * (code & 15))) & 15u);
+            int v = code < 16 ? nib : 15; /* CODES: the cell's number; else: its plane */
+            v = pc_is_wood(code) ? 2 : v;
+            v = pc_is_flame(code) ? 4 : v;
+            v = pc_is_agent(code) ? (CODES ? 10 : 8) + (code & 3) : v;
+            if (CODES) stage_b[ok ? ei * EB + c : dump] = (uint8_t)(v == 15 ? 255 : v);
+            else stage_b[(ok & (int)(v != 15)) ? ei * EB + v * POM_CELLS + c : dump] = 1;
+            return ok & pc_is_flame(code) & (int)((code & 0x3FFF) >> 3 < POM_CELLS); /* FLAME_ID: the cell the flame was spawned at */
+        };
+        auto life = [&](int code, int c, int is_flame) { /* unconditional: a cell that is no flame looks at its own (zero) byte */
+            const int key = stage_b[is_flame ? ei * EB + P_DIR * POM_CELLS + ((code & 0x3FFF) >> 3) : ei * EB + P_FLAME * POM_CELLS + c];
+            const int tl = pom_sext8(tile[(POM_REC_FLAMES + wrap20(fIdx + (key ? key - 1 : 0))) * 16 + ec] >> 16);
+            stage_b[is_flame ? ei * EB + P_FLAME * POM_CELLS + c : dump] = (uint8_t)((int)(key != 0) & (int)(tl > 0) ? tl : 0);
+        };
+#pragma unroll
+        for (int i = 0; i < ROW_IT; i++) {
+            const int r = j + LPE * i;
+            const int ok = (LPE * i + LPE - 1 < 61) | (int)(r < 61); /* (a lane past the board reads some other row of the tile) */
+            const uint32_t w = tile[(POM_REC_BOARD + r) * 16 + ec];
+            const int lo = (int)(w & 0xFFFF), hi = (int)(w >> 16);
+            const int f0 = put(lo, 2 * r, ok);
+            const int f1 = put(hi, 2 * r + 1, ok & (int)(r < 60)); /* the board's last dword holds one cell */
+            if (f0 | f1) {
+                life(lo, 2 * r, f0);
+                life(hi, 2 * r + 1, f1);
+            }
+        }
+    }
+    int first[SLOT_IT];
+#pragma unroll
+    for (int i = 0; i < SLOT_IT; i++) {
+        const int idx = lane + 64 * i;
+        first[i] = (int)(key_b[i] != dump) & (int)(stage_b[key_b[i]] == idx - (E == 1 ? 0 : (idx * 3277) >> 16) * POM_Q + 1);
+    }
+    obs_lds_order();
+#pragma unroll
+    for (int i = 0; i < SLOT_IT; i++) stage_b[key_f[i]] = 0; /* the direction plane is the bombs' again */
+    obs_lds_order();
+#pragma unroll
+    for (int i = 0; i < SLOT_IT; i++) {
+        stage_b[first[i] ? key_b[i] : dump] = (uint8_t)pb_strength(bomb[i]);
+        stage_b[first[i] ? key_b[i] + 1 * POM_CELLS : dump] = (uint8_t)pb_time(bomb[i]);
+        stage_b[first[i] ? key_b[i] + 2 * POM_CELLS : dump] = (uint8_t)pb_dir(bomb[i]);
+    }
+    obs_lds_order();
+}
 
+/* The compact layout (POM_OBS_CODES): uint8 [n][5][11][11] — 605 bytes per env instead of 1,936, for training loops that expand
+ * the board codes themselves (an embedding look-up).  Four envs are staged at a time (2,420 B, a whole number of dwords) and leave
+ * as dword stores; the batch's last bytes, where n is no multiple of 4, leave byte by byte. */
+__device__ __forceinline__ void pom_observe_tile_codes(const ObserveParams& p, const uint32_t* tile, uint4* stage, int64_t tile_id, int lane)
+{
+    const uint8_t* stage_b = reinterpret_cast<const uint8_t*>(stage);
+    for (int q = 0; q < 16 / OBS_CODE_PASS_ENVS; q++) {
+        const int64_t e0 = tile_id * 16 + q * OBS_CODE_PASS_ENVS;
+        if (e0 >= p.n) break;
+        pom_observe_stage<true>(tile, stage, q, lane);
+        const int64_t left = p.n - e0;
+        const int bytes = (int)(left < OBS_CODE_PASS_ENVS ? left : OBS_CODE_PASS_ENVS) * OBS_CODE_ENV_BYTES;
+        uint8_t* out_b = reinterpret_cast<uint8_t*>(p.planes) + e0 * OBS_CODE_ENV_BYTES; /* e0 is a multiple of 4: on a dword */
+        uint32_t* out_w = reinterpret_cast<uint32_t*>(out_b);
+        const uint32_t* stage_w = reinterpret_cast<const uint32_t*>(stage);
+#pragma unroll
+        for (int i = 0; i < (OBS_CODE_PASS_ENVS * OBS_CODE_ENV_BYTES / 4 + 63) / 64; i++) {
+            const int idx = lane + 64 * i;
+            if (idx < (bytes >> 2)) out_w[idx] = stage_w[idx];
+        }
+        if (lane < (bytes & 3)) out_b[(bytes & ~3) + lane] = stage_b[(bytes & ~3) + lane];
+        obs_lds_order();
+    }
+}
+
+__device__ __forceinline__ void pom_observe_tile(const ObserveParams& p, const uint32_t* tile, uint4* stage, int64_t tile_id, int lane)
+{
+    static_assert(OBS_PASS_ENVS == 1, "the plane layout is staged env by env");
+    if (p.dtype == POM_OBS_CODES) pom_observe_tile_codes(p, tile, stage, tile_id, lane);
+    else
     for (int q = 0; q < 16 / OBS_PASS_ENVS; q++) {
         const int64_t e0 = tile_id * 16 + q * OBS_PASS_ENVS;
         if (e0 >= p.n) break;
-        constexpr int VECS = OBS_PASS_ENVS * OBS_ENV_BYTES / 16; /* 484 */
-#pragma unroll
-        for (int i = 0; i < (VECS + 63) / 64; i++)
-            if (lane + 64 * i < VECS) stage[lane + 64 * i] = make_uint4(0, 0, 0, 0);
-        __syncthreads(); /* one wavefront per workgroup: orders the phases' LDS traffic, costs no wait */
-        /* cells: one byte each into the plane its code names; flame cells also look their flame up */
-#pragma unroll
-        for (int i = 0; i < (OBS_PASS_ENVS * POM_CELLS + 63) / 64; i++) {
-            const int idx = lane + 64 * i;
-            if (idx >= OBS_PASS_ENVS * POM_CELLS) break;
-            const int ei = idx / POM_CELLS, c = idx - ei * POM_CELLS, ec = q * OBS_PASS_ENVS + ei;
-            const int code = tile_h[(c >> 1) * 32 + 2 * ec + (c & 1)];
-            const int pl = obs_plane_of(code);
-            uint8_t* o = stage_b + ei * OBS_ENV_BYTES + c;
-            if (pl >= 0) o[pl * POM_CELLS] = 1;
-            if (pl == 4) {
-                const int id = (code & 0x3FFF) >> 3;
-                const uint32_t m = tile[POM_REC_META * 16 + ec], m2 = tile[POM_REC_META2 * 16 + ec];
-                const int fIdx = (int)(m >> 24), fCnt = (int)(m2 & 0xFF);
-                POM_NOUNROLL
-                for (int k = 0; k < fCnt && k < POM_Q; k++) {
-                    const uint32_t f = tile[(POM_REC_FLAMES + wrap20(fIdx + k)) * 16 + ec];
-                    if ((int)(f & 0xFF) + POM_N * (int)((f >> 8) & 0xFF) == id) {
-                        const int tl = pom_sext8(f >> 16);
-                        o[15 * POM_CELLS] = (uint8_t)(tl < 0 ? 0 : tl);
-                        break;
-                    }
-                }
-            }
-        }
-        /* bombs: the first live bomb on a cell speaks for it */
-#pragma unroll
-        for (int i = 0; i < (OBS_PASS_ENVS * POM_Q + 63) / 64; i++) {
-            const int idx = lane + 64 * i;
-            if (idx >= OBS_PASS_ENVS * POM_Q) break;
-            const int ei = idx / POM_Q, k = idx - ei * POM_Q, ec = q * OBS_PASS_ENVS + ei;
-            const uint32_t m = tile[POM_REC_META * 16 + ec];
-            const int bIdx = (int)((m >> 8) & 0xFF), bCnt = (int)((m >> 16) & 0xFF);
-            if (k >= bCnt) continue;
-            const int b = (int)tile[(POM_REC_BOMBS + wrap20(bIdx + k)) * 16 + ec];
-            int first = 1;
-            POM_NOUNROLL
-            for (int j = 0; j < k; j++) first &= pb_pos((int)tile[(POM_REC_BOMBS + wrap20(bIdx + j)) * 16 + ec]) != pb_pos(b);
-            if (!first || pb_x(b) >= POM_N || pb_y(b) >= POM_N) continue;
-            uint8_t* o = stage_b + ei * OBS_ENV_BYTES + pb_y(b) * POM_N + pb_x(b);
-            o[12 * POM_CELLS] = (uint8_t)pb_strength(b);
-            o[13 * POM_CELLS] = (uint8_t)pb_time(b);
-            o[14 * POM_CELLS] = (uint8_t)pb_dir(b);
-        }
-        /* out */
-        __syncthreads();
+        constexpr int VECS = OBS_PASS_ENVS * OBS_ENV_BYTES / 16; /* 121 */
+        pom_observe_stage<false>(tile, stage, q, lane);
         if (p.dtype == POM_OBS_U8 && !p.per_agent) {
             uint4* out = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(p.planes) + e0 * OBS_ENV_BYTES);
 #pragma unroll
             for (int i = 0; i < (VECS + 63) / 64; i++) {
                 const int idx = lane + 64 * i;
-                if (idx < VECS && e0 + idx / (OBS_ENV_BYTES / 16) < p.n) out[idx] = stage[idx]; /* (non-temporal stores: 45 us against 40 fused) */
+                if (64 * i + 63 < VECS || idx < VECS) out[idx] = stage[idx]; /* (non-temporal stores: 45 us against 40 fused) */
             }
         } else if (p.dtype == POM_OBS_U8) {
             obs_gather_out<uint8_t>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
@@ -686,7 +810,7 @@ __device__ __forceinline__ void pom_observe_tile(const ObserveParams& p, const u
         } else {
             obs_gather_out<float>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
         }
-        __syncthreads();
+        obs_lds_order();
     }
     /* attributes: lane -> (env lane/4, agent lane%4), 32 contiguous bytes each */
     const int ec = lane >> 2, id = lane & 3;
@@ -852,8 +976,8 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     /* POLICY: the danger map (32 rows of bytes) and the cell sets (12 rows) live where the tick keeps its bomb destinations
      * and explosion frames (26 rows) — the policy of a tick is over before its tick begins.  156 rows = 9,984 B: 16
      * wavefronts per CU, i.e. all of 65,536 envs resident at once. */
-    /* OBS: the staging area of one env's planes (1,936 + 16 B = 31 rows) lies over the same scratch rows — the tick is over when
-     * the observation begins: 143 rows = 9,152 B, still 16 wavefronts per CU */
+    /* OBS: the staging area — one env's planes (1,936 + 16 B) or four envs' code planes (2,420 B: 38 rows) — lies over the same
+     * scratch rows — the tick is over when the observation begins: 150 rows = 9,600 B, still 16 wavefronts per CU */
     constexpr int OBS_ROWS = (OBS_STAGE_VECS * 16 + EPW * 4 - 1) / (EPW * 4);
     constexpr int ROWS = POLICY ? POM_REC_DWORDS + 44 : OBS ? POM_REC_DWORDS + (OBS_ROWS > 26 ? OBS_ROWS : 26) : LDS_ROWS;
     static_assert(ROWS >= LDS_ROWS, "the tick's scratch rows fit under the overlay");
@@ -1458,7 +1582,12 @@ __global__ __launch_bounds__(64) void pom_observe_kernel(ObserveParams p)
     }
     const int64_t tile_id = p.block0 + tile_local;
     load_tile16_x4(p.state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    /* The builtin, not inline asm: the compiler's own wait-count bookkeeping must SEE that the LDS-DMA rows have landed before the
+     * pass loop begins — otherwise it assumes at the loop's head that they may still be in flight and puts an s_waitcnt vmcnt(0) in
+     * front of the first tile read of EVERY pass, which (stores count in vmcnt too) waits for the previous pass's global stores:
+     * 31 of a wavefront's 58 k cycles, profiles/r04_observe_pmc.txt.  0x0F70: vmcnt(0), the other counters left alone. */
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
     pom_observe_tile(p, tile, stage, tile_id, lane);
 }
 

@@ -25,14 +25,24 @@ env.make_game(pa.make_boards(a.envs, seed=1000003))
 for t in range(300):
     env.step_device(mv[t % 8].data_ptr())
 planes, _, _ = env.observe(attrs=False)
+codes, _, _ = env.observe(dtype="codes", attrs=False)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 out = {}
-for name in ("step only", "two launches", "one launch"):
+for name in ("step only", "two launches", "one launch", "codes: two launches", "codes: one launch", "observe only", "codes: observe only"):
     for rep in range(2):
         e0.record(stream)
         for t in range(a.steps):
             if name == "one launch":
                 env.step_device_observe(mv[t % 8], out=planes, attrs=False)
+            elif name == "codes: one launch":
+                env.step_device_observe(mv[t % 8], dtype="codes", out=codes, attrs=False)
+            elif name == "observe only":
+                env.observe(out=planes, attrs=False)
+            elif name == "codes: observe only":
+                env.observe(dtype="codes", out=codes, attrs=False)
+            elif name == "codes: two launches":
+                env.step_device(mv[t % 8].data_ptr())
+                env.observe(dtype="codes", out=codes, attrs=False)
             else:
                 env.step_device(mv[t % 8].data_ptr())
                 if name == "two launches":

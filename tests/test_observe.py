@@ -52,6 +52,32 @@ def test_oracle_planes_on_a_hand_made_state():
     assert v.shape == (1, 4, 16, 11, 11) and v[0, 0, 8, 0, 0] == 1 and v[0, 1, 11, 0, 0] == 1 and v[0, 3, 9, 0, 0] == 1
 
 
+def test_oracle_codes_on_a_hand_made_state():
+    from pomcpp_amd.state import new_states
+    ob = _oracle()
+    s = new_states(1)
+    b = s["board"][0]
+    b[0, 0] = Item.AGENT0 + 3
+    b[2, 3] = Item.RIGID
+    b[4, 5] = Item.WOOD + 2
+    b[6, 6] = Item.BOMB
+    b[7, 1] = Item.KICK
+    b[8, 8] = 5            # FOG
+    b[8, 9] = 2            # not an Item the reference writes (WOOD is 2 << 8)
+    b[9, 9] = Item.FLAMES + ((9 + 11 * 9) << 3) + 1
+    s["bombs_queue"][0, 0] = 6 + (6 << 4) + (1 << 8) + (3 << 12) + (7 << 16) + (4 << 20)
+    s["bombs_count"][0] = 1
+    s["flames_queue"][0, 0]["x"] = 9
+    s["flames_queue"][0, 0]["y"] = 9
+    s["flames_queue"][0, 0]["timeLeft"] = 3
+    s["flames_count"][0] = 1
+    c = ob.observe_codes(s)
+    assert c.shape == (1, 5, 11, 11) and c.dtype == np.uint8
+    assert (c[0, 0, 0, 0], c[0, 0, 2, 3], c[0, 0, 4, 5], c[0, 0, 6, 6], c[0, 0, 7, 1], c[0, 0, 8, 8], c[0, 0, 8, 9], c[0, 0, 9, 9]) == (13, 1, 2, 3, 8, 5, 255, 4)
+    assert (c[0, 1, 6, 6], c[0, 2, 6, 6], c[0, 3, 6, 6], c[0, 4, 9, 9]) == (3, 7, 4, 3)
+    assert (c[0, 0] == 0).sum() == 121 - 8 and c[0, 1:].sum() == 3 + 7 + 4 + 3
+
+
 def _played_states(n, ticks, kind="ffa", seed=3):
     from pomcpp_amd.batch import BatchEnvironment, MODE_ENV
     env = BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=300)
@@ -98,6 +124,28 @@ def test_views_and_element_types(hip_lib, per_agent, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,ticks", [("ffa", 200, 0), ("ffa", 1001, 57), ("stress", 778, 23), ("stress", 67, 5), ("ffa", 5, 120), ("ffa", 16, 30)])
+def test_codes_match_the_oracle(hip_lib, kind, n, ticks):
+    """the compact layout (POM_OBS_CODES); batch sizes with every remainder mod 4 (a pass stages four envs and the batch's last
+    bytes leave one by one), the bytes behind the last env untouched"""
+    import torch
+    ob = _oracle()
+    env = _played_states(n, ticks, kind)
+    want = ob.observe_codes(env.get_state())
+    buf = torch.full((n * 605 + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+    got, attrs, eattrs = env.observe(dtype="codes", out=buf[: n * 605].view(n, 5, 11, 11))
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert (buf[n * 605:] == 0xAB).all()
+    _, want_attrs, want_env = ob.observe(env.get_state())
+    assert np.array_equal(attrs.cpu().numpy(), want_attrs) and np.array_equal(eattrs.cpu().numpy()[:, :2], want_env)
+    if kind == "stress" and ticks > 10:
+        assert want[:, 1].any() and want[:, 3].any() and want[:, 4].any() and (want[:, 0] == 4).any()
+    with pytest.raises(ValueError):
+        env.observe(dtype="codes", per_agent=True)
+    env.close()
+
+
+@pytest.mark.gpu
 def test_observation_follows_the_game(hip_lib):
     """observe -> step -> observe on the stream the steps run on: planes always describe the state a download returns"""
     ob = _oracle()
@@ -128,7 +176,7 @@ def test_bad_arguments_are_refused(hip_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("at_end,fresh", [(True, False), (False, False), (True, True)])
-@pytest.mark.parametrize("per_agent,dtype", [(False, "uint8"), (True, "uint8"), (False, "float32"), (True, "float16")])
+@pytest.mark.parametrize("per_agent,dtype", [(False, "uint8"), (True, "uint8"), (False, "float32"), (True, "float16"), (False, "codes")])
 def test_step_and_observation_in_one_launch(hip_lib, oracle, at_end, fresh, per_agent, dtype):
     """pom_batch_step_device_observe: the launch that plays the tick writes the observation of the state it leaves behind.  Every
     tick: planes and attributes against the numpy restatement applied to the downloaded state, and the state itself against a
@@ -153,7 +201,9 @@ def test_step_and_observation_in_one_launch(hip_lib, oracle, at_end, fresh, per_
             twin.step_device(mv)
             states = env.get_state()
             assert states.tobytes() == twin.get_state().tobytes(), t
-            want, want_attrs, want_env = ob.observe(states, per_agent=per_agent, dtype=getattr(np, dtype))
+            want, want_attrs, want_env = ob.observe(states, per_agent=per_agent, dtype=np.uint8 if dtype == "codes" else getattr(np, dtype))
+            if dtype == "codes":
+                want = ob.observe_codes(states)
             assert np.array_equal(got.cpu().numpy(), want), t
             assert np.array_equal(attrs.cpu().numpy(), want_attrs), t
             e = eattrs.cpu().numpy()
