@@ -146,6 +146,55 @@ def test_codes_match_the_oracle(hip_lib, kind, n, ticks):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["uint8", "codes"])
+def test_first_in_queue_speaks_for_a_cell(hip_lib, dtype):
+    """hand-made states crowded with duplicates — up to 20 live bombs on five cells, up to 20 live flames on five centres (and up to
+    255 counted), queue heads anywhere in the ring, flame cells whose centre has no flame or lies outside the board: the first
+    live slot in queue order speaks (State::GetBomb's scan, bboard.cpp:277-287).  The export resolves "first" with key tables and a
+    lowering loop; this is the test that makes that loop run."""
+    from pomcpp_amd.batch import BatchEnvironment, MODE_ENV
+    from pomcpp_amd.state import new_states
+    ob = _oracle()
+    rng = np.random.default_rng(12)
+    n = 203
+    s = new_states(n)
+    for e in range(n):
+        cells = rng.choice(121, size=5, replace=False)
+        centres = rng.choice(121, size=5, replace=False)
+        s["bombs_index"][e] = rng.integers(0, 20)
+        s["bombs_count"][e] = rng.integers(0, 21)
+        for k in range(20):
+            c = int(cells[rng.integers(0, 5)])
+            s["bombs_queue"][e, k] = (c % 11) | ((c // 11) << 4) | (int(rng.integers(0, 4)) << 8) | (int(rng.integers(1, 11)) << 12) \
+                | (int(rng.integers(0, 10)) << 16) | (int(rng.integers(0, 5)) << 20)
+        s["flames_index"][e] = rng.integers(0, 20)
+        s["flames_count"][e] = rng.choice([0, 1, 5, 20, 21, 200, int(rng.integers(0, 21))])
+        for k in range(20):
+            c = int(centres[rng.integers(0, 5)])
+            f = s["flames_queue"][e, k]
+            f["x"], f["y"], f["timeLeft"], f["strength"] = c % 11, c // 11, rng.integers(-3, 12), rng.integers(0, 8)
+        b = s["board"][e].reshape(-1)
+        for c in cells:
+            b[c] = Item.BOMB if rng.integers(0, 2) else Item.AGENT0 + int(rng.integers(0, 4))
+        for c in rng.choice(121, size=30, replace=False):
+            if c in cells:
+                continue
+            centre = int(centres[rng.integers(0, 5)]) if rng.integers(0, 4) else int(rng.integers(0, 2047))  # some without a flame / off the board
+            b[c] = Item.FLAMES + (centre << 3) + int(rng.integers(0, 4))
+    with BatchEnvironment(n, mode=MODE_ENV) as env:
+        env.make_game(s)
+        states = env.get_state()
+        assert states.tobytes() == s.tobytes()
+        if dtype == "codes":
+            want = ob.observe_codes(states)
+        else:
+            want, _, _ = ob.observe(states)
+        got, _, _ = env.observe(dtype=dtype, attrs=False)
+        assert np.array_equal(got.cpu().numpy(), want)
+        assert want[:, -1].any() and (want[:, 1 if dtype == "codes" else 12] > 0).sum() > 2 * n
+
+
+@pytest.mark.gpu
 def test_observation_follows_the_game(hip_lib):
     """observe -> step -> observe on the stream the steps run on: planes always describe the state a download returns"""
     ob = _oracle()
