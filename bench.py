@@ -73,7 +73,7 @@ def _all_reduce(t, op, dist_mod):
 
 def reduce_counters(counters, dist_mod=None):
     """Sum the per-rank int64 counters over ranks (RCCL all-reduce on GPU, gloo in CPU tests)."""
-    if dist_mod is not None and dist_mod.is_initialized() and dist_mod.get_world_size() > 1:
+    if dist_mod is not None and dist_mod.is_initialized():  # (a communicator of one rank too: POM_BENCH_RCCL_SOLO)
         _all_reduce(counters, dist_mod.ReduceOp.SUM, dist_mod)
     return counters
 
@@ -81,7 +81,7 @@ def reduce_counters(counters, dist_mod=None):
 def reduce_max(value: float, device, dist_mod=None) -> float:
     import torch
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    if dist_mod is not None and dist_mod.is_initialized() and dist_mod.get_world_size() > 1:
+    if dist_mod is not None and dist_mod.is_initialized():
         _all_reduce(t, dist_mod.ReduceOp.MAX, dist_mod)
     return float(t.item())
 
@@ -90,13 +90,20 @@ def timed_region(run_steps, steps: int, barrier, in_region_reduce=None) -> float
     """The timed region: exactly `steps` steps between two barriers (each = dist.barrier + torch.cuda.synchronize()).  With
     several ranks `in_region_reduce` — the path's one collective, the all-reduce of the step counters — is issued INSIDE it,
     behind the last step.  Returns this rank's wall time."""
+    trace = os.environ.get("POM_BENCH_TRACE") == "1"
     barrier()
     t0 = time.perf_counter()
     run_steps(steps)
+    t_a = time.perf_counter()
     if in_region_reduce is not None:
         in_region_reduce()
+    t_b = time.perf_counter()
     barrier()
-    return time.perf_counter() - t0
+    t1 = time.perf_counter()
+    if trace:  # host time of the region's three pieces (the device runs behind the first two)
+        print(f"[trace] steps queued {1e6 * (t_a - t0):.0f} us, reduction queued {1e6 * (t_b - t_a):.0f} us, closing barrier {1e6 * (t1 - t_b):.0f} us",
+              file=sys.stderr, flush=True)
+    return t1 - t0
 
 
 # ---- the launcher behind `--gpus N` ---------------------------------------------------------------------------------
@@ -352,8 +359,12 @@ def worker(args) -> None:
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     backend = "none"
-    if world > 1:
+    # POM_BENCH_RCCL_SOLO=1: everything the N > 1 path does — the RCCL communicator, barriers, the tuning vote, the in-region
+    # all-reduce on a side stream — with a communicator of ONE rank: the only way to run that code under RCCL on a one-GPU box
+    multi = world > 1 or os.environ.get("POM_BENCH_RCCL_SOLO") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         backend = "gloo" if rehearsal else "nccl"
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -385,7 +396,7 @@ def worker(args) -> None:
     counters = torch.zeros(4, dtype=torch.int64, device=device)
 
     def barrier() -> None:
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -405,7 +416,7 @@ def worker(args) -> None:
         run_steps(args.burn_in)
         env.sync()
     tuned, tuning_steps = None, 0
-    if args.streams == 0 and world > 1:
+    if args.streams == 0 and multi:
         # Untimed: how many sub-batches per step?  More parts overlap more load/store with compute, but ROCm maps all streams
         # of the process onto 4 hardware queues and parts that share a queue serialize (profiles/r01_streams.txt) — how many
         # are free depends on the process (torch, RCCL's streams), so with a communicator in the process measure instead of
@@ -433,8 +444,16 @@ def worker(args) -> None:
         _all_reduce(votes, dist.ReduceOp.MAX, dist)  # every rank must run the same shape: the slowest rank's best
         env.set_streams(int(torch.argmin(votes).item()) + 1)
     run_steps(args.warmup)
-    env.counters_into(counters.data_ptr())
-    reduce_counters(counters, dist)  # warm the RCCL communicator outside the timed region
+    side = torch.cuda.Stream(device=device) if multi else None
+    if multi:
+        # warm what the timed region will use, the way it will use it: the side stream (its first use creates a hardware queue:
+        # 0.66 ms of host time, scripts/experiments/rccl/join_timing.py) and RCCL's all-reduce issued from it
+        env.counters_into(counters.data_ptr())
+        side.wait_stream(stream)
+        with torch.cuda.stream(side):
+            reduce_counters(counters, dist)
+        stream.wait_stream(side)
+        torch.cuda.synchronize()
     env.reset_counters()
 
     # The timed region: exactly K steps between two (barrier + torch.cuda.synchronize()) pairs.  With several ranks it also holds
@@ -442,8 +461,7 @@ def worker(args) -> None:
     # per-wavefront counters summed on the device behind the last step (on the launch stream), then ONE 32-byte all-reduce
     # (RCCL over xGMI) on a side stream.  Envs shard with no exchange on the data path, so this is all the ranks ever say to
     # each other.  On one GPU there is no collective; the counters are read after the region.
-    side = torch.cuda.Stream(device=device) if world > 1 else None
-    reduce_in_region = world > 1
+    reduce_in_region = multi
 
     def counters_allreduce() -> None:
         env.counters_into(counters.data_ptr())  # joins the sub-batches, one reduction kernel, on the launch stream
@@ -493,7 +511,7 @@ def worker(args) -> None:
     # by the device SimpleAgent policy, act x4 + Step per env-step as Environment::Step does.  200 untimed ticks first: games
     # last ~190 ticks under this policy, so the batch is then a steady mix of openings, mid-games and restarts.
     config3 = None
-    if world == 1 and args.policy == "random" and tpl == 1 and not args.no_config3:
+    if not multi and args.policy == "random" and tpl == 1 and not args.no_config3:
         env.make_game(start)
         env.set_tick(0)
         env.step_simple(args.seed, 200)
@@ -515,7 +533,7 @@ def worker(args) -> None:
     # with the caller's stream, so no pipelining across ticks).
     other = None
     default_run = (args.envs == 65536 and args.kind == "ffa" and args.dist == "random" and not args.fresh_boards)
-    if world == 1 and args.policy == "random" and tpl == 1 and not args.no_config3 and default_run:
+    if not multi and args.policy == "random" and tpl == 1 and not args.no_config3 and default_run:
         other = {}
         for name, n_o, kind_o, dist_o in (("config2_4096_envs_random", 4096, "ffa", 1), ("config5_65536_envs_stress", 65536, "stress", 2)):
             e2 = BatchEnvironment(n_o, device=local_rank, mode=MODE_ENV, auto_reset=True, max_steps=args.max_steps,
@@ -716,7 +734,7 @@ def worker(args) -> None:
                     "65,536-env PMC figure per env"}
     # like-for-like base of an N > 1 line: this rank's shard stepped while the other ranks' GPUs idle (same envs per GPU, same kernels)
     single_base = None
-    if world > 1:
+    if multi:
         barrier()
         if rank == 0:
             evA, evB = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -747,7 +765,7 @@ def worker(args) -> None:
         traffic, traffic_source, measured_in_run, traffic_failure = None, None, False, None
         tj = os.path.join(ROOT, TRAFFIC_JSON)
         headline_shape = (tpl == 1 and args.kind == "ffa" and args.dist == "random" and args.policy == "random" and not args.fresh_boards)
-        if args.measure_traffic and world == 1 and tpl == 1 and not args.traffic_probe:
+        if args.measure_traffic and not multi and tpl == 1 and not args.traffic_probe:
             live = measure_traffic(args)
             if live and "failed" not in live:
                 traffic, measured_in_run = live["hbm_bytes_per_step"], True
@@ -787,7 +805,7 @@ def worker(args) -> None:
                 "issue": issue, "issue_streams": issue_streams,
                 "burn_in_ticks": args.burn_in, "launches_per_step_tuning_ms": tuned, "untimed_tuning_steps": tuning_steps,
                 "parallelism": f"env-shard x{world}", "ranks": world, "collective_backend": backend,
-                "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                "rccl_ranks": dist.get_world_size() if multi else 1,
                 "collective_in_timed_region": ("one 32-byte all-reduce(SUM) of the step / episode counters behind the last step, on a side stream"
                                                if reduce_in_region else None),
                 "per_gpu_batch_note": (f"{ENVS_SINGLE_GPU} envs on one GPU (the headline), {ENVS_PER_GPU_SHARDED} per GPU with several "
@@ -840,11 +858,11 @@ def worker(args) -> None:
             line["config3_simple_agent"] = config3
         if other:
             line["other_configs"] = other
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(start, args.seed, dist_id, args.max_steps)
         print(json.dumps(line), flush=True)
     env.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
