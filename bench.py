@@ -422,6 +422,7 @@ def worker(args) -> None:
         # are free depends on the process (torch, RCCL's streams), so with a communicator in the process measure instead of
         # guessing.  A single-GPU run uses the library's default (3 from 49,152 envs up).  Results do not depend on the choice.
         tuned = {}
+        k_tune = max(10, min(args.steps, 100))  # calls of the length the timed region will issue: a third stream pays from ~40 ticks up
         for k in (3, 2, 1):  # first touch of a sub-stream creates its hardware queue (~10 ms once): keep that out of the timings
             env.set_streams(k)
             run_steps(5)
@@ -434,11 +435,11 @@ def worker(args) -> None:
                 run_steps(10)
                 env.sync()
                 t_a = time.perf_counter()
-                run_steps(40)
+                run_steps(k_tune)
                 env.sync()
-                dt = (time.perf_counter() - t_a) / 40 * 1e3
+                dt = (time.perf_counter() - t_a) / k_tune * 1e3
                 best_k = dt if best_k is None else min(best_k, dt)
-                tuning_steps += 50
+                tuning_steps += 10 + k_tune
             tuned[k] = best_k
         votes = torch.tensor([tuned[1], tuned[2], tuned[3]], dtype=torch.float64, device=device)
         _all_reduce(votes, dist.ReduceOp.MAX, dist)  # every rank must run the same shape: the slowest rank's best

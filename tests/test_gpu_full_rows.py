@@ -145,3 +145,32 @@ def test_bench_launcher_runs_two_real_ranks_on_one_gpu(hip_lib):
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 16384) < 1.0  # value = all ranks' env-steps over the slowest rank's time
     base = r["config"]["single_gpu_base"]  # rank 0's shard stepped alone, in the same run: the like-for-like base of a scaling curve
     assert base and base["value"] > 0 and base["steps"] == 12
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_multi_rank_path_under_rccl_with_one_rank(hip_lib):
+    """The N > 1 code of bench.py under RCCL itself (the rehearsal above runs it over gloo): POM_BENCH_RCCL_SOLO makes a one-rank
+    nccl communicator and takes every `several ranks` branch — communicator warm-up, the stream vote, barriers, the counters'
+    all-reduce on a side stream inside the timed region.  And the region must not pay for first uses: with 65,536 envs its steps run
+    ~12 us each; the all-reduce and the closing barrier may add tens of microseconds to the whole region, not hundreds per step."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, POM_BENCH_RCCL_SOLO="1", MASTER_PORT="29533")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-config3"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["config"]["collective_backend"] == "nccl" and r["config"]["rccl_ranks"] == 1
+    assert "all-reduce" in r["config"]["collective_in_timed_region"]
+    assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 65536) < 1.0
+    base = r["config"]["single_gpu_base"]
+    assert base and base["steps"] == 20
+    assert r["ms_per_step"] < 2.0 * base["ms_per_step"], (r["ms_per_step"], base["ms_per_step"])  # (it was 2.9 x before the side stream was warmed)
