@@ -88,6 +88,13 @@ for t in range(300):
         s = env.get_state(lo, m)
         want, want_attrs, _ = ob.observe(s)
         assert np.array_equal(planes[lo:lo + m].cpu().numpy(), want) and np.array_equal(attrs[lo:lo + m].cpu().numpy(), want_attrs), t
+        codes, _, _ = env.observe(dtype="codes", attrs=False)  # the compact layout of the same state, the whole batch against the 16 planes
+        pl = planes.to(torch.int64)
+        board = torch.full_like(pl[:, 0], 255)
+        for plane, value in ((0, 0), (1, 1), (2, 2), (3, 3), (4, 4), (5, 6), (6, 7), (7, 8), (8, 10), (9, 11), (10, 12), (11, 13)):
+            board = torch.where(pl[:, plane] == 1, torch.full_like(board, value), board)
+        assert torch.equal(codes[:, 0].to(torch.int64), board) and torch.equal(codes[:, 1:5], planes[:, 12:16]), t
+        assert np.array_equal(codes[lo:lo + m].cpu().numpy(), ob.observe_codes(s)), t
 env.close()
-print(f"fused step + observation: {N} envs x 300 ticks, slices = numpy restatement every 25 ticks")
+print(f"fused step + observation: {N} envs x 300 ticks, slices = numpy restatement every 25 ticks; code planes = the 16 planes, all envs")
 print(f"soak r04 ok in {time.time() - t_all:.0f} s (POM_CHAIN_WAIT_US={os.environ.get('POM_CHAIN_WAIT_US', 'default')})")
