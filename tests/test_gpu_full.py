@@ -66,6 +66,31 @@ def test_262144_envs_step_counts_and_shard_equivalence(hip_lib, oracle):
             assert _digest(env.get_state()) == _digest(whole[k * q:(k + 1) * q])
 
 
+def test_1048576_envs_beyond_the_memory_side_cache(hip_lib, oracle):
+    """The size of `bench.other_configs.headline_1048576_envs` (470 MB of records + as much of snapshots: every tick streams them from
+    and to HBM proper; sub-batches on parallel streams, not chained launches): boards drawn on the device, 60 ticks of random moves with
+    auto-reset; three slices — the first tile, one in the middle across a 65,536 boundary, the batch's last envs — equal the oracle, the
+    step count is exact, and a 65,536-env shard stepped on a handle of its own with env_offset (chained launches) ends in the same states."""
+    n, ticks, seed = 1048576, 60, 9
+    with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800) as env:
+        env.generate(21)
+        slices = ((0, 1024), (7 * 65536 - 700, 1400), (n - 1024, 1024))
+        starts = [env.get_state(lo, cnt) for lo, cnt in slices]
+        shard_lo = 11 * 65536
+        shard_start = env.get_state(shard_lo, 65536)
+        env.step_random(seed, DIST_RANDOM, ticks=ticks)
+        assert env.counters()[CNT_STEPS] == n * ticks
+        for (lo, cnt), ini in zip(slices, starts):
+            want = ini.copy()
+            oracle.run_random(want, ini, ticks, seed, lo, 0, DIST_RANDOM, 800)
+            assert _digest(env.get_state(lo, cnt)) == _digest(want), lo
+        shard_end = env.get_state(shard_lo, 65536)
+    with BatchEnvironment(65536, mode=MODE_ENV, auto_reset=True, max_steps=800, env_offset=shard_lo) as env:
+        env.make_game(shard_start)
+        env.step_random(seed, DIST_RANDOM, ticks=ticks)
+        assert _digest(env.get_state()) == _digest(shard_end)
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 129])
 def test_ragged_batch_sizes(hip_lib, oracle, n):
     start = pa.make_boards(n, seed=n)
