@@ -61,6 +61,7 @@ struct PomChain {
     uint32_t turn = 0;                      /* which stream the next launch goes to */
     bool unverified = false;                /* chained launches since the tiles' words were last checked (chain_settle) */
     uint64_t wait_limit = 0;                /* StepParams.chain_wait_limit */
+    int64_t wave_slots = 0;                 /* wavefronts of the step kernel the device holds at once: 16 per CU (launch_many_chain's rotation) */
     StepParams last_key;                    /* what the chained launches possibly still in flight were launched with (tick0 = the */
     void (*last_kernel)(StepParams) = nullptr; /* offset between ticks and visits), and which instantiation */
     std::vector<PomChainCall> log;          /* the chained calls since the last settle */
@@ -89,6 +90,11 @@ static bool chain_setup(PomChain* c, int64_t tiles, hipStream_t stream)
     /* how long a wavefront waits for its tile: POM_CHAIN_WAIT_US (tests force give-ups with 0), default two seconds */
     const char* wl = getenv("POM_CHAIN_WAIT_US");
     c->wait_limit = (uint64_t)(wl ? atoll(wl) : (long long)POM_CHAIN_WAIT_LIMIT_US) * 100u; /* the wall clock ticks at 100 MHz */
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+            c->wave_slots = (int64_t)cus * 16; /* the step kernel's occupancy: 4 wavefronts per SIMD (registers and LDS tile) */
+    }
 #if defined(POM_CHAIN_DIAG)
     const size_t words = (size_t)tiles * (POM_CHAIN_WORD_STRIDE + 68); /* + 68 diagnostic words per tile */
 #else

@@ -128,6 +128,7 @@ struct StepParams {
     uint32_t chain_seq0;
     uint32_t tape_len;         /* CHAIN with explicit moves: `moves` is a tape int32[tape_len][n][4], the visit at distance d from
                                   chain_seq0 plays tick d of it (0: `moves` is one tick's Move[4] array or nullptr) */
+    uint32_t chain_rot; /* chained: the launch's workgroups take their XCD's tiles starting this many positions in (< tiles per XCD; launch_many_chain) */
     uint64_t chain_wait_limit; /* how long a wavefront waits for the visit before its own, in ticks of the 100 MHz wall clock */
     /* OBS instantiation (pom_batch_step_device_observe): the planes / attributes of the state the tick leaves behind, written by
      * the same launch while the tile is still in LDS (pom_batch.h pom_batch_observe for the layout) */
@@ -996,10 +997,13 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     if (CHAIN) {
         /* the XCD the workgroup IS on decides its tile (launches of different queues start their round-robin at different
          * XCDs): XCD x plays tiles x * q .. x * q + q - 1, its k-th workgroup (workgroup ids x0, x0 + 8, ...) the k-th of them.
-         * The grid is padded to a multiple of 8 workgroups. */
+         * The grid is padded to a multiple of 8 workgroups.  chain_rot rotates that order within the XCD (a bijection: still every
+         * tile once per launch). */
         chain_xcd = pom_chain_xcd();
         const int64_t q = gridDim.x / 8;
-        tile_local = (int64_t)chain_xcd * q + blockIdx.x / 8;
+        int64_t k_in_xcd = (int64_t)(blockIdx.x / 8) + p.chain_rot;
+        if (k_in_xcd >= q) k_in_xcd -= q;
+        tile_local = (int64_t)chain_xcd * q + k_in_xcd;
         if (chain_xcd >= 8u) { /* not the machine this was written for: nothing is stepped, no ticket is drawn (the verify pass reports it) */
             if (lane == 0) __hip_atomic_fetch_or(p.chain_err, (uint32_t)POM_CHAIN_E_XCD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;

@@ -215,6 +215,7 @@ static int fill_params(PomBatch* h, StepParams& p, const int32_t* moves_dev, uin
     p.chain_seq0 = 0;
     p.tape_len = 0;
     p.chain_wait_limit = 0;
+    p.chain_rot = 0;
     p.obs_planes = nullptr;
     p.obs_agent_attrs = p.obs_env_attrs = nullptr;
     p.obs_dtype = p.obs_per_agent = 0;
@@ -784,6 +785,18 @@ static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bo
      * three streams against 9.9 on two, 60 ticks 10.1 / 10.7) and costs while it fills and drains (20 ticks 12.8 / 12.5, 10 ticks
      * 16.8 / 15.2; scripts/experiments/chain/call_length.py).  Any mix is fine: the tickets order the ticks, not the streams. */
     const int use = !h->chain_auto ? h->chain_parts : launches >= POM_CHAIN_LONG_CALL ? 3 : 2;
+    /* On two streams, where one launch fills the chip's wavefront slots exactly (65,536 envs: 4,096 tiles, 16 slots on each of 256
+     * CUs), every launch takes its XCD's tiles starting a sixteenth of them BEHIND where the launch before it started (a rotation
+     * of the workgroup -> tile map: still every tile once per launch, still on its XCD).  With the same order in every launch the
+     * two launches in flight meet on the same tiles more often than they must — the later visitor spins in a slot for the rest of
+     * the earlier one's tick; short calls: 20 ticks 11.65 -> 11.31 us per step (ten runs each, medians; another box 11.75 -> 11.16),
+     * 10 ticks 13.44 -> 13.08, 39 ticks unchanged.  Not on three streams (long calls: 9.0 -> 9.8 - 11.0 us, the launches there trail
+     * each other by a whole cycle and the common order is what keeps them apart) and not at other sizes (32,768 and 16,384 envs: no
+     * effect; 131,072: worse).  profiles/r04_chain_rotation.txt.  POM_CHAIN_ROT_DIV: the divisor (0: off). */
+    static const int rot_div = getenv("POM_CHAIN_ROT_DIV") ? atoi(getenv("POM_CHAIN_ROT_DIV")) : 16;
+    const uint32_t per_xcd = (uint32_t)(((tiles + POM_WPB - 1) / POM_WPB + 7) / 8);
+    const bool fills_the_chip = c->wave_slots > 0 && tiles <= c->wave_slots && tiles * 4 >= (int64_t)c->wave_slots * 3;
+    const uint32_t back = (use == 2 && fills_the_chip && rot_div > 0) ? per_xcd / (uint32_t)rot_div : 0u;
     h->chain_last_use = use;
     int issued = 0;
     hipError_t err = hipSuccess;
@@ -793,6 +806,7 @@ static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bo
         const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
         hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
         StepParams q = p;
+        q.chain_rot = back ? (uint32_t)(((uint64_t)(c->visits + (uint32_t)issued) * (uint64_t)(per_xcd - back)) % per_xcd) : 0u;
         void* args[1] = {&q};
         err = hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, dim3(64 * POM_WPB), args, 0, st, ev0, ev1, 0);
         if (err != hipSuccess) break;
