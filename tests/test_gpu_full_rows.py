@@ -159,7 +159,11 @@ def test_bench_multi_rank_path_under_rccl_with_one_rank(hip_lib):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, POM_BENCH_RCCL_SOLO="1", MASTER_PORT="29533")
+    import socket
+    with socket.socket() as sk:  # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, POM_BENCH_RCCL_SOLO="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-config3"],
