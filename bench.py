@@ -51,7 +51,10 @@ ALGO_BYTES_PER_STEP = 2024  # 1004 B State read + 1004 B State write + 16 B Move
 PACKED_BYTES_PER_STEP = 2 * 448  # what the device record moves per env-step: 112 dwords read + written (pom_packed.h)
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 TRAFFIC_JSON = os.path.join("profiles", "r04_traffic.json")
-ENVS_SINGLE_GPU, ENVS_PER_GPU_SHARDED = 65536, 32768  # BASELINE: 64k envs at one GPU; config 4 = 262,144 envs = 8 x 32,768
+# BASELINE's metric: 64k envs per GPU.  Round 4: the same with several GPUs — weak scaling with the per-GPU work really fixed, so that
+# value(N) / (N x value(1)) compares like with like (until then N > 1 ran config 4's 32,768 per GPU: half the chip's wavefront slots,
+# 4.3 G against 7.4 G per GPU whatever the interconnect does).  Config 4 itself (262,144 envs on 8 GPUs) is `--gpus 8 --envs 32768`.
+ENVS_SINGLE_GPU, ENVS_PER_GPU_SHARDED = 65536, 65536
 
 
 def shard_plan(rank: int, world: int, envs_per_gpu: int) -> dict:
@@ -300,8 +303,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs", type=int, default=0,
-                    help="envs per GPU (default: 65,536 on one GPU — the headline; 32,768 per GPU with --gpus N > 1, i.e. BASELINE "
-                         "config 4's 262,144 envs at 8 GPUs)")
+                    help="envs per GPU (default: 65,536 — the headline's batch — at every N; BASELINE config 4's 262,144 envs on 8 GPUs: "
+                         "--gpus 8 --envs 32768)")
     ap.add_argument("--kind", default="ffa", choices=["ffa", "stress"])
     ap.add_argument("--dist", default="random", choices=["harmless", "random", "stress"])
     ap.add_argument("--ticks-per-launch", type=int, default=1)
@@ -809,8 +812,8 @@ def worker(args) -> None:
                 "rccl_ranks": dist.get_world_size() if multi else 1,
                 "collective_in_timed_region": ("one 32-byte all-reduce(SUM) of the step / episode counters behind the last step, on a side stream"
                                                if reduce_in_region else None),
-                "per_gpu_batch_note": (f"{ENVS_SINGLE_GPU} envs on one GPU (the headline), {ENVS_PER_GPU_SHARDED} per GPU with several "
-                                       "(config 4 = 262,144 envs at 8 GPUs): compare N > 1 lines with `--gpus 1 --envs 32768`"),
+                "per_gpu_batch_note": (f"{ENVS_PER_GPU_SHARDED} envs per GPU at every N (the headline's batch: weak scaling with the per-GPU "
+                                       "work fixed); BASELINE config 4 (262,144 envs on 8 GPUs) is `--gpus 8 --envs 32768`"),
                 "episodes_finished": episodes_finished,
                 "single_gpu_base": single_base,
             },

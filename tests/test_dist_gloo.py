@@ -80,16 +80,21 @@ def test_launcher_starts_n_ranks_and_relays_rank0_line():
 
 
 @pytest.mark.timeout(300)
-def test_gpus_8_without_envs_is_baseline_config_4_and_reduces_inside_the_region():
-    """the driver's command shape `bench.py --gpus 8 ...`: 32,768 envs per GPU = BASELINE config 4's 262,144, and the counter
-    all-reduce sits between the region's two barriers (bench.timed_region, the function the real worker times with)"""
+def test_gpus_8_keeps_the_headline_batch_per_gpu_and_reduces_inside_the_region():
+    """the driver's command shape `bench.py --gpus 8 ...`: 65,536 envs per GPU as on one GPU (weak scaling with the per-GPU work
+    fixed), and the counter all-reduce sits between the region's two barriers (bench.timed_region, the function the real worker
+    times with); BASELINE config 4 (262,144 envs on 8 GPUs) is `--envs 32768`"""
     import json
     out = _launch(["--gpus", "8", "--steps", "10"], 8)
     assert out.returncode == 0, out.stderr
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
-    assert r["n_gpus"] == 8 and r["rccl_ranks"] == 8 and r["envs_per_gpu"] == 32768 and r["global_envs"] == 262144
-    assert r["steps_total"] == 262144 * 10 and r["slowest"] == 8.0
+    assert r["n_gpus"] == 8 and r["rccl_ranks"] == 8 and r["envs_per_gpu"] == 65536 and r["global_envs"] == 524288
+    assert r["steps_total"] == 524288 * 10 and r["slowest"] == 8.0
     assert r["region"] == ["barrier", "steps", "allreduce", "barrier"]
+    out = _launch(["--gpus", "8", "--envs", "32768", "--steps", "10"], 8)
+    assert out.returncode == 0, out.stderr
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert r["envs_per_gpu"] == 32768 and r["global_envs"] == 262144 and r["steps_total"] == 262144 * 10
 
 
 def test_default_batch_per_gpu(monkeypatch):
@@ -97,10 +102,10 @@ def test_default_batch_per_gpu(monkeypatch):
     import bench
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     assert bench.parse_args([]).envs == 65536 and bench.parse_args(["--gpus", "1"]).envs == 65536
-    assert bench.parse_args(["--gpus", "8"]).envs == 32768 and bench.parse_args(["--gpus", "2"]).envs == 32768
+    assert bench.parse_args(["--gpus", "8"]).envs == 65536 and bench.parse_args(["--gpus", "2"]).envs == 65536
     assert bench.parse_args(["--gpus", "8", "--envs", "4096"]).envs == 4096
     monkeypatch.setenv("WORLD_SIZE", "8")  # under torch.distributed.run
-    assert bench.parse_args(["--gpus", "8"]).envs == 32768
+    assert bench.parse_args(["--gpus", "8"]).envs == 65536
 
 
 @pytest.mark.timeout(200)
