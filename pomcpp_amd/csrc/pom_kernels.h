@@ -540,18 +540,6 @@ struct ObserveParams {
     int32_t dtype, per_agent;
 };
 
-__device__ __forceinline__ int obs_plane_of(int code) /* which of the planes 0..11 a cell code sets, -1 = none (fog, ...) */
-{
-    if (code == 0) return 0;
-    if (code == 1) return 1;
-    if (pc_is_wood(code)) return 2;
-    if (code == POM_C_BOMB) return 3;
-    if (pc_is_flame(code)) return 4;
-    if (pc_is_powerup(code)) return code - 1; /* 6, 7, 8 -> 5, 6, 7 */
-    if (pc_is_agent(code)) return 8 + (code & 3);
-    return -1;
-}
-
 /* four staged bytes starting at byte offset `b` of the staging area (any alignment): two aligned dwords and a byte funnel */
 __device__ __forceinline__ uint32_t obs_bytes4(const uint32_t* stage_w, int b)
 {
@@ -622,17 +610,6 @@ enum {
     OBS_STAGE_VECS = OBS_PLANE_STAGE_VECS > OBS_CODE_STAGE_VECS ? OBS_PLANE_STAGE_VECS : OBS_CODE_STAGE_VECS
 };
 static_assert(POM_OBS_CODE_PLANES == OBS_CODE_PLANES, "pom_batch.h");
-
-/* POM_OBS_CODES: what one cell shows as the small numbers of the reference's Item enum (bboard.hpp:54-71; the Python Pommerman
- * board uses the same ones): 0 passage, 1 rigid, 2 wood (any flag), 3 bomb, 4 flames, 5 fog, 6 extra-bomb, 7 incr-range, 8 kick,
- * 9 agent dummy, 10..13 agents 0..3; 255 for anything else */
-__device__ __forceinline__ int obs_code_of(int code)
-{
-    if (pc_is_agent(code)) return 10 + (code & 3);
-    if (pc_is_flame(code)) return 4;
-    if (pc_is_wood(code)) return 2;
-    return (code < 10 && code != 2 && code != 4) ? code : 255;
-}
 
 /* One pass of the export: E envs of the tile (q-th group of E) into the staging area — the 16 planes of an env (CODES = false,
  * E = 1) or the five code planes of four envs (CODES = true).  "The first live bomb on a cell speaks for it" and "the first live
@@ -714,7 +691,11 @@ __device__ __forceinline__ void pom_observe_stage(const uint32_t* tile, uint4* s
         const int ei = E == 1 ? 0 : lane & (E - 1), j = E == 1 ? lane : lane / E, ec = q * E + ei;
         const int fIdx = (int)(tile[POM_REC_META * 16 + ec] >> 24);
         auto put = [&](int code, int c, int ok) { /* the cell's byte; returns whether the cell is a flame with a centre on the board */
-            /* codes below 16 by table: a nibble per code, 15 = none */
+            /* What the cell's code sets.  The 16 planes: passage 0, rigid 1, wood (any flag) 2, Item::BOMB 3, flames 4, the three power-ups
+             * (codes 6, 7, 8) 5, 6, 7, agent i 8 + i, anything else (fog, ...) none.  POM_OBS_CODES: the small numbers of the reference's
+             * Item enum (bboard.hpp:54-71; the Python Pommerman board uses the same ones) — 0 passage, 1 rigid, 2 wood, 3 bomb, 4 flames,
+             * 5 fog, 6 extra-bomb, 7 incr-range, 8 kick, 9 agent dummy, 10 + i agent i; 255 for anything else.
+             * Codes below 16 by table, a nibble per code (15 = none); wood, flames and agents by their bits. */
             const int nib = (int)(((CODES ? 0xFFFFFF98765F3F10ull : 0xFFFFFFF765FF3F10ull) >> (4 * (code & 15))) & 15u);
             int v = code < 16 ? nib : 15; /* CODES: the cell's number; else: its plane */
             v = pc_is_wood(code) ? 2 : v;
