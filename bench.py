@@ -425,7 +425,7 @@ def worker(args) -> None:
         # are free depends on the process (torch, RCCL's streams), so with a communicator in the process measure instead of
         # guessing.  A single-GPU run uses the library's default (3 from 49,152 envs up).  Results do not depend on the choice.
         tuned = {}
-        k_tune = max(10, min(args.steps, 100))  # calls of the length the timed region will issue: a third stream pays from ~40 ticks up
+        k_tune = max(10, min(args.steps, 100))  # calls of the length the timed region will issue: a third stream pays from ~50 ticks up
         for k in (3, 2, 1):  # first touch of a sub-stream creates its hardware queue (~10 ms once): keep that out of the timings
             env.set_streams(k)
             run_steps(5)

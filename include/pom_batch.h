@@ -64,7 +64,7 @@ typedef struct PomBatchOptions {
     int32_t max_steps;    /* ENV mode: env is done once timeStep reaches this (0 = no limit); StartGame's bound, environment.cpp:71 */
     int64_t env_offset;   /* global index of env 0, keys the synthetic move stream when a job is sharded over GPUs */
     int32_t envs_per_wave; /* 0 = default (16); else 16, 32 or 64 envs per wavefront (results are identical) */
-    int32_t streams;       /* 0 = choose (chained launches: 2 in a short call, 3 from 40 launches up; sub-batches by batch size); else 1..8: the streams chained
+    int32_t streams;       /* 0 = choose (chained launches: 2 in a short call, 3 from 50 launches up; sub-batches by batch size); else 1..8: the streams chained
                               launches rotate over, and the sub-batches per step — each on an internal stream — where launches
                               are not chained (results are identical; 1 = plain launches in a row on the handle's stream) */
     int32_t lanes_per_env; /* 0 = default (4: a quad of adjacent lanes runs each env's tick and splits its order-free parts,
@@ -91,7 +91,7 @@ enum {
                               pom_batch_destroy; a helper that cannot be started falls back to DIRECT for its part) */
     POM_ISSUE_GRAPH = 3,   /* chunks of 20 ticks replayed as HIP graphs, one per sub-stream; no library-owned thread */
     POM_ISSUE_CHAIN = 4    /* chained launches (pomcpp_amd/csrc/pom_chain.h): every launch covers the WHOLE batch and plays one tick,
-                              consecutive launches go to different internal HIP streams (two in a short call, three from 40 ticks
+                              consecutive launches go to different internal HIP streams (two in a short call, three from 50 ticks
                               up), and a ticket word per 16-env tile orders that tile's ticks — a tile's next tick waits for the
                               same tile's previous tick only, not for the slowest wavefront of the launch before.  Asynchronous
                               like the other modes: the call returns when its launches are queued; every other call of this API

@@ -617,7 +617,7 @@ static int launch_many_streams(PomBatch* h, const StepParams& p0, int launches, 
 }
 
 #ifndef POM_CHAIN_LONG_CALL
-#define POM_CHAIN_LONG_CALL 40
+#define POM_CHAIN_LONG_CALL 50
 #endif
 /* POM_ISSUE_CHAIN (pom_chain.h): `launches` one-tick launches, each over the WHOLE batch, dealt round-robin to the handle's
  * streams; the tiles' ticket words order the ticks.  *used = false: not available for this handle, nothing was launched, the
@@ -781,9 +781,10 @@ static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bo
     c->last_kernel = kernel;
     if (int rc = fork_parts(h, POM_KIND_CHAIN)) return rc;
     const dim3 grid((unsigned)(((tiles + POM_WPB - 1) / POM_WPB + 7) / 8 * 8)); /* a multiple of 8: every XCD gets as many workgroups as it has tiles */
-    /* how many streams: a third launch in flight pays once the pipeline runs (65,536 envs, per step: 400-tick call 9.1 us on
-     * three streams against 9.9 on two, 60 ticks 10.1 / 10.7) and costs while it fills and drains (20 ticks 12.8 / 12.5, 10 ticks
-     * 16.8 / 15.2; scripts/experiments/chain/call_length.py).  Any mix is fine: the tickets order the ticks, not the streams. */
+    /* how many streams: a third launch in flight pays once the pipeline runs and costs while it fills and drains.  65,536 envs, us
+     * per step on two / three streams at the round-4 kernels (with the rotation below on two): 30 ticks 10.47 / 11.13, 40 ticks
+     * 10.20 / 10.76, 60 ticks 10.05 / 9.72, 100 ticks 9.79 / 9.64, 300 ticks 9.7 / 9.0.  Any mix is fine: the tickets order the
+     * ticks, not the streams. */
     const int use = !h->chain_auto ? h->chain_parts : launches >= POM_CHAIN_LONG_CALL ? 3 : 2;
     /* On two streams, where one launch fills the chip's wavefront slots exactly (65,536 envs: 4,096 tiles, 16 slots on each of 256
      * CUs), every launch takes its XCD's tiles starting a sixteenth of them BEHIND where the launch before it started (a rotation
