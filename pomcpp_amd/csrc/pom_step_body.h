@@ -182,6 +182,8 @@ struct PomStepper {
     uint32_t oldp_ = 0; /* the agents' positions before the tick, a byte each (x | y << 4) */
     int irregular_ = 0; /* a bounce put an agent somewhere else than where he stood before the tick */
     int folded_ = 0;    /* between the bomb pass and TickBombs: the queued words already carry this tick's timer decrement */
+    uint32_t occ_[4] = {0u, 0u, 0u, 0u}; /* explode_long's set of bomb cells */
+    int occ_valid_ = 0, occ_keep_ = 0;   /* ... is current; ... may be kept for the next blast (TickBombs: nothing moves or is planted in between) */
     POM_HD PomStepper(A& a_, PomLane& l_) : a(a_), L(l_) {}
 
     POM_HD int bomb_at(int i) const { return a.bomb(wrap20(L.bIdx + i)); }
@@ -561,8 +563,11 @@ struct PomStepper {
         else flame_prologue(x, y, strength);
         int dir = 0, i = 1, sp = 0; /* the rays before `dir` are done, ray `dir` goes on at distance i, the others start at 1 */
         constexpr int NR = 4 / A::G;
-        uint32_t occ[4];
-        bomb_cells(occ);
+        /* the set is kept from one blast of TickBombs to the next (top_explosions): between them bombs only disappear, and a set that
+         * is too large is what the look-ups below are written for */
+        uint32_t (&occ)[4] = occ_;
+        if (!occ_valid_) bomb_cells(occ);
+        occ_valid_ = occ_keep_;
         POM_NOUNROLL
         for (;;) {
             const int c0 = y * POM_N + x;
@@ -909,12 +914,15 @@ struct PomStepper {
      * if the tick had no bombs */
     POM_HD void top_explosions(int top, int n)
     {
+        occ_valid_ = 0;
+        occ_keep_ = 1;
         POM_NOUNROLL
         for (int k = 0; k < n && L.bCnt > 0; k++) {
             const int c = k == 0 ? top : bomb_at(0); /* the first look needs no trip to the queue */
             if (pb_time(c) != 0) break;
             explode(pb_x(c), pb_y(c), pb_strength(c), REM_TOP, c);
         }
+        occ_valid_ = occ_keep_ = 0;
     }
     /* FillPositions / FillDestPos (step_utility.cpp:130-152), dead agents included, and the two questions that decide what
      * the tick has to do about them.  Positions travel as a byte per agent (x | y << 4), destinations as (x+1) | (y+1) << 4.
