@@ -17,7 +17,7 @@
 
 /* step 1 of the specification: 1 = rigid, 2 = wood, anything else = passage (ChooseItemOuter, bboard.cpp:59-74) */
 POM_HD uint32_t pom_board_cell_kind(uint32_t key, int c) { return pom_mulhi32(pom_board_draw(key, (uint32_t)c), 7u); }
-POM_HD int pom_board_cell_code(uint32_t kind) { return kind == 1u ? POM_RIGID : kind == 2u ? POM_WOOD : POM_PASSAGE; }
+POM_HD int pom_board_cell_code(uint32_t kind) { return kind == 1u ? POM_C_RIGID : kind == 2u ? POM_C_WOOD : POM_C_PASSAGE; } /* the cell's code (pom_packed.h) */
 
 /* step 2: which woods carry a flag.  Selection sampling in ascending cell order (exactly ceil(woods / 2) woods are chosen,
  * bboard.cpp:367-381): wood cell c, with `left` woods not yet visited (this one included), is chosen iff
@@ -28,7 +28,7 @@ POM_HD uint32_t pom_board_threshold(uint32_t key, int c, int left)
 {
     return pom_mulhi32(pom_board_draw(key, (uint32_t)(POM_BOARD_DRAW_SELECT + c)), (uint32_t)left);
 }
-POM_HD int pom_board_flag_code(uint32_t key, int c) { return POM_WOOD + 1 + (int)(pom_board_draw(key, (uint32_t)(POM_BOARD_DRAW_FLAG + c)) >> 30); }
+POM_HD int pom_board_flag_code(uint32_t key, int c) { return POM_C_WOOD + 1 + (int)(pom_board_draw(key, (uint32_t)(POM_BOARD_DRAW_FLAG + c)) >> 30); }
 /* the countdown done by one thread alone: w0 = wood cells 0..63, w1 = wood cells 64..120 (bit c - 64); put(c, code) rewrites a
  * chosen cell */
 template <class Put>

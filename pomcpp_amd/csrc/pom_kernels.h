@@ -25,19 +25,19 @@
 #include "pom_step_body.h"
 
 /* ---------------------------------------------------------------------------------------------
- * LDS tile of one wavefront, [row][EPW] dwords.  Rows 0..111 mirror the HBM record row for row (pom_packed.h), so the
- * whole record moves with unguarded groups of 64/EPW rows; then 5 rows of bomb-destination bytes and 21 rows of
- * explosion frames: 138 rows = 35.3 / 17.7 / 8.8 KB for 64 / 32 / 16 envs per wavefront.
+ * LDS tile of one wavefront, [row][EPW] dwords.  Rows 0..81 mirror the HBM record row for row (pom_packed.h), so the
+ * whole record moves in groups of 64/EPW rows; then 5 rows of bomb-destination bytes and 21 rows of
+ * explosion frames: 108 rows = 27.6 / 13.8 / 6.9 KB for 64 / 32 / 16 envs per wavefront.
  * ------------------------------------------------------------------------------------------- */
 enum {
-    ROW_BOARD = POM_REC_BOARD,    /* 61 rows: two 16-bit cells per dword            */
+    ROW_BOARD = POM_REC_BOARD,    /* 31 rows: four 8-bit cells per dword            */
     ROW_BOMBS = POM_REC_BOMBS,    /* 20 rows: raw bomb words, physical queue slots  */
     ROW_FLAMES = POM_REC_FLAMES,  /* 20 rows                                        */
     ROW_BDEST = POM_REC_DWORDS,   /*  5 rows: 20 bytes, bomb destination snapshot   */
     ROW_STACK = POM_REC_DWORDS + 5, /* 21 rows: explosion frames                    */
     LDS_ROWS = POM_REC_DWORDS + 26
 };
-static_assert(POM_REC_DWORDS % 4 == 0, "the record moves in groups of up to 4 rows");
+static_assert(POM_REC_DWORDS % 2 == 0, "the one-lane shapes move the record in groups of 1 or 2 rows");
 
 /*
  * EPW = envs per wavefront (64, 32 or 16), G = lanes that work on one env during the tick (pom_step_body.h):
@@ -86,8 +86,8 @@ struct LdsEnv {
     /* "the other lanes' LDS writes so far are visible from here on": true at every instruction of a wavefront in lock-step, so
      * nothing to do; the four-lane host model of tests/emul makes its lanes meet here */
     __device__ void sync() const {}
-    __device__ int cell(int c) const { return reinterpret_cast<const uint16_t*>(t)[(c >> 1) * (2 * EPW) + (c & 1)]; }
-    __device__ void put_cell(int c, int v) { reinterpret_cast<uint16_t*>(t)[(c >> 1) * (2 * EPW) + (c & 1)] = (uint16_t)v; }
+    __device__ int cell(int c) const { return reinterpret_cast<const uint8_t*>(t)[(c >> 2) * (4 * EPW) + (c & 3)]; }
+    __device__ void put_cell(int c, int v) { reinterpret_cast<uint8_t*>(t)[(c >> 2) * (4 * EPW) + (c & 3)] = (uint8_t)v; }
     __device__ int bomb(int s) const { return (int)t[(ROW_BOMBS + s) * EPW]; }
     __device__ void put_bomb(int s, int v) { t[(ROW_BOMBS + s) * EPW] = (uint32_t)v; }
     __device__ int flame(int s) const { return (int)t[(ROW_FLAMES + s) * EPW]; }
@@ -152,15 +152,15 @@ struct StepParams {
 template <int EPW, int ROWS>
 __device__ __forceinline__ void pom_boardgen_wave(uint32_t* col, uint32_t key, int lane)
 {
-    uint16_t* cells = reinterpret_cast<uint16_t*>(col);
+    uint8_t* cells = reinterpret_cast<uint8_t*>(col);
     const uint32_t k0 = pom_board_cell_kind(key, lane);
-    cells[(lane >> 1) * (2 * EPW) + (lane & 1)] = (uint16_t)pom_board_cell_code(k0);
+    cells[(lane >> 2) * (4 * EPW) + (lane & 3)] = (uint8_t)pom_board_cell_code(k0);
     const int c1 = lane + 64;
     uint32_t k1 = 0u;
     if (c1 < POM_CELLS) {
         k1 = pom_board_cell_kind(key, c1);
-        if (c1 == POM_CELLS - 1) col[(c1 >> 1) * EPW] = (uint32_t)pom_board_cell_code(k1); /* the last dword's unused half: 0, as pom_pack_state writes it */
-        else cells[(c1 >> 1) * (2 * EPW) + (c1 & 1)] = (uint16_t)pom_board_cell_code(k1);
+        if (c1 == POM_CELLS - 1) col[(c1 >> 2) * EPW] = (uint32_t)pom_board_cell_code(k1); /* the last dword's unused bytes: 0, as pom_pack_state writes them */
+        else cells[(c1 >> 2) * (4 * EPW) + (c1 & 3)] = (uint8_t)pom_board_cell_code(k1);
     }
     const uint64_t w0 = __ballot(k0 == 2u), w1 = __ballot(k1 == 2u);
     const int r = POM_REC_TIMESTEP + lane;
@@ -196,11 +196,11 @@ __device__ __forceinline__ void pom_boardgen_wave(uint32_t* col, uint32_t key, i
             }
         }
     }
-    if ((ch0 >> lane) & 1) cells[(lane >> 1) * (2 * EPW) + (lane & 1)] = (uint16_t)pom_board_flag_code(key, lane);
-    if ((ch1 >> lane) & 1) cells[(c1 >> 1) * (2 * EPW) + (c1 & 1)] = (uint16_t)pom_board_flag_code(key, c1);
+    if ((ch0 >> lane) & 1) cells[(lane >> 2) * (4 * EPW) + (lane & 3)] = (uint8_t)pom_board_flag_code(key, lane);
+    if ((ch1 >> lane) & 1) cells[(c1 >> 2) * (4 * EPW) + (c1 & 3)] = (uint8_t)pom_board_flag_code(key, c1);
     if (lane < POM_AGENT_COUNT) {
         const int c = pom_corner_cell(lane);
-        cells[(c >> 1) * (2 * EPW) + (c & 1)] = (uint16_t)(POM_C_AGENT | lane);
+        cells[(c >> 2) * (4 * EPW) + (c & 3)] = (uint8_t)(POM_C_AGENT + lane);
     }
 }
 
@@ -244,45 +244,56 @@ __device__ __forceinline__ void store_tile(uint32_t* col, int64_t np, const uint
 }
 /* EPW = 16: the same movement in 16-byte pieces (gfx950's global_load_lds_dwordx4 / dwordx4 stores).  A tile row is 16 envs
  * = 64 contiguous bytes in HBM and in LDS, so lane l takes envs 4(l%4)..+3 of row r0 + l/4 and one instruction covers 16 rows:
- * 7 instead of 28 per direction.  `base` = the tile's first dword, np = the row stride: with the buffers laid out tile by tile
- * (pom_packed.h) np = 16 and an instruction moves 1,024 contiguous bytes. */
+ * for the 82 rows of a record five whole instructions and one in which only the lanes of rows 80 and 81 take part (5 + 1 instead
+ * of 82 / 4 per direction).  `base` = the tile's first dword, np = the row stride: with the buffers laid out tile by tile
+ * (pom_packed.h) np = 16 and a whole instruction moves 1,024 contiguous bytes. */
 /* AUX: the instruction's cache policy bits (16 = sc1: served by the L2, never by this CU's vector cache) */
 template <int ROWS = POM_REC_DWORDS, int AUX = 0>
 __device__ __forceinline__ void load_tile16_x4(const uint32_t* base, int64_t np, uint32_t* tile, int lane)
 {
-    static_assert(ROWS % 16 == 0 && ROWS <= POM_REC_DWORDS, "whole instructions, inside the record");
+    static_assert(ROWS <= POM_REC_DWORDS, "inside the record");
     const uint32_t* g = base + (int64_t)(lane >> 2) * np + 4 * (lane & 3);
     const int64_t stride = 16 * np;
 #pragma unroll
-    for (int r0 = 0; r0 < ROWS; r0 += 16) {
+    for (int r0 = 0; r0 + 16 <= ROWS; r0 += 16) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(tile + r0 * 16), 16, 0, AUX);
         g += stride;
     }
+    if (ROWS % 16 != 0 && (lane >> 2) < ROWS % 16) /* the last rows: the lanes beyond them sit this one out */
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(tile + (ROWS / 16) * 16 * 16), 16, 0, AUX);
 }
 template <bool NT = false>
 __device__ __forceinline__ void store_tile16_x4(uint32_t* base, int64_t np, const uint32_t* tile, int lane)
 {
+    constexpr int ROWS = POM_REC_DWORDS;
     uint4* g = reinterpret_cast<uint4*>(base + (int64_t)(lane >> 2) * np + 4 * (lane & 3));
     const int64_t stride = 4 * np; /* in uint4 */
     const uint4* l = reinterpret_cast<const uint4*>(tile) + lane;
+    typedef uint32_t pom_u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int r0 = 0; r0 < POM_REC_DWORDS; r0 += 16) {
+    for (int r0 = 0; r0 + 16 <= ROWS; r0 += 16) {
         if (NT) {
-            typedef uint32_t pom_u32x4 __attribute__((ext_vector_type(4)));
             const uint4 v = l[r0 * 4];
             __builtin_nontemporal_store(pom_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<pom_u32x4*>(g));
         } else *g = l[r0 * 4];
         g += stride;
     }
+    if (ROWS % 16 != 0 && (lane >> 2) < ROWS % 16) {
+        if (NT) {
+            const uint4 v = l[(ROWS / 16) * 16 * 4];
+            __builtin_nontemporal_store(pom_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<pom_u32x4*>(g));
+        } else *g = l[(ROWS / 16) * 16 * 4];
+    }
 }
 /*
- * The restart snapshot is kept array-of-structs: env e's record is the 448 contiguous bytes snap[e * 112 .. e * 112 + 111].
- * A restart needs ONE env's whole record, and in the column layout of the state buffer that is 112 dwords in 112
+ * The restart snapshot is kept array-of-structs: env e's record is the 328 contiguous bytes snap[e * 82 .. e * 82 + 81].
+ * A restart needs ONE env's whole record, and in the column layout of the state buffer that is 82 dwords in 82
  * different 64-byte sectors (4 useful bytes each: 18 MB of HBM fetch per step at 65,536 envs for the 3.8 % of envs that
  * restart, a fifth of the kernel's whole traffic; profiles/r02a_head1_summary.txt).  Here the whole wavefront fetches the
- * record of one restarting env — lane l takes dwords l and l + 64, seven fully used sectors — and writes it into that env's
- * tile column.  `src` = &snap[e * 112]; ROWS = how many leading rows the caller needs.
+ * record of one restarting env — lane l takes dwords l and l + 64, whole sectors — and writes it into that env's
+ * tile column.  `src` = &snap[e * POM_REC_DWORDS]; ROWS = how many leading rows the caller needs.
  */
 template <int EPW, int ROWS = POM_REC_DWORDS>
 __device__ __forceinline__ void restart_column(uint32_t* col, const uint32_t* src, int lane)
@@ -321,7 +332,7 @@ struct PolicyStore {
     __device__ uint32_t setw(int k) const { return scol[k * 16]; }
     __device__ void set_put(int k, uint32_t bits) { scol[k * 16] = bits; }
     __device__ uint32_t board_word(int k) const { return t[k * 16]; }
-    __device__ int cell(int c) const { return reinterpret_cast<const uint16_t*>(t)[(c >> 1) * 32 + (c & 1)]; }
+    __device__ int cell(int c) const { return reinterpret_cast<const uint8_t*>(t)[(c >> 2) * 64 + (c & 3)]; }
     __device__ int bomb(int s) const { return (int)t[(POM_REC_BOMBS + s) * 16]; }
 };
 
@@ -683,41 +694,41 @@ __device__ __forceinline__ void pom_observe_stage(const uint32_t* tile, uint4* s
         }
     }
     obs_lds_order();
-    /* cells: a byte each into the plane its code names (or its code into the board plane); flame cells look their flame up.  A lane
-     * takes a dword of the board — two cells — of one env per round: lane -> (env of the pass, board row of the tile), so that every
+    /* cells: a byte each into the plane its code names (or its Item number into the board plane); flame cells look their flame up.  A lane
+     * takes half a dword of the board — two cells — of one env per round: lane -> (env of the pass, unit of two cells), so that every
      * address is a base plus a constant */
     {
-        constexpr int LPE = 64 / E, ROW_IT = (61 + LPE - 1) / LPE; /* lanes per env; rounds over the 61 board rows */
+        constexpr int UNITS = (POM_CELLS + 1) / 2; /* 61 */
+        constexpr int LPE = 64 / E, ROW_IT = (UNITS + LPE - 1) / LPE; /* lanes per env; rounds over the 61 two-cell units */
         const int ei = E == 1 ? 0 : lane & (E - 1), j = E == 1 ? lane : lane / E, ec = q * E + ei;
         const int fIdx = (int)(tile[POM_REC_META * 16 + ec] >> 24);
-        auto put = [&](int code, int c, int ok) { /* the cell's byte; returns whether the cell is a flame with a centre on the board */
-            /* What the cell's code sets.  The 16 planes: passage 0, rigid 1, wood (any flag) 2, Item::BOMB 3, flames 4, the three power-ups
-             * (codes 6, 7, 8) 5, 6, 7, agent i 8 + i, anything else (fog, ...) none.  POM_OBS_CODES: the small numbers of the reference's
-             * Item enum (bboard.hpp:54-71; the Python Pommerman board uses the same ones) — 0 passage, 1 rigid, 2 wood, 3 bomb, 4 flames,
-             * 5 fog, 6 extra-bomb, 7 incr-range, 8 kick, 9 agent dummy, 10 + i agent i; 255 for anything else.
-             * Codes below 16 by table, a nibble per code (15 = none); wood, flames and agents by their bits. */
-            const int nib = (int)(((CODES ? 0xFFFFFF98765F3F10ull : 0xFFFFFFF765FF3F10ull) >> (4 * (code & 15))) & 15u);
-            int v = code < 16 ? nib : 15; /* CODES: the cell's number; else: its plane */
-            v = pc_is_wood(code) ? 2 : v;
-            v = pc_is_flame(code) ? 4 : v;
-            v = pc_is_agent(code) ? (CODES ? 10 : 8) + (code & 3) : v;
-            if (CODES) stage_b[ok ? ei * EB + c : dump] = (uint8_t)(v == 15 ? 255 : v);
-            else stage_b[(ok & (int)(v != 15)) ? ei * EB + v * POM_CELLS + c : dump] = 1;
-            return ok & pc_is_flame(code) & (int)((code & 0x3FFF) >> 3 < POM_CELLS); /* FLAME_ID: the cell the flame was spawned at */
+        auto put = [&](int code, int c, int ok) { /* the cell's byte; returns whether the cell is a flame */
+            /* What the cell's code (pom_packed.h: 0 passage, 1 rigid, 2 bomb, 3..5 power-ups, 6..10 wood, 11..14 agents, 15.. flames) sets.
+             * The 16 planes: passage 0, rigid 1, wood (any flag) 2, Item::BOMB 3, flames 4, the three power-ups 5, 6, 7, agent i 8 + i.
+             * POM_OBS_CODES: the small numbers of the reference's Item enum (bboard.hpp:54-71; the Python Pommerman board uses the same
+             * ones) — 0 passage, 1 rigid, 2 wood, 3 bomb, 4 flames, 6 extra-bomb, 7 incr-range, 8 kick, 10 + i agent i.  One table, a
+             * nibble per code, every flame code reading entry 15. */
+            const int k = code < 15 ? code : 15;
+            const int v = (int)(((CODES ? 0x4DCBA22222876310ull : 0x4BA9822222765310ull) >> (4 * k)) & 15u);
+            if (CODES) stage_b[ok ? ei * EB + c : dump] = (uint8_t)v;
+            else stage_b[ok ? ei * EB + v * POM_CELLS + c : dump] = 1;
+            return ok & pc_is_flame(code);
         };
         auto life = [&](int code, int c, int is_flame) { /* unconditional: a cell that is no flame looks at its own (zero) byte */
-            const int key = stage_b[is_flame ? ei * EB + P_DIR * POM_CELLS + ((code & 0x3FFF) >> 3) : ei * EB + P_FLAME * POM_CELLS + c];
+            int origin = code - POM_C_FLAME; /* FLAME_ID: the cell the flame was spawned at */
+            if (code >= POM_C_FLAGGED) origin = pom_flame_origin(code, c); /* (a burnt wood with a power-up under it: rare) */
+            const int key = stage_b[is_flame ? ei * EB + P_DIR * POM_CELLS + origin : ei * EB + P_FLAME * POM_CELLS + c];
             const int tl = pom_sext8(tile[(POM_REC_FLAMES + wrap20(fIdx + (key ? key - 1 : 0))) * 16 + ec] >> 16);
             stage_b[is_flame ? ei * EB + P_FLAME * POM_CELLS + c : dump] = (uint8_t)((int)(key != 0) & (int)(tl > 0) ? tl : 0);
         };
 #pragma unroll
         for (int i = 0; i < ROW_IT; i++) {
             const int r = j + LPE * i;
-            const int ok = (LPE * i + LPE - 1 < 61) | (int)(r < 61); /* (a lane past the board reads some other row of the tile) */
-            const uint32_t w = tile[(POM_REC_BOARD + r) * 16 + ec];
-            const int lo = (int)(w & 0xFFFF), hi = (int)(w >> 16);
+            const int ok = (LPE * i + LPE - 1 < UNITS) | (int)(r < UNITS); /* (a lane past the board reads some other row of the tile) */
+            const uint32_t w = tile[(POM_REC_BOARD + (r >> 1)) * 16 + ec] >> (16 * (r & 1));
+            const int lo = (int)(w & 0xFF), hi = (int)((w >> 8) & 0xFF);
             const int f0 = put(lo, 2 * r, ok);
-            const int f1 = put(hi, 2 * r + 1, ok & (int)(r < 60)); /* the board's last dword holds one cell */
+            const int f1 = put(hi, 2 * r + 1, ok & (int)(r < UNITS - 1)); /* the board's last unit holds one cell */
             if (f0 | f1) {
                 life(lo, 2 * r, f0);
                 life(hi, 2 * r + 1, f1);
@@ -1355,7 +1366,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
 
 /* The hand-off by itself (pom_chain_litmus, tests): the same tile choice, ticket, wait, sc1 DMA load, non-temporal store and
  * publication as the CHAIN step kernels, with a "tick" whose result gives every stale or torn read away — visit v of a tile must
- * find ALL 1,792 dwords of the record equal to v (the j-th dword XOR-tagged with its index, so that a record of another tile or a
+ * find ALL 1,312 dwords of the record equal to v (the j-th dword XOR-tagged with its index, so that a record of another tile or a
  * shifted piece cannot pass either) and leaves them at v + 1.  out[0]: records that were not what the visit before left (counted
  * per wavefront), out[1]: dwords that differed, out[2]: visits played. */
 struct LitmusParams {
@@ -1432,14 +1443,15 @@ __global__ void pom_chain_verify_kernel(const unsigned long long* tile_seq, int6
 
 /* ---------------------------------------------------------------------------------------------
  * SimpleAgent policy (pom_policy_body.h): one lane per AGENT, the quad 4e..4e+3 = the four agents of env e,
- * 16 envs per wavefront.  The wavefront DMAs record rows 0..91 (board, meta, agents, bombs) of its 16 envs into a shared
+ * 16 envs per wavefront.  The wavefront DMAs record rows 0..63 (board, meta, agents, bombs: 0..61) of its 16 envs into a shared
  * tile; per env the four lanes together prepare a danger map ([128][16] bytes) and three cell sets.  The reachability
  * questions are flood fills on 121-bit cell sets in registers, so a wavefront needs only 9 KB of LDS (17 wavefronts per CU).  Output:
  * Move[4] per env into the handle's move buffer, agent memory (2 dwords per agent) updated in place.  A finished env that the
  * next step will restart is read from its snapshot column — or, with fresh boards, drawn here exactly as the tick will draw
  * it — and gets fresh (zero) agent memory, so policy and tick see the same game.
  * ------------------------------------------------------------------------------------------- */
-enum { POL_ROWS = 92, POL_LOAD_ROWS = 96 }; /* the policy reads rows 0..91; they arrive 16 rows per instruction */
+enum { POL_ROWS = POM_REC_FLAMES, POL_LOAD_ROWS = 64 }; /* the policy reads rows 0..61 (board, meta, agents, bombs); they arrive 16 rows per instruction */
+static_assert(POL_ROWS <= POL_LOAD_ROWS && POL_LOAD_ROWS <= POM_REC_DWORDS, "policy rows");
 
 
 struct PolicyParams {
@@ -1678,11 +1690,12 @@ __global__ __launch_bounds__(64) void pom_step_one_kernel(StepOneParams q)
     /* pack into column 0: exactly pom_pack_state + the live-bomb test of pom_pack_kernel, a record dword per lane */
     const int32_t* st = aos;
     int bad = 0;
-    if (lane < 61) {
-        const int lo = pom_cell_encode(st[2 * lane]);
-        const int hi = 2 * lane + 1 < POM_CELLS ? pom_cell_encode(st[2 * lane + 1]) : 0;
-        bad |= (lo < 0) | (hi < 0);
-        tile[(POM_REC_BOARD + lane) * 16] = (uint32_t)(lo & 0xFFFF) | ((uint32_t)(hi & 0xFFFF) << 16);
+    {
+        const int c = lane + 64, e0 = pom_cell_encode(st[lane], lane), e1 = c < POM_CELLS ? pom_cell_encode(st[c], c) : 0;
+        bad |= (e0 < 0) | (e1 < 0);
+        uint8_t* cells = reinterpret_cast<uint8_t*>(tile);
+        cells[(lane >> 2) * 64 + (lane & 3)] = (uint8_t)e0; /* (the tile was zeroed: the three bytes past cell 120 stay 0) */
+        if (c < POM_CELLS) cells[(c >> 2) * 64 + (c & 3)] = (uint8_t)e1;
     }
     const int32_t alive = st[122], bIdx = st[167], bCnt = st[168], fIdx = st[249], fCnt = st[250];
     if (lane == 61) {
@@ -1770,11 +1783,8 @@ __global__ __launch_bounds__(64) void pom_step_one_kernel(StepOneParams q)
     /* unpack column 0 (pom_unpack_state, a few State dwords per lane) straight into host memory */
     int32_t* out = p.io + POM_ONE_OUT;
     const uint32_t m = tile[POM_REC_META * 16], m2 = tile[POM_REC_META2 * 16];
-    if (lane < 61) {
-        const uint32_t w = tile[(POM_REC_BOARD + lane) * 16];
-        out[2 * lane] = pom_cell_decode((int)(w & 0xFFFF));
-        if (2 * lane + 1 < POM_CELLS) out[2 * lane + 1] = pom_cell_decode((int)(w >> 16));
-    }
+    out[lane] = pom_cell_decode(pom_rec_cell(tile, 16, lane), lane);
+    if (lane + 64 < POM_CELLS) out[lane + 64] = pom_cell_decode(pom_rec_cell(tile, 16, lane + 64), lane + 64);
     if (lane == 61) {
         out[121] = (int32_t)tile[POM_REC_TIMESTEP * 16];
         out[122] = pom_sext8(m);

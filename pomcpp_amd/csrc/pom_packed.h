@@ -4,29 +4,36 @@
  * i.e. bboard::State, /root/reference/include/bboard.hpp:356-506).
  *
  * HBM layout: an array of 16-env TILES, struct-of-arrays inside a tile — dword d of env e lives at
- * buf[(e / 16) * 1792 + d * 16 + (e % 16)] (pom_rec_col, row stride POM_TILE_ENVS).  A tile is 7,168
- * contiguous bytes: the wavefront that owns it moves it with seven 1-KB instructions (16 bytes per lane),
- * every cache line full in both directions, and touches ONE region of memory instead of 112 rows that
+ * buf[(e / 16) * 1312 + d * 16 + (e % 16)] (pom_rec_col, row stride POM_TILE_ENVS).  A tile is 5,248
+ * contiguous bytes (41 lines of 128 B): the wavefront that owns it moves it with five 1-KB instructions (16 bytes per lane)
+ * and one of 128 bytes, every cache line full in both directions, and touches ONE region of memory instead of 82 rows that
  * lie n_pad * 4 bytes apart (rounds 1-2: 4.35 G env-steps/s at 524,288 envs against 6.5 G at 262,144 —
  * beyond the memory-side cache the strided rows cost DRAM and TLB locality).
  *
- * POM_REC_DWORDS = 112 dwords (448 B) per env instead of 251:
- *   [0..60]    board, 121 cells of 16 bits (cell c in dword c>>1, half c&1)
- *   [61]       timeStep
- *   [62]       aliveAgents:8 | bombs.index:8 | bombs.count:8 | flames.index:8
- *   [63]       flames.count:8 | status:8 | ubflags:16
- *   [64..71]   agents: A0[i] = x:8 | y:8 | bombCount:8 (signed) | canKick@24 | dead@25
+ * POM_REC_DWORDS = 82 dwords (328 B) per env instead of 251 (rounds 1-4: 112, with 16-bit cells):
+ *   [0..30]    board, 121 cells of 8 bits (cell c in byte c&3 of dword c>>2; the last three bytes 0)
+ *   [31]       timeStep
+ *   [32]       aliveAgents:8 | bombs.index:8 | bombs.count:8 | flames.index:8
+ *   [33]       flames.count:8 | status:8 | ubflags:16
+ *   [34..41]   agents: A0[i] = x:8 | y:8 | bombCount:8 (signed) | canKick@24 | dead@25
  *                      A1[i] = maxBombCount:16 | bombStrength:16
- *   [72..91]   bombs.queue raw (all 20 slots: stale slots are state)
- *   [92..111]  flames.queue: x:8 | y:8 | timeLeft:8 (signed) | strength:8
+ *   [42..61]   bombs.queue raw (all 20 slots: stale slots are state)
+ *   [62..81]   flames.queue: x:8 | y:8 | timeLeft:8 (signed) | strength:8
  *
- * Cell code (16 bit) for board value v (Item, bboard.hpp:54-71):
- *   v < 0x4000                       -> v            (passage, rigid, bomb, fog, powerups, wood+flag)
- *   FLAMES <= v < FLAMES + 0x4000    -> 0x4000 | (v - FLAMES)
- *   AGENT0 <= v < AGENT0 + 4         -> 0x8000 | (v - AGENT0)
- * Every value the reference can produce from a valid start is representable;
- * anything else is rejected at upload (POM_E_UNREPRESENTABLE) instead of being
- * silently altered.
+ * Cell code (8 bit) for board value v (Item, bboard.hpp:54-71) — every value a game can reach from a valid start has one, and
+ * the 256 codes are exactly used up:
+ *   0 passage  1 rigid  2 Item::BOMB  3 / 4 / 5 extra-bomb / incr-range / kick  6..10 wood with flag 0..4  11..14 agent 0..3
+ *   15 + id             a flame with FLAME_ID id = origin cell (0..120) and no power-up under it
+ *   136 + 40 (f - 1) + 10 r + (d - 1)
+ *                       a flame with power-up flag f = 1..3: the origin is NOT stored as a number but as where it lies from the
+ *                       cell — d = 1..10 cells back along ray r (0: the cell is at +x of the origin, 1: -x, 2: +y, 3: -y).  A flagged
+ *                       flame cell is a burnt wood, wood ends the ray that burns it, and SpawnFlame's rays run along the origin's
+ *                       row and column (bboard.cpp:24-57, 198-263): in a reachable state the origin of such a cell always lies on
+ *                       its row or column, at most 10 cells away.
+ * So a cell is self-contained (no reference into the flame queue, whose slots are overwritten when it overflows), PopFlame's
+ * "is this my flame" (bboard.cpp:148-180) is a compare on the code, and the record's board is 124 bytes instead of 244.
+ * Values outside this set — fog, hand-written flame cells whose origin is not on their row / column, wood flags above 4, ... —
+ * are rejected at upload (POM_E_UNREPRESENTABLE), never silently altered.
  */
 #ifndef POM_PACKED_H_
 #define POM_PACKED_H_
@@ -38,15 +45,16 @@
 
 enum {
     POM_REC_BOARD = 0,
-    POM_REC_TIMESTEP = 61,
-    POM_REC_META = 62,
-    POM_REC_META2 = 63,
-    POM_REC_AGENTS = 64,
-    POM_REC_BOMBS = 72,
-    POM_REC_FLAMES = 92,
-    POM_REC_DWORDS = 112,
+    POM_REC_BOARD_DWORDS = 31,
+    POM_REC_TIMESTEP = 31,
+    POM_REC_META = 32,
+    POM_REC_META2 = 33,
+    POM_REC_AGENTS = 34,
+    POM_REC_BOMBS = 42,
+    POM_REC_FLAMES = 62,
+    POM_REC_DWORDS = 82,
     POM_TILE_ENVS = 16,                              /* envs per tile of the device buffers = row stride of a column, in dwords */
-    POM_TILE_DWORDS = POM_REC_DWORDS * POM_TILE_ENVS /* 1792 */
+    POM_TILE_DWORDS = POM_REC_DWORDS * POM_TILE_ENVS /* 1312 */
 };
 
 /* status byte of META2 */
@@ -59,25 +67,59 @@ enum {
                              put it on its next start state; the finished episode's record is in the terminal buffer */
 };
 
-enum { POM_C_PASSAGE = 0, POM_C_RIGID = 1, POM_C_BOMB = 3, POM_C_FLAME = 0x4000, POM_C_AGENT = 0x8000 };
+enum {
+    POM_C_PASSAGE = 0, POM_C_RIGID = 1, POM_C_BOMB = 2, POM_C_EXTRABOMB = 3, POM_C_INCRRANGE = 4, POM_C_KICK = 5,
+    POM_C_WOOD = 6,    /* + flag 0..4 */
+    POM_C_AGENT = 11,  /* + id */
+    POM_C_FLAME = 15,  /* + origin cell */
+    POM_C_FLAGGED = 136 /* + 40 (flag - 1) + 10 ray + (distance - 1) */
+};
 
 /* where env e's column starts in a device buffer (dword units); its dword d is at pom_rec_col(e) + d * POM_TILE_ENVS */
 POM_HD int64_t pom_rec_col(int64_t e) { return (e >> 4) * POM_TILE_DWORDS + (e & 15); }
 
-POM_HD int pom_cell_encode(int32_t v) /* -1 if not representable */
+/* the code of a flame cell with power-up flag f (1..3) that lies d (1..10) cells along ray r (0 +x, 1 -x, 2 +y, 3 -y) from its origin */
+POM_HD int pom_flagged_code(int f, int r, int d) { return POM_C_FLAGGED + 40 * (f - 1) + 10 * r + (d - 1); }
+
+POM_HD int pom_cell_encode(int32_t v, int c /* the cell: y * 11 + x */) /* -1 if not representable */
 {
-    if (v >= 0 && v < 0x4000) return v;
-    if (v >= POM_FLAMES && v < POM_FLAMES + 0x4000) return POM_C_FLAME | (v - POM_FLAMES);
-    if (v >= POM_AGENT0 && v < POM_AGENT0 + POM_AGENT_COUNT) return POM_C_AGENT | (v - POM_AGENT0);
+    if (v == POM_PASSAGE) return POM_C_PASSAGE;
+    if (v == POM_RIGID) return POM_C_RIGID;
+    if (v == POM_BOMB) return POM_C_BOMB;
+    if (v >= POM_EXTRABOMB && v <= POM_KICK) return POM_C_EXTRABOMB + (v - POM_EXTRABOMB);
+    if (v >= POM_WOOD && v <= POM_WOOD + 4) return POM_C_WOOD + (v - POM_WOOD);
+    if (v >= POM_AGENT0 && v < POM_AGENT0 + POM_AGENT_COUNT) return POM_C_AGENT + (v - POM_AGENT0);
+    if (v >= POM_FLAMES && v < POM_FLAMES + (POM_CELLS << 3)) {
+        const int id = (v - POM_FLAMES) >> 3, f = (v - POM_FLAMES) & 7;
+        if (f == 0) return POM_C_FLAME + id;
+        if (f > 3) return -1;
+        const int cy = c / POM_BOARD_SIZE, cx = c - cy * POM_BOARD_SIZE, oy = id / POM_BOARD_SIZE, ox = id - oy * POM_BOARD_SIZE;
+        if (oy == cy && ox != cx) return pom_flagged_code(f, cx > ox ? 0 : 1, cx > ox ? cx - ox : ox - cx);
+        if (ox == cx && oy != cy) return pom_flagged_code(f, cy > oy ? 2 : 3, cy > oy ? cy - oy : oy - cy);
+    }
     return -1;
 }
 
-POM_HD int32_t pom_cell_decode(int e)
+POM_HD int32_t pom_cell_decode(int e, int c)
 {
-    if (e < 0x4000) return e;
-    if (e < 0x8000) return POM_FLAMES + (e & 0x3FFF);
-    return POM_AGENT0 + (e & 0x3FFF);
+    if (e < POM_C_WOOD) return e <= POM_C_RIGID ? e : e == POM_C_BOMB ? POM_BOMB : POM_EXTRABOMB + (e - POM_C_EXTRABOMB);
+    if (e < POM_C_AGENT) return POM_WOOD + (e - POM_C_WOOD);
+    if (e < POM_C_FLAME) return POM_AGENT0 + (e - POM_C_AGENT);
+    if (e < POM_C_FLAGGED) return POM_FLAMES + ((e - POM_C_FLAME) << 3);
+    const int k = e - POM_C_FLAGGED, f = k / 40 + 1, r = (k % 40) / 10, d = k % 10 + 1;
+    const int origin = c - d * (r == 0 ? 1 : r == 1 ? -1 : r == 2 ? POM_BOARD_SIZE : -POM_BOARD_SIZE);
+    return POM_FLAMES + (origin << 3) + f;
 }
+/* FLAME_ID (bboard.hpp:98-101) of a flame code at cell c */
+POM_HD int pom_flame_origin(int e, int c)
+{
+    if (e < POM_C_FLAGGED) return e - POM_C_FLAME;
+    const int k = (e - POM_C_FLAGGED) % 40, r = k / 10, d = k % 10 + 1;
+    return c - d * (r == 0 ? 1 : r == 1 ? -1 : r == 2 ? POM_BOARD_SIZE : -POM_BOARD_SIZE);
+}
+
+/* cell c of a record addressed with a stride (a column of a device tile: POM_TILE_ENVS; a dense record: 1) */
+POM_HD int pom_rec_cell(const uint32_t* rec, int64_t stride, int c) { return (int)((rec[(POM_REC_BOARD + (c >> 2)) * stride] >> (8 * (c & 3))) & 0xFFu); }
 
 /*
  * Pack one boundary State into a record.  `rec` is addressed with a stride so
@@ -95,11 +137,14 @@ POM_HD int pom_pack_state(const int32_t* st, uint32_t* rec, int64_t stride)
     const int32_t* flames = st + 169;          /* @676  */
     int bad = 0;
 
-    for (int k = 0; k < 61; k++) {
-        int lo = pom_cell_encode(board[2 * k]);
-        int hi = (2 * k + 1 < POM_CELLS) ? pom_cell_encode(board[2 * k + 1]) : 0;
-        bad |= (lo < 0) | (hi < 0);
-        rec[(POM_REC_BOARD + k) * stride] = (uint32_t)(lo & 0xFFFF) | ((uint32_t)(hi & 0xFFFF) << 16);
+    for (int k = 0; k < POM_REC_BOARD_DWORDS; k++) {
+        uint32_t w = 0;
+        for (int j = 0; j < 4 && 4 * k + j < POM_CELLS; j++) {
+            const int e = pom_cell_encode(board[4 * k + j], 4 * k + j);
+            bad |= e < 0;
+            w |= (uint32_t)(e & 0xFF) << (8 * j);
+        }
+        rec[(POM_REC_BOARD + k) * stride] = w;
     }
     rec[POM_REC_TIMESTEP * stride] = (uint32_t)timeStep;
 
@@ -139,11 +184,7 @@ POM_HD int32_t pom_sext16(uint32_t v) { return (int32_t)(int16_t)(v & 0xFFFF); }
 /* inverse of pom_pack_state; the two padding bytes of each agent come out 0 */
 POM_HD void pom_unpack_state(const uint32_t* rec, int64_t stride, int32_t* st)
 {
-    for (int k = 0; k < 61; k++) {
-        uint32_t w = rec[(POM_REC_BOARD + k) * stride];
-        st[2 * k] = pom_cell_decode((int)(w & 0xFFFF));
-        if (2 * k + 1 < POM_CELLS) st[2 * k + 1] = pom_cell_decode((int)(w >> 16));
-    }
+    for (int c = 0; c < POM_CELLS; c++) st[c] = pom_cell_decode(pom_rec_cell(rec, stride, c), c);
     st[121] = (int32_t)rec[POM_REC_TIMESTEP * stride];
     const uint32_t m = rec[POM_REC_META * stride], m2 = rec[POM_REC_META2 * stride];
     st[122] = pom_sext8(m);

@@ -31,9 +31,9 @@
  * it, a byte per cell — and three 121-bit cell sets, "walkable", "agent" and "safe", one 32-cell word per lane, which the floods and
  * the safe-place scan work on in registers instead of reading cells.
  *
- * Store interface P:  int cell(int c)            16-bit board code (pom_packed.h), c = y*11+x
+ * Store interface P:  int cell(int c)            8-bit board code (pom_packed.h), c = y*11+x
  *                     int bomb(int slot)         raw bomb word of physical slot
- *                     uint32_t board_word(int k) board dword k = cells 2k (low half) and 2k+1; k up to 63 must be readable
+ *                     uint32_t board_word(int k) board dword k = cells 4k .. 4k+3, a byte each; k up to 31 must be readable
  *                     int danger(int c) / void danger_init(int c) / void danger_put(int c, int t)     per-env danger map, 128
  *                                                entries of at least 8 bits (c up to 127 must be readable)
  *                     uint32_t setw(int k) / void set_put(int k, uint32_t bits)   per-env cell sets, words
@@ -72,8 +72,29 @@ extern "C" int pom_stat_fwd, pom_stat_bwd;
 #define POM_COUNT_LEVEL(v) ((void)0)
 #endif
 
+/* Four cell codes in a dword (pom_packed.h) -> 0x01 in the bytes of the walkable cells (passage 0, power-ups 3..5) and of the agent
+ * cells (11..14).  Range tests on all four bytes at once: with the top bit of every byte cleared, adding 128 - k sets it again iff
+ * the byte's low seven bits are >= k (no carry leaves a byte); codes >= 128 are flames. */
+POM_HD void pom_cells_walk_agent(uint32_t d, uint32_t& walk, uint32_t& agent)
+{
+    const uint32_t l = d & 0x7F7F7F7Fu;
+    const uint32_t ge1 = l + 0x7F7F7F7Fu, ge3 = l + 0x7D7D7D7Du, ge6 = l + 0x7A7A7A7Au, ge11 = l + 0x75757575u, ge15 = l + 0x71717171u;
+    walk = ((((ge3 & ~ge6) | ~ge1) & ~d) >> 7) & 0x01010101u;
+    agent = ((ge11 & ~ge15 & ~d) >> 7) & 0x01010101u;
+}
+/* the four 0 / 1 bytes of f as four bits — bits 0..3 (hi = 0) or 4..7 (hi = 1) — added to acc: one v_dot4_u32_u8 on the device */
+POM_HD uint32_t pom_gather_flags(uint32_t f, uint32_t acc, int hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(f, hi ? 0x80402010u : 0x08040201u, acc, false);
+#else
+    const uint32_t n = (f & 1u) | ((f >> 7) & 2u) | ((f >> 14) & 4u) | ((f >> 21) & 8u);
+    return acc + (hi ? n << 4 : n);
+#endif
+}
+
 /* Shared preparation, executed by all four lanes of an env.  The 121-bit sets are four words and the env has four lanes:
- * member m builds word m of every set (cells 32m .. 32m+31) with plain stores, from whole board dwords (two cells each).  The
+ * member m builds word m of every set (cells 32m .. 32m+31) with plain stores, from whole board dwords (four cells each).  The
  * danger map is cleared and rasterised by bombs m, m+4, ...  Three phases — every lane must have finished one before any lane
  * starts the next (on the device the wavefront runs them back to back in lock-step; a sequential host emulation runs each
  * phase for all four members in turn). */
@@ -91,17 +112,18 @@ template <class P>
 POM_HD void pom_policy_prepare_fill(P& p, const PomPolicyEnv& E)
 {
     const int m = p.member();
-    /* walkable (IS_WALKABLE, bboard.hpp:81-84: passage or a power-up) -> word m, agent cells (item >= AGENT0) -> word 4+m */
+    /* walkable (IS_WALKABLE, bboard.hpp:81-84: passage or a power-up) -> word m, agent cells (item >= AGENT0) -> word 4+m: eight
+     * board dwords of four cell codes each, classified four at a time (pom_cells_walk_agent) */
     uint32_t w = 0, g = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const uint32_t d = p.board_word(16 * m + i); /* cells 32m+2i (low half) and 32m+2i+1; m = 3 runs past the board ... */
-        const uint32_t lo = d & 0xFFFFu, hi = d >> 16;
-        const uint32_t wl = (lo == 0u) | ((lo - 6u) < 3u), wh = (hi == 0u) | ((hi - 6u) < 3u);
-        w |= (wl << (2 * i)) | (wh << (2 * i + 1));
-        g |= ((lo >> 15) << (2 * i)) | ((hi >> 15) << (2 * i + 1));
+    for (int i = 0; i < 8; i += 2) {
+        uint32_t w0, g0, w1, g1;
+        pom_cells_walk_agent(p.board_word(8 * m + i), w0, g0); /* cells 32m + 4i .. + 3; m = 3 runs past the board ... */
+        pom_cells_walk_agent(p.board_word(8 * m + i + 1), w1, g1);
+        w |= pom_gather_flags(w1, pom_gather_flags(w0, 0u, 0), 1) << (4 * i);
+        g |= pom_gather_flags(g1, pom_gather_flags(g0, 0u, 0), 1) << (4 * i);
     }
-    const uint32_t keep = m == 3 ? 0x01FFFFFFu : ~0u; /* ... into dwords that are not cells: 121 = 96 + 25 */
+    const uint32_t keep = m == 3 ? 0x01FFFFFFu : ~0u; /* ... into bytes that are not cells: 121 = 96 + 25 */
     p.set_put(m, w & keep);
     p.set_put(4 + m, g & keep);
     /* IsInDanger for every cell at once: min BMB_TIME over the bombs whose cross (IsInBombRange, strategy.hpp:163-169: the

@@ -19,7 +19,7 @@
  *   - the recursive chain explosion (bboard.cpp:24-57,111-118,198-263) is an explicit
  *     frame stack in LDS (<= 21 frames), the tail-recursive bounce-back chain
  *     (step_utility.cpp:62-128) a bounded loop;
- *   - board cells are the 16-bit codes of pom_packed.h, bombs the reference's raw
+ *   - board cells are the 8-bit codes of pom_packed.h, bombs the reference's raw
  *     bit-packed ints, flames one dword each.
  *
  * G lanes per env.  The store says how many lanes of the wavefront work on one env (A::G): 1 in the
@@ -36,7 +36,7 @@
  *   void sync()   where split code goes on to READ what other lanes of the group have just written (free on the device: a
  *                 wavefront runs in lock-step; the four-lane host model of tests/emul needs to be told)
  *   set_x(...)  write by the owner lane only (replicated code)   put_x(...)  write by the calling lane (split code)
- *   int  cell(int c) / void set_cell(int c, int code)      c = y*11+x, 16-bit codes
+ *   int  cell(int c) / void set_cell(int c, int code)      c = y*11+x, 8-bit codes
  *   int  bomb(int slot) / void set_bomb(int slot, int v)    physical queue slot 0..19
  *   int  flame(int slot) / void set_flame(int slot, int v)  packed x|y<<8|time<<16|strength<<24
  *   int  bdest(int i) / void set_bdest(int i, int v)        byte: snapshot of bomb destinations
@@ -97,16 +97,32 @@ struct PomLane { /* the register-resident part of one env */
 #endif
 };
 
-/* ---- cell-code predicates (Item helpers, bboard.hpp:73-109, on 16-bit codes) */
+/* ---- cell-code predicates (Item helpers, bboard.hpp:73-109, on the 8-bit codes of pom_packed.h: 0 passage, 1 rigid, 2 bomb,
+ * 3..5 power-ups, 6..10 wood, 11..14 agents, 15.. flames — every class a range) */
 /* (bitwise | and one unsigned range compare, not || and &&: on lane-varying values hipcc turns the short-circuit forms into
  * nested exec-mask branches) */
-POM_HD int pc_is_wood(int e) { return (e >> 8) == 2; }
-POM_HD int pc_is_powerup(int e) { return (unsigned)(e - 6) < 3u; }
+POM_HD int pc_is_wood(int e) { return (unsigned)(e - POM_C_WOOD) < 5u; }
+POM_HD int pc_is_powerup(int e) { return (unsigned)(e - POM_C_EXTRABOMB) < 3u; }
 POM_HD int pc_is_walkable(int e) { return (int)pc_is_powerup(e) | (int)(e == 0); }
-POM_HD int pc_is_flame(int e) { return (e & 0xC000) == POM_C_FLAME; }
-POM_HD int pc_is_agent(int e) { return e >= POM_C_AGENT; }
-POM_HD int pc_is_static_block(int e) { return (int)pc_is_wood(e) | (int)pc_is_powerup(e) | (int)(e == 1); }
-POM_HD int pc_flag_item(int f) { return f == 0 ? 0 : f + 5; } /* FlagItem, bboard.cpp:182-189: 1,2,3 -> 6,7,8 */
+POM_HD int pc_is_flame(int e) { return e >= POM_C_FLAME; }
+POM_HD int pc_is_agent(int e) { return (unsigned)(e - POM_C_AGENT) < 4u; }
+POM_HD int pc_agent_id(int e) { return e - POM_C_AGENT; } /* of an agent cell */
+POM_HD int pc_wood_flag(int e) { return (e - POM_C_WOOD) & 3; } /* WOOD_POWFLAG of a wood cell, bboard.hpp:106-109 (flag 4 reads as 0) */
+POM_HD int pc_is_static_block(int e) { return (int)((unsigned)(e - POM_C_EXTRABOMB) < 8u) | (int)(e == POM_C_RIGID); } /* wood, power-up or rigid */
+POM_HD int pc_blocks_bomb(int e) { return (int)((unsigned)(e - POM_C_EXTRABOMB) < 12u) | (int)(e == POM_C_RIGID); } /* ... or an agent */
+POM_HD int pc_flag_item(int f) { return f == 0 ? 0 : f + (POM_C_EXTRABOMB - 1); } /* FlagItem, bboard.cpp:182-189: 1,2,3 -> extra-bomb, incr-range, kick */
+/* the flame item SpawnFlameItem leaves (bboard.cpp:42-50) on the cell i steps along ray r from the origin cell c0; f: the flag of the
+ * wood it burnt there (0: no wood, or wood without a power-up) */
+POM_HD int pc_flame_code(int c0, int r, int i, int f) { return f == 0 ? POM_C_FLAME + c0 : POM_C_FLAGGED - 41 + 40 * f + 10 * r + i; }
+/* PopFlame's test (bboard.cpp:160-176) for the cell i >= 1 steps along ray r from the popping flame's origin c0: -1 if the cell is
+ * not a flame of that origin, else the item it gives way to */
+POM_HD int pc_flame_pops_to(int e, int c0, int r, int i)
+{
+    const int k = e - (POM_C_FLAGGED - 1) - 10 * r - i; /* a flagged flame of this origin: 0, 40 or 80 */
+    const int flagged = (int)(k == 0) | (int)(k == 40) | (int)(k == 80);
+    const int item = POM_C_EXTRABOMB + (int)(k >= 40) + (int)(k >= 80);
+    return e == POM_C_FLAME + c0 ? POM_C_PASSAGE : flagged ? item : -1;
+}
 
 /* ---- bomb word (bboard.hpp:261-335) */
 POM_HD int pb_x(int b) { return b & 0xF; }
@@ -307,8 +323,8 @@ struct PomStepper {
         a.set_flame(slot, x | (y << 8) | (POM_FLAME_LIFETIME << 16) | ((strength & 0xFF) << 24));
         L.fCnt++;
         const int c = y * POM_N + x;
-        if (pc_is_agent(e)) kill(e & 0x3FFF);
-        a.set_cell(c, POM_C_FLAME | (c << 3));
+        if (pc_is_agent(e)) kill(pc_agent_id(e));
+        a.set_cell(c, POM_C_FLAME + c);
     }
     POM_HD void flame_prologue(int x, int y, int strength) { flame_prologue(x, y, strength, a.cell(y * POM_N + x)); }
 
@@ -394,15 +410,15 @@ struct PomStepper {
                         const int cy = div11(c);
                         if (bomb_index_alone((c - cy * POM_N) | (cy << 4)) >= 0) {
                             chains = 1;
-                            chain_key = (i << 12) | pc_is_agent(e) | ((e & 3) << 1);
+                            chain_key = (i << 12) | pc_is_agent(e) | ((pc_agent_id(e) & 3) << 1);
                             break;
                         }
-                        if (pc_is_agent(e)) victims |= 1 << (e & 3); /* killed, the ray goes on (bboard.cpp:26-29) */
+                        if (pc_is_agent(e)) victims |= 1 << pc_agent_id(e); /* killed, the ray goes on (bboard.cpp:26-29) */
                     }
                     if (e == POM_C_RIGID) break;
                     len = i;
                     if (pc_is_wood(e)) {
-                        ends |= (uint32_t)(e & 3) << (2 * r);
+                        ends |= (uint32_t)pc_wood_flag(e) << (2 * r);
                         break;
                     }
                 }
@@ -417,7 +433,7 @@ struct PomStepper {
                     const int len = (lens >> (4 * r)) & 0xF;
                     POM_NOUNROLL
                     for (int i = 1; i <= len; i++)
-                        a.put_cell(ray_cell(c0, r, i), POM_C_FLAME | ((c0 << 3) + (i == len ? (int)((ends >> (2 * r)) & 3u) : 0)));
+                        a.put_cell(ray_cell(c0, r, i), pc_flame_code(c0, r, i, i == len ? (int)((ends >> (2 * r)) & 3u) : 0));
                 }
                 a.sync(); /* the next blast's scan looks at cells other lanes' rays have just written */
                 if (rem == REM_TOP && top_word != -1) { /* nothing touched the queue: the head is still the word the caller saw */
@@ -525,15 +541,15 @@ struct PomStepper {
                 if (open && i <= lim) {
                     if ((e == POM_C_BOMB || pc_is_agent(e)) && cell_in(occ, cb[q])) {
                         chain = i;
-                        info = pc_is_agent(e) | ((e & 3) << 1);
+                        info = pc_is_agent(e) | ((pc_agent_id(e) & 3) << 1);
                         open = 0;
                     } else if (e == POM_C_RIGID) {
                         open = 0;
                     } else {
-                        if (pc_is_agent(e)) vict |= 1 << (e & 3); /* killed, the ray goes on (bboard.cpp:26-29) */
+                        if (pc_is_agent(e)) vict |= 1 << pc_agent_id(e); /* killed, the ray goes on (bboard.cpp:26-29) */
                         len = i;
                         if (pc_is_wood(e)) {
-                            ends = e & 3;
+                            ends = pc_wood_flag(e);
                             wood = 1;
                             open = 0;
                         }
@@ -596,7 +612,7 @@ struct PomStepper {
                     }
                     POM_NOUNROLL
                     for (int d = rs1; d <= len1; d++)
-                        a.put_cell(ray_cell(c0, r, d), POM_C_FLAME | ((c0 << 3) + ((wood1 && d == len1) ? ends1 : 0)));
+                        a.put_cell(ray_cell(c0, r, d), pc_flame_code(c0, r, d, (wood1 && d == len1) ? ends1 : 0));
                     kill_set(vict1);
                 }
                 rstar = first == 0x7FFFFFFF ? 4 : first >> 16;
@@ -644,7 +660,7 @@ struct PomStepper {
                     victims |= rvict[q];
                     POM_NOUNROLL
                     for (int d = rs[q]; d <= rlen[q]; d++)
-                        a.put_cell(ray_cell(c0, r, d), POM_C_FLAME | ((c0 << 3) + ((rwood[q] && d == rlen[q]) ? rends[q] : 0)));
+                        a.put_cell(ray_cell(c0, r, d), pc_flame_code(c0, r, d, (rwood[q] && d == rlen[q]) ? rends[q] : 0));
                 }
             }
             kill_set(a.gor(victims));
@@ -665,7 +681,7 @@ struct PomStepper {
                 int go_on = 0;
                 if (e != POM_C_RIGID) {
                     const int was_wood = pc_is_wood(e);
-                    a.set_cell(c, POM_C_FLAME | ((pc0 << 3) + (was_wood ? (e & 3) : 0)));
+                    a.set_cell(c, pc_flame_code(pc0, dir, i, was_wood ? pc_wood_flag(e) : 0));
                     go_on = !was_wood;
                 }
                 if (go_on) i++;
@@ -727,21 +743,18 @@ struct PomStepper {
             const int x = f & 0xFF, y = (f >> 8) & 0xFF;
             int s = (f >> 24) & 0xFF;
             s = s > POM_N ? POM_N : s; /* cells further out are out of bounds anyway */
-            const int sig = x + POM_N * y;
             if (!oob(x, y)) {
                 const int c0 = y * POM_N + x;
-                {
-                    const int e = a.cell(c0);
-                    if (pc_is_flame(e) & (int)(((e & 0x3FFF) >> 3) == sig)) a.set_cell(c0, pc_flag_item(e & 3));
-                }
+                /* the centre: a flame cell at its own origin never carries a flag (it is not on a ray of its flame) */
+                if (a.cell(c0) == POM_C_FLAME + c0) a.set_cell(c0, POM_C_PASSAGE);
                 POM_NOUNROLL
                 for (int r = a.sub(); r < 4; r += A::G) {
                     const int lim = ray_room(x, y, s, r);
                     POM_NOUNROLL
                     for (int i = 1; i <= lim; i++) {
                         const int c = ray_cell(c0, r, i);
-                        const int e = a.cell(c);
-                        if (pc_is_flame(e) & (int)(((e & 0x3FFF) >> 3) == sig)) a.put_cell(c, pc_flag_item(e & 3));
+                        const int to = pc_flame_pops_to(a.cell(c), c0, r, i);
+                        if (to >= 0) a.put_cell(c, to);
                     }
                 }
             }
@@ -783,7 +796,7 @@ struct PomStepper {
             }
             put4(id, L.a0, ag_setpos(av, ox, oy));
             irregular_ |= (ox | (oy << 4)) != (int)((oldp_ >> (8 * id)) & 0xFF);
-            a.set_cell(oy * POM_N + ox, POM_C_AGENT | id);
+            a.set_cell(oy * POM_N + ox, POM_C_AGENT + id);
             if (origin_agent != -1) {
                 id = origin_agent;
                 continue;
@@ -792,7 +805,7 @@ struct PomStepper {
                 const int b = bomb_at(bd);
                 const int dir = pb_dir(b);
                 if (mv_dx(dir) == 0 && mv_dy(dir) == 0) { /* bounced back onto a resting bomb */
-                    a.set_cell(oy * POM_N + ox, POM_C_AGENT | id);
+                    a.set_cell(oy * POM_N + ox, POM_C_AGENT + id);
                     return;
                 }
                 const int bx = ox - mv_dx(dir), by = oy - mv_dy(dir);
@@ -861,7 +874,7 @@ struct PomStepper {
         int blocked = oob(tx, ty);
         if (!blocked) {
             const int e = a.cell(ty * POM_N + tx);
-            blocked = pc_is_static_block(e) | pc_is_agent(e);
+            blocked = pc_blocks_bomb(e);
         }
         if (blocked) {
             set_bomb_at(k, pb_set(b, 0xF00000u, 0));
@@ -1153,7 +1166,7 @@ struct PomStepper {
                         item = a.cell(dc);
                         /* my own cell, asked together with the destination (one round trip): nobody writes it in this round —
                          * whoever wants it waits for me and moves in a later one */
-                        shows_me = a.cell(oc) == (POM_C_AGENT | m);
+                        shows_me = a.cell(oc) == POM_C_AGENT + m;
 #pragma unroll
                         for (int j = 0; j < 4; j++)
                             collide |= (j != m) & !((deadmask >> j) & 1) & (((dstp >> (8 * j)) & 0xFF) == (uint32_t)dkey);
@@ -1173,14 +1186,14 @@ struct PomStepper {
                             if (shows_me) a.put_cell(oc, vacated);
                         } else if (!collide) {
                             if (pc_is_powerup(item)) { /* ConsumePowerup, step_utility.cpp:247-262 */
-                                if (item == POM_EXTRABOMB) a1v = (a1v & ~0xFFFF) | ((a1v + 1) & 0xFFFF);
-                                else if (item == POM_INCRRANGE) a1v += 1 << 16;
+                                if (item == POM_C_EXTRABOMB) a1v = (a1v & ~0xFFFF) | ((a1v + 1) & 0xFFFF);
+                                else if (item == POM_C_INCRRANGE) a1v += 1 << 16;
                                 else av |= 1 << 24;
                                 item = POM_C_PASSAGE;
                             }
                             if (item == POM_C_PASSAGE) { /* step.cpp:120-140 */
                                 if (shows_me) a.put_cell(oc, vacated);
-                                a.put_cell(dc, POM_C_AGENT | m);
+                                a.put_cell(dc, POM_C_AGENT + m);
                                 av = ag_setpos(av, ddx, ddy);
                             } else if (item == POM_C_BOMB) { /* step.cpp:147-184 */
                                 /* Stepping onto a resting bomb without kicking it while no bomb moves at all: the agent loop
@@ -1192,7 +1205,7 @@ struct PomStepper {
                                 if (!bombs_move && shows_me && bomb_index_alone(ddx | (ddy << 4)) >= 0) {
                                 } else {
                                     a.put_cell(oc, vacated);
-                                    a.put_cell(dc, POM_C_AGENT | m);
+                                    a.put_cell(dc, POM_C_AGENT + m);
                                     av = ag_setpos(av, ddx, ddy);
                                     if (ag_kick(av)) {
                                         const int bi = bomb_index_alone(ddx | (ddy << 4)); /* GetBomb; the lanes are on different cells */
@@ -1275,7 +1288,7 @@ struct PomStepper {
                     kill(i);
                     deadmask |= 1 << i;
                     const int oc = y * POM_N + x;
-                    if (a.cell(oc) == (POM_C_AGENT | i))
+                    if (a.cell(oc) == POM_C_AGENT + i)
                         a.set_cell(oc, ((on_bomb >> i) & 1) ? POM_C_BOMB : POM_C_PASSAGE);
                     i = next;
                     continue;
@@ -1290,10 +1303,10 @@ struct PomStepper {
                     continue;
                 }
                 if (pc_is_powerup(item)) { /* ConsumePowerup, step_utility.cpp:247-262 */
-                    if (item == POM_EXTRABOMB) {
+                    if (item == POM_C_EXTRABOMB) {
                         const int a1v = sel4(i, L.a1);
                         put4(i, L.a1, (a1v & ~0xFFFF) | ((a1v + 1) & 0xFFFF));
-                    } else if (item == POM_INCRRANGE) {
+                    } else if (item == POM_C_INCRRANGE) {
                         put4(i, L.a1, sel4(i, L.a1) + (1 << 16));
                     } else {
                         put4(i, L.a0, sel4(i, L.a0) | (1 << 24));
@@ -1302,13 +1315,13 @@ struct PomStepper {
                 }
                 const int oc = y * POM_N + x;
                 if (item == POM_C_PASSAGE || (ouroboros && pc_is_agent(item))) { /* step.cpp:120-140 */
-                    if (a.cell(oc) == (POM_C_AGENT | i))
+                    if (a.cell(oc) == POM_C_AGENT + i)
                         a.set_cell(oc, ((on_bomb >> i) & 1) ? POM_C_BOMB : POM_C_PASSAGE);
-                    a.set_cell(dc, POM_C_AGENT | i);
+                    a.set_cell(dc, POM_C_AGENT + i);
                     put4(i, L.a0, ag_setpos(sel4(i, L.a0), ddx, ddy));
                 } else if (item == POM_C_BOMB) { /* step.cpp:147-184: kicker and non-kicker both step on */
                     a.set_cell(oc, ((on_bomb >> i) & 1) ? POM_C_BOMB : POM_C_PASSAGE);
-                    a.set_cell(dc, POM_C_AGENT | i);
+                    a.set_cell(dc, POM_C_AGENT + i);
                     const int cur = sel4(i, L.a0);
                     put4(i, L.a0, ag_setpos(cur, ddx, ddy));
                     if (ag_kick(cur)) {
@@ -1361,7 +1374,7 @@ struct PomStepper {
                 if (idx < POM_CELLS) {
                     const int e = a.cell(idx);
                     ripe |= (e == POM_C_PASSAGE) | pc_is_flame(e);
-                    if (pc_is_static_block(e) | pc_is_agent(e)) {
+                    if (pc_blocks_bomb(e)) {
                         const int ag = get_agent(pb_x(b), pb_y(b));
                         const int ag3 = ag & 3; /* (ag == -1: agent 3's fields are read and the answer masked) */
                         const int m2 = (mvp >> (4 * ag3)) & 0xF;

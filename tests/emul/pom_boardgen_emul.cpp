@@ -10,8 +10,8 @@
 
 static void put_cell(uint32_t* rec, int c, int code)
 {
-    uint32_t& w = rec[POM_REC_BOARD + (c >> 1)];
-    w = (c & 1) ? (w & 0x0000FFFFu) | ((uint32_t)code << 16) : (w & 0xFFFF0000u) | (uint32_t)(code & 0xFFFF);
+    uint32_t& w = rec[POM_REC_BOARD + (c >> 2)];
+    w = (w & ~(0xFFu << (8 * (c & 3)))) | ((uint32_t)(code & 0xFF) << (8 * (c & 3)));
 }
 
 extern "C" void pom_emul_boardgen(uint64_t seed, uint32_t env, uint32_t episode, void* state_1004)
@@ -31,8 +31,8 @@ extern "C" void pom_emul_boardgen(uint64_t seed, uint32_t env, uint32_t episode,
         if (POM_REC_TIMESTEP + lane < POM_REC_DWORDS) rec[POM_REC_TIMESTEP + lane] = pom_fresh_row(POM_REC_TIMESTEP + lane);
     }
     pom_board_flags(key, ballot[0], ballot[1], [&](int c, int code) { put_cell(rec, c, code); });
-    for (int a = 0; a < 4; a++) put_cell(rec, pom_corner_cell(a), POM_C_AGENT | a);
-    rec[POM_REC_BOARD + 60] &= 0x0000FFFFu; /* the half dword past cell 120 is not part of the record's content */
+    for (int a = 0; a < 4; a++) put_cell(rec, pom_corner_cell(a), POM_C_AGENT + a);
+    rec[POM_REC_BOARD + 30] &= 0x000000FFu; /* the three bytes past cell 120 are not part of the record's content */
     std::memset(state_1004, 0, POM_STATE_BYTES);
     pom_unpack_state(rec, 1, (int32_t*)state_1004);
 }

@@ -10,7 +10,7 @@
 #include "pom_step_body.h"
 
 struct ArrayEnv {
-    uint16_t cells[122];
+    uint8_t cells[124];
     int bombs[20], flames[20], stack[POM_STACK_DEPTH];
     uint8_t bd[20];
     static constexpr int G = 1; /* one lane per env: the split sections degenerate to plain loops */
@@ -20,12 +20,12 @@ struct ArrayEnv {
     int gadd(int v) const { return v; }
     template <int J> int gbcast(int v) const { return v; }
     void sync() const {}
-    void put_cell(int c, int v) { cells[c] = (uint16_t)v; }
+    void put_cell(int c, int v) { cells[c] = (uint8_t)v; }
     void put_bomb(int s, int v) { bombs[s] = v; }
     void put_flame(int s, int v) { flames[s] = v; }
     void put_bdest(int i, int v) { bd[i] = (uint8_t)v; }
     int cell(int c) const { return cells[c]; }
-    void set_cell(int c, int v) { cells[c] = (uint16_t)v; }
+    void set_cell(int c, int v) { cells[c] = (uint8_t)v; }
     int bomb(int s) const { return bombs[s]; }
     void set_bomb(int s, int v) { bombs[s] = v; }
     int flame(int s) const { return flames[s]; }
@@ -70,7 +70,7 @@ int pom_emul_prep(const void* state_1004, const int32_t* moves, int32_t* dest_xy
 }
 
 /* The device buffers' layout (pom_packed.h: tiles of 16 envs, pom_rec_col): `n` States packed into a buffer of ceil(n/16) tiles
- * exactly as pom_pack_kernel does it, then unpacked again.  Returns 0 if every State comes back and every env's 112 dwords lie
+ * exactly as pom_pack_kernel does it, then unpacked again.  Returns 0 if every State comes back and every env's POM_REC_DWORDS dwords lie
  * inside its own tile at the documented places, else a line number. */
 int pom_emul_tile_roundtrip(const void* states_1004, int n, void* out_1004)
 {
@@ -109,10 +109,7 @@ uint32_t pom_emul_step(void* state_1004, const int32_t* moves, int env_mode, int
     if (pom_pack_state((const int32_t*)state_1004, rec, 1)) return 0xFFFFFFFFu;
     ArrayEnv env;
     std::memset(&env, 0, sizeof env);
-    for (int r = 0; r < 61; r++) {
-        env.cells[2 * r] = (uint16_t)(rec[POM_REC_BOARD + r] & 0xFFFF);
-        env.cells[2 * r + 1] = (uint16_t)(rec[POM_REC_BOARD + r] >> 16);
-    }
+    for (int c = 0; c < POM_CELLS; c++) env.cells[c] = (uint8_t)pom_rec_cell(rec, 1, c);
     for (int k = 0; k < 20; k++) {
         env.bombs[k] = (int)rec[POM_REC_BOMBS + k];
         env.flames[k] = (int)rec[POM_REC_FLAMES + k];
@@ -130,7 +127,9 @@ uint32_t pom_emul_step(void* state_1004, const int32_t* moves, int env_mode, int
             status = pom_env_epilogue(L, time_step, max_steps, status);
         }
     }
-    for (int r = 0; r < 61; r++) rec[POM_REC_BOARD + r] = (uint32_t)env.cells[2 * r] | ((uint32_t)env.cells[2 * r + 1] << 16);
+    for (int r = 0; r < POM_REC_BOARD_DWORDS; r++)
+        rec[POM_REC_BOARD + r] = (uint32_t)env.cells[4 * r] | ((uint32_t)env.cells[4 * r + 1] << 8) | ((uint32_t)env.cells[4 * r + 2] << 16) |
+                                 ((uint32_t)env.cells[4 * r + 3] << 24); /* (cells 121..123 stay 0) */
     rec[POM_REC_TIMESTEP] = (uint32_t)time_step;
     rec[POM_REC_META] = pom_lane_meta(L);
     rec[POM_REC_META2] = pom_lane_meta2(L, status);

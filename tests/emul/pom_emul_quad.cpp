@@ -37,7 +37,7 @@ namespace {
 
 enum { OP_OR = 1, OP_MIN, OP_ADD, OP_BCAST, OP_SYNC = OP_BCAST + 4, OP_END };
 enum { W_NONE = 0, W_PUT = 1, W_SET_OWNER = 2, W_SET_SHADOW = 3 };
-enum { N_CELL = 122, N_SLOT = 20, N_STACK = POM_STACK_DEPTH, N_ADDR = N_CELL + 3 * N_SLOT + N_STACK };
+enum { N_CELL = 124, N_SLOT = 20, N_STACK = POM_STACK_DEPTH, N_ADDR = N_CELL + 3 * N_SLOT + N_STACK };
 /* one address space for the merge: cells, bombs, flames, bomb destinations, frames */
 enum { A_CELL = 0, A_BOMB = N_CELL, A_FLAME = A_BOMB + N_SLOT, A_BDEST = A_FLAME + N_SLOT, A_STACK = A_BDEST + N_SLOT };
 
@@ -161,8 +161,8 @@ struct QuadLaneEnv {
     void sync() const { (void)rendezvous(OP_SYNC, 0); }
 
     int cell(int c) const { return rd(A_CELL + c); }
-    void put_cell(int c, int v) { wr(A_CELL + c, v & 0xFFFF, W_PUT); }
-    void set_cell(int c, int v) { wr(A_CELL + c, v & 0xFFFF, set_kind()); }
+    void put_cell(int c, int v) { wr(A_CELL + c, v & 0xFF, W_PUT); }
+    void set_cell(int c, int v) { wr(A_CELL + c, v & 0xFF, set_kind()); }
     int bomb(int s) const { return rd(A_BOMB + s); }
     void put_bomb(int s, int v) { wr(A_BOMB + s, v, W_PUT); }
     void set_bomb(int s, int v) { wr(A_BOMB + s, v, set_kind()); }
@@ -267,10 +267,7 @@ uint32_t pom_emul_quad_step(void* state_1004, const int32_t* moves, int env_mode
     std::memset(q.kind, 0, sizeof q.kind);
     std::memset(q.n_dirty, 0, sizeof q.n_dirty);
     q.diverged.store(0);
-    for (int r = 0; r < 61; r++) {
-        q.mem[A_CELL + 2 * r] = (int)(rec[POM_REC_BOARD + r] & 0xFFFF);
-        q.mem[A_CELL + 2 * r + 1] = (int)(rec[POM_REC_BOARD + r] >> 16);
-    }
+    for (int c = 0; c < POM_CELLS; c++) q.mem[A_CELL + c] = pom_rec_cell(rec, 1, c);
     for (int k = 0; k < 20; k++) {
         q.mem[A_BOMB + k] = (int)rec[POM_REC_BOMBS + k];
         q.mem[A_FLAME + k] = (int)rec[POM_REC_FLAMES + k];
@@ -297,7 +294,9 @@ uint32_t pom_emul_quad_step(void* state_1004, const int32_t* moves, int env_mode
         }
     }
     const PomLane& L = q.lanes[0];
-    for (int r = 0; r < 61; r++) rec[POM_REC_BOARD + r] = (uint32_t)q.mem[A_CELL + 2 * r] | ((uint32_t)q.mem[A_CELL + 2 * r + 1] << 16);
+    for (int r = 0; r < POM_REC_BOARD_DWORDS; r++)
+        rec[POM_REC_BOARD + r] = (uint32_t)q.mem[A_CELL + 4 * r] | ((uint32_t)q.mem[A_CELL + 4 * r + 1] << 8) |
+                                 ((uint32_t)q.mem[A_CELL + 4 * r + 2] << 16) | ((uint32_t)q.mem[A_CELL + 4 * r + 3] << 24);
     rec[POM_REC_TIMESTEP] = (uint32_t)time_step;
     rec[POM_REC_META] = pom_lane_meta(L);
     rec[POM_REC_META2] = pom_lane_meta2(L, status);

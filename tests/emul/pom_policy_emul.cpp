@@ -8,7 +8,7 @@
 #include "pom_policy_body.h"
 
 struct PolicyArrays {
-    uint16_t cells[128];
+    uint8_t cells[128];
     int bombs[20];
     int dmap[128];
     uint32_t sets[12];
@@ -20,7 +20,7 @@ struct PolicyArrays {
     uint32_t setw(int k) const { return sets[k]; }
     void set_put(int k, uint32_t bits) { sets[k] = bits; }
     int cell(int c) const { return cells[c]; }
-    uint32_t board_word(int k) const { return (uint32_t)cells[2 * k] | ((uint32_t)cells[2 * k + 1] << 16); }
+    uint32_t board_word(int k) const { return (uint32_t)cells[4 * k] | ((uint32_t)cells[4 * k + 1] << 8) | ((uint32_t)cells[4 * k + 2] << 16) | ((uint32_t)cells[4 * k + 3] << 24); }
     int bomb(int s) const { return bombs[s]; }
 };
 
@@ -137,14 +137,9 @@ int pom_emul_simple_act(const void* state_1004, int id, int32_t* mem16, int draw
     if (pom_pack_state((const int32_t*)state_1004, rec, 1)) return -1;
     PolicyArrays st;
     std::memset(&st, 0, sizeof st);
-    for (int r = 0; r < 61; r++) {
-        st.cells[2 * r] = (uint16_t)(rec[POM_REC_BOARD + r] & 0xFFFF);
-        st.cells[2 * r + 1] = (uint16_t)(rec[POM_REC_BOARD + r] >> 16);
-    }
-    for (int r = 61; r < 64; r++) { /* dwords 61..63 of the record follow the board in the tile: the body must mask them */
-        st.cells[2 * r] = (uint16_t)(rec[r] & 0xFFFF);
-        st.cells[2 * r + 1] = (uint16_t)(rec[r] >> 16);
-    }
+    for (int c = 0; c < POM_CELLS; c++) st.cells[c] = (uint8_t)pom_rec_cell(rec, 1, c);
+    for (int c = POM_CELLS + 3; c < 128; c++) /* dword 31 of the record follows the board in the tile: the body must mask it */
+        st.cells[c] = (uint8_t)(rec[POM_REC_TIMESTEP] >> (8 * (c & 3)));
     for (int c = POM_CELLS; c < 128; c++) st.dmap[c] = (c * 7) % 3; /* rows past the map: arbitrary */
     for (int k = 0; k < 20; k++) st.bombs[k] = (int)rec[POM_REC_BOMBS + k];
     PomPolicyEnv E;
