@@ -172,7 +172,13 @@ POM_HD int ag_kick(int a0) { return (a0 >> 24) & 1; }
 POM_HD int ag_setpos(int a0, int x, int y) { return (a0 & ~0xFFFF) | x | (y << 8); }
 POM_HD int ag_bombcount_add(int a0, int d) { return (a0 & ~0xFF0000) | (int)(((uint32_t)a0 + ((uint32_t)d << 16)) & 0xFF0000u); } /* d may be -1: unsigned arithmetic */
 
-POM_HD int wrap20(int p) { return p >= POM_Q ? p - POM_Q : p; } /* p < 40 */
+POM_HD int wrap20(int p) /* 0 <= p < 40 */
+{
+    /* (one v_min_u32 instead of compare + select: on gfx950 a v_cmp's lane mask is not ready for the very next instruction, so every
+     * select that cannot be scheduled away costs a compare, a wait and the select) */
+    const unsigned u = (unsigned)p, w = u - (unsigned)POM_Q; /* wraps far above 40 when p < 20 */
+    return (int)(u < w ? u : w);
+}
 POM_HD uint32_t pom_zero_bytes(uint32_t x) /* 0x80 in exactly the bytes of x that are 0 */
 {
     return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
@@ -185,11 +191,17 @@ POM_HD int div11(int c) /* c / 11 for a cell index (exact for 0 <= c < 586): one
     return c / POM_N;
 #endif
 }
-POM_HD int oob(int x, int y) { return (int)((unsigned)x >= (unsigned)POM_N) | (int)((unsigned)y >= (unsigned)POM_N); } /* (| not ||: no branch) */
+POM_HD int oob(int x, int y) /* either coordinate outside 0..10 (as unsigned numbers a negative one is huge: one v_max_u32, one compare) */
+{
+    const unsigned ux = (unsigned)x, uy = (unsigned)y;
+    return (ux > uy ? ux : uy) >= (unsigned)POM_N;
+}
 
 /* displacement of a Move / Direction (step_utility.cpp:9-31): 1 up(-y) 2 down(+y) 3 left(-x) 4 right(+x) */
-POM_HD int mv_dx(int m) { return m == 4 ? 1 : m == 3 ? -1 : 0; }
-POM_HD int mv_dy(int m) { return m == 2 ? 1 : m == 1 ? -1 : 0; }
+/* (two bits per move in a constant — 1 + displacement, 1 for everything that is no direction, m = 0..15 — instead of two compares
+ * and two selects each) */
+POM_HD int mv_dx(int m) { return (int)((0x55555615u >> (2 * m)) & 3u) - 1; }
+POM_HD int mv_dy(int m) { return (int)((0x55555561u >> (2 * m)) & 3u) - 1; }
 
 template <class A>
 struct PomStepper {
@@ -345,10 +357,9 @@ struct PomStepper {
     /* rays 0..3 = +x, -x, +y, -y.  Selects on the two bits of the ray number, not a ternary chain: with the ray number a lane's
      * own (lane r of a quad takes ray r) hipcc turns the chain into nested exec-mask branches — 20 scalar instructions and
      * three jumps for one multiply. */
-    POM_HD static int ray_step(int dir)
+    POM_HD static int ray_step(int dir) /* 1, -1, 11, -11: a byte each of one constant */
     {
-        const int mag = (dir & 2) ? POM_N : 1;
-        return (dir & 1) ? -mag : mag;
+        return (int)(int8_t)(0xF50BFF01u >> (8 * dir));
     }
     POM_HD static int ray_cell(int c0, int dir, int i)
     {
@@ -360,8 +371,9 @@ struct PomStepper {
     }
     POM_HD static int ray_room(int x, int y, int s, int dir)
     {
-        const int v = (dir & 2) ? y : x;
-        const int room = (dir & 1) ? v : POM_N - 1 - v;
+        /* the cells between (x, y) and the edge in the four directions, a nibble each: 10 - x, x, 10 - y, y */
+        const unsigned rooms = (unsigned)(POM_N - 1 - x) | ((unsigned)x << 4) | ((unsigned)(POM_N - 1 - y) << 8) | ((unsigned)y << 12);
+        const int room = (int)((rooms >> (4 * dir)) & 0xFu);
         return room < s ? room : s;
     }
 
@@ -397,6 +409,8 @@ struct PomStepper {
             int chain_key = 0; /* this lane's ray stopped at a cell with a queued bomb: distance << 12 | agent there | his id << 1 */
             uint32_t lens = 0; /* reach of ray r in nibble r */
             uint32_t ends = 0; /* power-up flag of the wood a ray ends on, 2 bits per ray (only a ray's last cell can be wood) */
+            /* (cell by cell: with one or two cells per ray the four-at-a-time classification of scan_ray costs more than it saves —
+             * measured, 1,011 -> 1,084 VALU per wavefront-tick on the headline) */
             POM_NOUNROLL
             for (int r = a.sub(); r < 4; r += A::G) {
                 const int lim = ray_room(x, y, s, r);
@@ -520,41 +534,68 @@ struct PomStepper {
      * flame gets (`len`: the last cell that takes it, start - 1 if none), the flag of the wood it ends on (`ends`, with
      * `wood` set), the agents it kills on the way (`vict`), and — instead of going on — the first BOMB / agent cell that is in
      * `occ`, the cells with a queued bomb (`chain`: its distance, 0 = none; `info`: agent there | his id << 1):
-     * SpawnFlameItem, bboard.cpp:24-57, without its writes. */
+     * SpawnFlameItem, bboard.cpp:24-57, without its writes.
+     * The four cell codes of a round are classified together, a byte each of one dword (round 5; until then cell by cell, ~25
+     * instructions each): with the top bit of every byte cleared, adding 128 - k sets it again iff the byte is >= k, so a class of
+     * codes — rigid 1, Item::BOMB 2, wood 6..10, agents 11..14 — is two adds and an and-not for all four cells; the ray ends at the
+     * LOWEST flagged byte, everything below it takes the flame. */
     POM_HD void scan_ray(int c0, int r, int start, int lim, const uint32_t occ[4], int& len, int& ends, int& wood, int& vict, int& chain,
                          int& info)
     {
+        constexpr int W = 4; /* cells per round */
         len = start - 1;
         ends = wood = vict = chain = info = 0;
-        int open = 1;
+        const uint32_t H = 0x80808080u;
         POM_NOUNROLL
-        for (int i0 = start; open && i0 <= lim; i0 += 4) {
-            int eb[4], cb[4];
+        for (int i0 = start; i0 <= lim; i0 += W) {
+            uint32_t d = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                cb[q] = ray_cell(c0, r, i0 + q <= lim ? i0 + q : lim); /* clamped: stays on the ray */
-                eb[q] = a.cell(cb[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int i = i0 + q, e = eb[q];
-                if (open && i <= lim) {
-                    if ((e == POM_C_BOMB || pc_is_agent(e)) && cell_in(occ, cb[q])) {
-                        chain = i;
-                        info = pc_is_agent(e) | ((pc_agent_id(e) & 3) << 1);
-                        open = 0;
-                    } else if (e == POM_C_RIGID) {
-                        open = 0;
-                    } else {
-                        if (pc_is_agent(e)) vict |= 1 << pc_agent_id(e); /* killed, the ray goes on (bboard.cpp:26-29) */
-                        len = i;
-                        if (pc_is_wood(e)) {
-                            ends = pc_wood_flag(e);
-                            wood = 1;
-                            open = 0;
-                        }
-                    }
+            for (int q = 0; q < W; q++) /* (clamped: stays on the ray) */
+                d |= (uint32_t)a.cell(ray_cell(c0, r, i0 + q <= lim ? i0 + q : lim)) << (8 * q);
+            const int n = lim - i0 + 1; /* how many of the round's cells are cells of the ray (>= 1) */
+            const uint32_t onray = n >= W ? H : H >> (8 * (W - n));
+            const uint32_t l = d & 0x7F7F7F7Fu, lo = ~d; /* lo: top bit set where the code is below 128 */
+            const uint32_t ge1 = l + 0x7F7F7F7Fu, ge2 = l + 0x7E7E7E7Eu, ge3 = l + 0x7D7D7D7Du, ge6 = l + 0x7A7A7A7Au, ge11 = l + 0x75757575u,
+                           ge15 = l + 0x71717171u;
+            const uint32_t rigid = ge1 & ~ge2 & lo, bombc = ge2 & ~ge3 & lo, woodc = ge6 & ~ge11 & lo & onray, agentc = ge11 & ~ge15 & lo & H;
+            /* where the ray ends whatever the bombs do: rigid (before it), wood (on it), the end of the ray */
+            const uint32_t fixed = ((rigid | woodc) & onray & H) | (~onray & H);
+            const uint32_t fixed_low = fixed & (0u - fixed); /* its lowest flag: 0 if none, then fixed_low - 1 is every byte */
+            /* BOMB / agent cells before that: SpawnFlameItem sets off the first queued bomb on such a cell (bboard.cpp:30-40) */
+            uint32_t cand = (bombc | agentc) & H & (fixed_low - 1u);
+            uint32_t chain_at = 0u;
+            POM_NOUNROLL
+            while (cand) {
+                const int q = __builtin_ctz(cand) >> 3;
+                if (cell_in(occ, ray_cell(c0, r, i0 + q))) { /* (a candidate lies in front of the ray's end: a cell of the ray) */
+                    chain_at = cand & (0u - cand);
+                    break;
                 }
+                cand &= cand - 1u;
+            }
+            const uint32_t stop = fixed | chain_at;
+            const uint32_t at = stop & (0u - stop), below = at - 1u;
+            const int before = __builtin_popcount(below & H); /* cells of this round in front of the one the ray ends at (W: it goes on) */
+            const int on_wood = (at & woodc) != 0u;
+            len = i0 - 1 + before + on_wood;
+            uint32_t dead = agentc & below; /* agents on cells the flame takes: killed, the ray goes on (bboard.cpp:26-29) */
+            POM_NOUNROLL
+            while (dead) {
+                const int q = __builtin_ctz(dead) >> 3;
+                dead &= dead - 1u;
+                vict |= 1 << pc_agent_id((int)((d >> (8 * q)) & 0xFFu));
+            }
+            if (at) {
+                const int e = (int)((d >> (8 * before)) & 0xFFu);
+                if (on_wood) {
+                    ends = pc_wood_flag(e);
+                    wood = 1;
+                }
+                if (at & chain_at) {
+                    chain = i0 + before;
+                    info = pc_is_agent(e) | ((pc_agent_id(e) & 3) << 1);
+                }
+                break;
             }
         }
     }
