@@ -618,6 +618,66 @@ def worker(args) -> None:
         ms_obs["codes"] = ev6.elapsed_time(ev7) / n_x
         e3.close()
         del tape, planes, a_at, e_at, codes
+        # CLOSED LOOP (the reference's real call shape, Environment::Step: this tick's Move[4] from the caller every tick,
+        # environment.cpp:139-149): the batch cut into R ranges, each carrying  policy(range) -> step(range) -> policy(range) ...  on a
+        # stream of its own (pom_batch_step_device_range), so that one range's policy runs while the others step; K ticks captured into
+        # one HIP graph and replayed.  The policy is a stand-in kernel (pom_bench_policy): with `codes` it reads every byte of the
+        # fused POM_OBS_CODES observation the step of the same range wrote one tick earlier, and draws Move[4] from it.
+        from pomcpp_amd.batch import bench_policy
+        loop = {}
+        n_ranges = int(os.environ.get("POM_BENCH_LOOP_RANGES", "2"))  # (profiles/r05_closed_loop_sweep.txt: a launch costs ~3 us however it is issued)
+        k_loop, reps_loop = 25, 8
+        per = plan["n_envs"] // n_ranges // 16 * 16
+        ranges = [(i * per, per if i < n_ranges - 1 else plan["n_envs"] - i * per) for i in range(n_ranges)]
+        for with_obs in (False, True):
+            e5 = BatchEnvironment(plan["n_envs"], device=local_rank, mode=MODE_ENV, auto_reset=RESET_AT_END, max_steps=args.max_steps,
+                                  stream=stream.cuda_stream)
+            e5.make_game(start)
+            e5.step_random(args.seed, dist_id, ticks=300)  # a steady mix of game phases
+            codes5 = e5.observe(dtype="codes", attrs=False)[0] if with_obs else None
+            moves5 = torch.zeros((plan["n_envs"], 4), dtype=torch.int32, device=device)
+            e5.sync()
+            torch.cuda.synchronize()
+            side = [torch.cuda.Stream(device=device) for _ in ranges]
+            main5 = torch.cuda.Stream(device=device)
+
+            def issue_loop(main_s):
+                for s5 in side:
+                    s5.wait_stream(main_s)
+                for t in range(k_loop):
+                    for (f5, c5), s5 in zip(ranges, side):
+                        bench_policy(codes5, moves5, f5, c5, t, s5)
+                        e5.step_device_range(f5, c5, moves5, s5, codes=codes5)
+                for s5 in side:
+                    main_s.wait_stream(s5)
+
+            g5 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g5, stream=main5):
+                issue_loop(main5)
+            cnt0 = int(e5.counters()[0])
+            g5.replay()
+            torch.cuda.synchronize()
+            evl0, evl1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(main5):
+                evl0.record(main5)
+                for _ in range(reps_loop):
+                    g5.replay()
+                evl1.record(main5)
+            torch.cuda.synchronize()
+            ms_l = evl0.elapsed_time(evl1) / (reps_loop * k_loop)
+            played = int(e5.counters()[0]) - cnt0
+            assert played == plan["n_envs"] * k_loop * (reps_loop + 1), (played, plan["n_envs"] * k_loop * (reps_loop + 1))
+            loop["codes" if with_obs else "plain"] = ms_l
+            e5.close()
+            del g5, codes5, moves5
+        other["closed_loop_65536_envs"] = {
+            "value": plan["n_envs"] / (loop["plain"] * 1e-3), "unit": "env-steps/s", "us_per_tick": loop["plain"] * 1e3,
+            "value_with_codes_observation": plan["n_envs"] / (loop["codes"] * 1e-3), "us_per_tick_with_codes_observation": loop["codes"] * 1e3,
+            "ranges": n_ranges, "ticks_per_graph": k_loop, "graph_replays_timed": reps_loop,
+            "note": "pom_batch_step_device_range: per tick and range one launch of a stand-in device policy (pom_bench_policy: writes this "
+                    "tick's Move[4]; *_with_codes_observation: after reading every byte of the range's fused POM_OBS_CODES observation of "
+                    "the tick before) and one launch of the step (with the observation fused), each range on its own stream, the whole loop "
+                    "a replayed HIP graph; POM_RESET_AT_END; every env-step counted by the device counters"}
         # Throughput mode: ticks_per_launch = T > 1 keeps the record in LDS for T ticks (synthetic move stream only) —
         # NOT the canonical roofline run (a step there is one HBM round trip per tick); reported on its own, per tick
         for name, n_o, t_o in (("throughput_T4_65536_envs", 65536, 4), ("throughput_T16_65536_envs", 65536, 16),

@@ -260,6 +260,26 @@ int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_
 int pom_batch_step_device_observe(PomBatch* h, const int32_t* moves_dev, void* planes_dev, int32_t dtype, int32_t per_agent,
                                   int32_t* agent_attrs_dev, int32_t* env_attrs_dev);
 
+/* CLOSED-LOOP stepping: Step(State*, Move[4]) with THIS tick's moves from the caller every tick (the reference's real call shape:
+ * Environment::Step collects act() of every agent and then steps, src/bboard/environment.cpp:139-149), without the whole chip
+ * waiting for the caller's policy between two ticks.  One tick for the envs [first, first + count) only (whole tiles: first a
+ * multiple of 16, count a multiple of 16 or reaching the batch's end), ONE launch on `stream` (NULL: the handle's stream), moves
+ * from moves_dev = int32 [n][4] indexed by the env's number in the batch.  planes_dev != NULL: the observation of those envs
+ * after the tick is written by the same launch (layout and arguments as pom_batch_observe, the arrays sized for the WHOLE batch;
+ * only the range's part is written).  Nothing is forked or joined: the call is ordered by `stream` alone, so a caller that cuts
+ * the batch into two or four ranges, each with a stream of its own carrying  policy(range) -> step(range) -> policy(range) ...,
+ * has range A's policy running while range B steps — and the chains can be captured into a HIP graph (the call makes no
+ * synchronising runtime call once the handle is settled: pom_batch_sync first).  The caller orders the streams behind whatever
+ * put the batch into its present state.  The handle's tick (which keys pom_batch_step_random's move stream) does not advance.
+ * Quad shape only (POM_E_ARG otherwise).  bench.py: other_configs.closed_loop_65536_envs. */
+int pom_batch_step_device_range(PomBatch* h, int64_t first, int64_t count, const int32_t* moves_dev, void* stream, void* planes_dev,
+                                int32_t dtype, int32_t per_agent, int32_t* agent_attrs_dev, int32_t* env_attrs_dev);
+/* A stand-in for a learned policy in measurements and tests of the closed loop (NOT part of the stepper): one launch on `stream`
+ * that writes Move[4] of the envs [first, first + count) into moves_dev (int32 [n][4]).  codes_dev != NULL: the POM_OBS_CODES
+ * observation of the batch (uint8 [n][5][11][11]) — every byte of the range's observations is read and the moves depend on them;
+ * NULL: the moves depend on (env, agent, tick) only.  The same function of its inputs on every call: tests recompute it. */
+int pom_bench_policy(const uint8_t* codes_dev, int32_t* moves_dev, int64_t first, int64_t count, uint32_t tick, void* stream);
+
 /* bboard::Step (include/bboard.hpp:668, src/bboard/step.cpp:9-284) for a single host State on the GPU (device 0): the literal
  * drop-in.  One launch per call: the kernel reads the State and Move[4] from a pinned page, plays the tick and writes the State
  * back; the call returns when that is done (about ten microseconds — the launch and the trip over PCIe, not the tick).

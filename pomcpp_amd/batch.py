@@ -84,6 +84,9 @@ def load_library() -> C.CDLL:
     lib.pom_batch_observe.argtypes = [P, VP, I32, I32, VP, VP]
     if not os.environ.get("POM_LIB") or hasattr(lib, "pom_batch_step_device_observe"):
         lib.pom_batch_step_device_observe.argtypes = [P, VP, VP, I32, I32, VP, VP]
+    if hasattr(lib, "pom_batch_step_device_range"):
+        lib.pom_batch_step_device_range.argtypes = [P, I64, I64, VP, VP, VP, I32, I32, VP, VP]
+        lib.pom_bench_policy.argtypes = [VP, VP, I64, I64, C.c_uint32, VP]
     lib.pom_batch_stream.argtypes = [P, C.POINTER(C.c_void_p)]
     lib.pom_batch_moves_device.argtypes = [P, C.POINTER(C.POINTER(C.c_int32))]
     lib.pom_batch_generate.argtypes = [P, U64]
@@ -289,12 +292,26 @@ class BatchEnvironment:
             ticks = shape[0]
             # the tape is read asynchronously and must stay unchanged until the handle has been synchronised: keep the tensor (and
             # with it its memory) alive until then, whatever the caller does with its own reference
+            if len(self._tapes) >= 4:  # a loop that never synchronises must not keep every tape alive: wait for the old ones
+                self.sync()
             self._tapes.append(moves)
             self._after_torch(moves)
             moves = moves.data_ptr()
         if ticks is None:
             raise ValueError("a raw device address needs `ticks`")
         _check(self._lib, self._lib.pom_batch_step_device_many(self._h, int(moves), int(ticks)))
+
+    def step_device_range(self, first: int, count: int, moves, stream=None, codes=None, planes=None) -> None:
+        """Closed-loop stepping (pom_batch_step_device_range): one tick for the envs [first, first + count) — whole tiles of 16 — as ONE
+        launch on `stream` (a raw hipStream_t / torch stream; None: the handle's stream), Move[4] from `moves` (int32[n, 4] device tensor
+        or address, indexed by env).  `codes` (uint8[n, 5, 11, 11]) or `planes` (uint8[n, 16, 11, 11]): the observation of those envs after
+        the tick, written by the same launch.  Nothing is forked or joined: the stream orders the call; sync() the handle once before a loop
+        of these (and before capturing them into a graph)."""
+        st = getattr(stream, "cuda_stream", stream)
+        mv = moves.data_ptr() if hasattr(moves, "data_ptr") else int(moves)
+        out, code = (codes, 3) if codes is not None else (planes, 0)
+        _check(self._lib, self._lib.pom_batch_step_device_range(self._h, int(first), int(count), mv, st, out.data_ptr() if out is not None else None,
+                                                                code, 0, None, None))
 
     def chain_stats(self) -> dict:
         """chained launches since creation: launches issued, checks run, tiles found left behind, ticks replayed for them"""
@@ -485,3 +502,13 @@ class BatchEnvironment:
         base, n_pad, rec = C.c_void_p(), C.c_int64(), C.c_int32()
         _check(self._lib, self._lib.pom_batch_device_view(self._h, C.byref(base), C.byref(n_pad), C.byref(rec)))
         return base.value, n_pad.value, rec.value
+
+
+def bench_policy(codes, moves, first: int, count: int, tick: int, stream=None) -> None:
+    """pom_bench_policy: the stand-in policy of the closed-loop measurements and tests — Move[4] of the envs [first, first + count) into
+    `moves` (int32[n, 4] device tensor), from the POM_OBS_CODES observation `codes` (or None: from (env, agent, tick) alone), one launch on
+    `stream`."""
+    lib = load_library()
+    st = getattr(stream, "cuda_stream", stream)
+    _check(lib, lib.pom_bench_policy(codes.data_ptr() if codes is not None else None, moves.data_ptr(), int(first), int(count), int(tick) & 0xFFFFFFFF, st))
+

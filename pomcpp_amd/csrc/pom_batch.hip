@@ -623,7 +623,9 @@ int pom_batch_observe(PomBatch* h, void* planes_dev, int32_t dtype, int32_t per_
     if (!h) return POM_E_ARG;
     if (int ar = observe_args("pom_batch_observe", planes_dev, dtype, per_agent, agent_attrs_dev, env_attrs_dev)) return ar;
     HIPCHK(hipSetDevice(h->device));
-    if (int jr = join_parts(h)) return jr;
+    /* quiesce, not only join: after chained launches a tile some visitor could not play is caught up first (chain_settle; free
+     * while no chained launch has been issued since the last check) — the planes always describe the state a download returns */
+    if (int jr = quiesce(h)) return jr;
     ObserveParams p;
     p.state = h->state;
     p.n = h->n;
@@ -651,6 +653,81 @@ int pom_batch_step_device_observe(PomBatch* h, const int32_t* moves_dev, void* p
     }
     const PomObserveOut obs = {planes_dev, agent_attrs_dev, env_attrs_dev, dtype, per_agent ? 1 : 0};
     return launch_step(h, moves_dev, 0, 0, 1, false, true, &obs);
+}
+
+/* closed-loop stepping: one tick for a range of whole tiles, one launch on the caller's stream, nothing forked or joined */
+int pom_batch_step_device_range(PomBatch* h, int64_t first, int64_t count, const int32_t* moves_dev, void* stream, void* planes_dev,
+                                int32_t dtype, int32_t per_agent, int32_t* agent_attrs_dev, int32_t* env_attrs_dev)
+{
+    int rc = check_range(h, first, count);
+    if (rc || !moves_dev) return rc ? rc : POM_E_ARG;
+    if (!h->quad || (first & 15) || ((count & 15) && first + count != h->n)) {
+        snprintf(g_err, sizeof g_err, "pom_batch_step_device_range: whole tiles of 16 envs (first %lld, count %lld), quad launch shape", (long long)first,
+                 (long long)count);
+        return POM_E_ARG;
+    }
+    if (planes_dev)
+        if (int ar = observe_args("pom_batch_step_device_range", planes_dev, dtype, per_agent, agent_attrs_dev, env_attrs_dev)) return ar;
+    if (count == 0) return POM_OK;
+    HIPCHK(hipSetDevice(h->device));
+    if (int qr = quiesce(h)) return qr; /* (free, and no runtime call at all, once the handle is settled: what a graph capture needs) */
+    StepParams p;
+    if (int fr = fill_params(h, p, moves_dev, 0, 0, 1)) return fr;
+    if (planes_dev) {
+        p.obs_planes = planes_dev;
+        p.obs_agent_attrs = agent_attrs_dev;
+        p.obs_env_attrs = env_attrs_dev;
+        p.obs_dtype = dtype;
+        p.obs_per_agent = per_agent ? 1 : 0;
+    }
+    p.block0 = first / 16;
+    p.block_end = (first + count + 15) / 16;
+    const void* kernel = planes_dev ? step_observe_kernel_for(h) : step_kernel_for(h, false, true);
+    void* args[1] = {&p};
+    HIPCHK(hipLaunchKernel(kernel, dim3((unsigned)((p.block_end - p.block0 + POM_WPB - 1) / POM_WPB)), dim3(64 * POM_WPB), args, 0,
+                           stream ? (hipStream_t)stream : h->stream));
+    return POM_OK;
+}
+
+/* the stand-in policy of the closed-loop measurements (pom_batch.h): a workgroup takes 64 envs, reads their observations — 64 x 605
+ * bytes, as dwords, coalesced; lane l sums w[k] * (2k + 1) over the group's dwords k = l, l + 256, ... — and every lane (env, agent) draws its move from its sum */
+__global__ __launch_bounds__(256) void pom_bench_policy_kernel(const uint8_t* codes, int32_t* moves, int64_t first, int64_t count, uint32_t tick)
+{
+    const int64_t e0 = first + (int64_t)blockIdx.x * 64;
+    const int64_t e = e0 + (threadIdx.x >> 2);
+    uint32_t acc = 0;
+    if (codes) {
+        const int64_t envs = count - (int64_t)blockIdx.x * 64 < 64 ? count - (int64_t)blockIdx.x * 64 : 64;
+        const uintptr_t lo = (uintptr_t)(codes + e0 * POM_OBS_CODE_PLANES * POM_CELLS), hi = lo + (uintptr_t)envs * POM_OBS_CODE_PLANES * POM_CELLS;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>((lo + 3) & ~(uintptr_t)3); /* whole dwords inside the range's bytes */
+        const int64_t nw = (int64_t)((hi & ~(uintptr_t)3) - ((lo + 3) & ~(uintptr_t)3)) / 4;
+        /* (a sum whose order does not matter: four loads in flight per lane) */
+        uint32_t a1 = 0, a2 = 0, a3 = 0;
+        int64_t k = threadIdx.x;
+        for (; k + 768 < nw; k += 1024) {
+            acc += w[k] * (uint32_t)(2 * k + 1);
+            a1 += w[k + 256] * (uint32_t)(2 * (k + 256) + 1);
+            a2 += w[k + 512] * (uint32_t)(2 * (k + 512) + 1);
+            a3 += w[k + 768] * (uint32_t)(2 * (k + 768) + 1);
+        }
+        for (; k < nw; k += 256) acc += w[k] * (uint32_t)(2 * k + 1);
+        acc += a1 + a2 + a3;
+    }
+    if (e < first + count) {
+        uint32_t x = acc ^ ((uint32_t)e * 0x9E3779B1u) ^ ((threadIdx.x & 3u) * 0x85EBCA6Bu) ^ (tick * 0xC2B2AE35u);
+        x ^= x >> 15;
+        x *= 0x2C1B3C6Du;
+        x ^= x >> 12;
+        moves[e * 4 + (threadIdx.x & 3)] = (int32_t)((x >> 8) % 6u);
+    }
+}
+int pom_bench_policy(const uint8_t* codes_dev, int32_t* moves_dev, int64_t first, int64_t count, uint32_t tick, void* stream)
+{
+    if (!moves_dev || first < 0 || count < 0) return POM_E_ARG;
+    if (count == 0) return POM_OK;
+    pom_bench_policy_kernel<<<dim3((unsigned)((count + 63) / 64)), dim3(256), 0, (hipStream_t)stream>>>(codes_dev, moves_dev, first, count, tick);
+    HIPCHK(hipGetLastError());
+    return POM_OK;
 }
 
 int pom_batch_generate(PomBatch* h, uint64_t board_seed)
