@@ -875,6 +875,10 @@ def worker(args) -> None:
                 "per_gpu_batch_note": (f"{ENVS_PER_GPU_SHARDED} envs per GPU at every N (the headline's batch: weak scaling with the per-GPU "
                                        "work fixed); BASELINE config 4 (262,144 envs on 8 GPUs) is `--gpus 8 --envs 32768`"),
                 "episodes_finished": episodes_finished,
+                # which of BASELINE.json's configs this line is (None: a shape BASELINE does not list, e.g. 65,536 envs on each of N > 1 GPUs)
+                "baseline_config": (4 if c4 else 3 if (args.policy == "simple" and args.envs == 65536 and world == 1) else
+                                    5 if (args.kind == "stress" and args.envs == 65536 and world == 1) else
+                                    2 if (args.envs == 4096 and world == 1 and args.policy == "random" and args.kind == "ffa") else None),
                 "single_gpu_base": single_base,
             },
             "roofline": {

@@ -265,6 +265,28 @@ int32_t pom_oracle_simple_act(const void* state, int id, PomSimpleMem* mem, int 
     return mv;
 }
 
+/* the strategy helpers by themselves, for the vectors recorded from the compiled reference (tests/golden/policy_traces.npz;
+ * the reference's own [strategy] tests call them: unit_test/bboard/strategy_test.cpp) */
+int32_t pom_oracle_is_adjacent_enemy(const void* state, int id, int distance) { return is_adjacent_enemy((const PomState*)state, id, distance); }
+void pom_oracle_fill_rmap(const void* state, int id, int32_t* map121, int32_t* move_to121)
+{
+    RMap r;
+    fill_rmap((const PomState*)state, &r, id);
+    for (int y = 0; y < N; y++)
+        for (int x = 0; x < N; x++) {
+            map121[y * N + x] = r.map[y][x];
+            const int ask = rm_dist(&r, x, y) != 0 && !(x == r.source.x && y == r.source.y);
+            move_to121[y * N + x] = ask ? move_towards_position(&r, (Pos){ x, y }) : -1;
+        }
+}
+/* the draw (0..4) that agent `agent` of env `env` is handed on tick `tick` of the synthetic stream (include/pom_rng.h), as
+ * pom_oracle_simple_policy and the device policy take it */
+int32_t pom_oracle_policy_draw(uint64_t seed, uint32_t env, uint32_t tick, int agent)
+{
+    const uint64_t r = pom_rng_draw(seed, env, tick);
+    return (int32_t)((((uint32_t)(r >> (16 * agent)) & 0xFFFFu) * 5u) >> 16);
+}
+
 /* one round of act() for n envs: what pom_batch_policy_simple computes.  done[e] != 0 marks a finished env (all IDLE). */
 void pom_oracle_simple_policy(const void* states, PomSimpleMem* mems, int n, uint64_t seed, int first_env, int tick,
                               const int32_t* done, int32_t* moves_out)

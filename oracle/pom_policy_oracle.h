@@ -24,6 +24,12 @@ typedef struct PomSimpleMem {
  * intDist(rng) call returns (uniform 0..4).  Returns the Move and updates the memory. */
 int32_t pom_oracle_simple_act(const void* state, int id, PomSimpleMem* mem, int draw);
 
+/* strategy::IsAdjacentEnemy (strategy.cpp:297-313); strategy::FillRMap's raw map (distance | predecessor << 16) and, per reachable
+ * cell other than the source, MoveTowardsPosition's answer (-1 elsewhere) (strategy.cpp:59-121); the stream's draw for an act() */
+int32_t pom_oracle_is_adjacent_enemy(const void* state, int id, int distance);
+void pom_oracle_fill_rmap(const void* state, int id, int32_t* map121, int32_t* move_to121);
+int32_t pom_oracle_policy_draw(uint64_t seed, uint32_t env, uint32_t tick, int agent);
+
 /* one round of act() for n envs (what pom_batch_policy_simple computes); done[e] != 0 marks a finished env (all IDLE) */
 void pom_oracle_simple_policy(const void* states, PomSimpleMem* mems, int n, uint64_t seed, int first_env, int tick,
                               const int32_t* done, int32_t* moves_out);

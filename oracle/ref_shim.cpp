@@ -144,6 +144,24 @@ void ref_simple_memory(void* p, int* out16)
     out16[14] = a->moveQueue.index;
     out16[15] = a->moveQueue.count;
 }
+/* the strategy helpers the reference's own [strategy] tests call (unit_test/bboard/strategy_test.cpp): IsAdjacentEnemy, and FillRMap
+ * with what MoveTowardsPosition makes of it — the raw map (distance | predecessor << 16 per cell) and, for every reachable cell
+ * other than the source, the first move of the path to it (-1 elsewhere: the reference spins forever when asked for those) */
+int ref_is_adjacent_enemy(const void* state, int id, int distance)
+{
+    return strategy::IsAdjacentEnemy(*static_cast<const State*>(state), id, distance) ? 1 : 0;
+}
+void ref_fill_rmap(const void* state, int id, int* map121, int* move_to121)
+{
+    strategy::RMap r;
+    strategy::FillRMap(*static_cast<const State*>(state), r, id);
+    for (int y = 0; y < BOARD_SIZE; y++)
+        for (int x = 0; x < BOARD_SIZE; x++) {
+            map121[y * BOARD_SIZE + x] = r.map[y][x];
+            const bool ask = strategy::IsReachable(r, x, y) && !(x == r.source.x && y == r.source.y);
+            move_to121[y * BOARD_SIZE + x] = ask ? int(strategy::MoveTowardsPosition(r, {x, y})) : -1;
+        }
+}
 void ref_simple_set_memory(void* p, const int* in16)
 {
     agents::SimpleAgent* a = static_cast<agents::SimpleAgent*>(p);

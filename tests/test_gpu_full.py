@@ -45,8 +45,9 @@ def test_full_size_is_deterministic_residency_invariant_and_matches_oracle_sampl
 
 
 def test_262144_envs_step_counts_and_shard_equivalence(hip_lib, oracle):
-    """Config 4's size on one GPU: stepping the whole batch equals stepping its 4 shards with env_offset, and two slices of it
-    (one in the middle, one across the last shard's boundary) equal the oracle."""
+    """Config 4's size on one GPU: stepping the whole batch equals stepping its shards with env_offset — 4 of 65,536 and the 8 of
+    32,768 that BASELINE's config 4 names — and slices of it (in the middle, across a shard boundary, inside two of the 8 shards)
+    equal the oracle."""
     n, ticks, seed = 262144, 40, 5
     start = pa.make_boards(n, seed=3)
     with BatchEnvironment(n, mode=MODE_ENV, auto_reset=True, max_steps=800) as env:
@@ -64,6 +65,22 @@ def test_262144_envs_step_counts_and_shard_equivalence(hip_lib, oracle):
             env.make_game(start[k * q:(k + 1) * q])
             env.step_random(seed, DIST_RANDOM, ticks=ticks)
             assert _digest(env.get_state()) == _digest(whole[k * q:(k + 1) * q])
+    # config 4 as BASELINE states it: 8 shards of 32,768 (`bench.py --gpus 8 --envs 32768`: rank r owns envs [r * 32768, (r + 1) * 32768),
+    # env_offset keys its move stream) — every shard, and an oracle slice inside each of two of them
+    q8 = n // 8
+    assert q8 == 32768
+    for k in range(8):
+        with BatchEnvironment(q8, mode=MODE_ENV, auto_reset=True, max_steps=800, env_offset=k * q8) as env:
+            env.make_game(start[k * q8:(k + 1) * q8])
+            env.step_random(seed, DIST_RANDOM, ticks=ticks)
+            got = env.get_state()
+            assert env.counters()[CNT_STEPS] == q8 * ticks
+        assert _digest(got) == _digest(whole[k * q8:(k + 1) * q8]), k
+        if k in (2, 7):
+            lo = k * q8 + 30000
+            want = np.ascontiguousarray(start[lo:lo + 1536]).copy()
+            oracle.run_random(want, np.ascontiguousarray(start[lo:lo + 1536]), ticks, seed, lo, 0, DIST_RANDOM, 800)
+            assert _digest(got[30000:31536]) == _digest(want), k
 
 
 def test_1048576_envs_beyond_the_memory_side_cache(hip_lib, oracle):
