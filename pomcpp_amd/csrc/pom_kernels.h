@@ -47,11 +47,22 @@ static_assert(POM_REC_DWORDS % 2 == 0, "the one-lane shapes move the record in g
  *          parts; their cross-lane traffic is DPP quad permutes (one VALU op, no LDS).
  * The LDS tile is [row][EPW]; bank = (row*EPW + env) mod 32; the G lanes of an env read the same address (broadcast).
  */
+/* Where cell c of the wavefront's env number el lives in the LDS tile, in bytes.  The tile is a copy of 64 / 16 ... EPW / 16 HBM tiles
+ * side by side, row for row, and an HBM tile's board is laid out by cell (pom_packed.h): for the shipped 16 envs per wavefront the
+ * offset is c * 16 + el — ONE v_lshl_add_u32 per access. */
+template <int EPW>
+__device__ __forceinline__ int tile_cell_byte(int el, int c)
+{
+    return EPW == 16 ? c * 16 + el : (c >> 2) * (4 * EPW) + (c & 3) * 16 + (el >> 4) * 64 + (el & 15);
+}
+
 template <int EPW, int GG>
 struct LdsEnv {
     static constexpr int G = GG;
     uint32_t* t; /* &tile[env_in_wave] */
     int sub_;    /* lane's index within its env's group; 0 = owner */
+    uint8_t* b;  /* the env's cell 0 (tile_cell_byte) */
+    __device__ LdsEnv(uint32_t* tile, int el, int sub) : t(tile + el), sub_(sub), b(reinterpret_cast<uint8_t*>(tile) + tile_cell_byte<EPW>(el, 0)) {}
     __device__ int sub() const { return G == 1 ? 0 : sub_; }
     __device__ bool owner() const { return G == 1 || sub_ == 0; }
     /* quad reductions: lane ^ 1, then lane ^ 2 */
@@ -86,8 +97,8 @@ struct LdsEnv {
     /* "the other lanes' LDS writes so far are visible from here on": true at every instruction of a wavefront in lock-step, so
      * nothing to do; the four-lane host model of tests/emul makes its lanes meet here */
     __device__ void sync() const {}
-    __device__ int cell(int c) const { return reinterpret_cast<const uint8_t*>(t)[(c >> 2) * (4 * EPW) + (c & 3)]; }
-    __device__ void put_cell(int c, int v) { reinterpret_cast<uint8_t*>(t)[(c >> 2) * (4 * EPW) + (c & 3)] = (uint8_t)v; }
+    __device__ int cell(int c) const { return b[EPW == 16 ? c * 16 : (c >> 2) * (4 * EPW) + (c & 3) * 16]; }
+    __device__ void put_cell(int c, int v) { b[EPW == 16 ? c * 16 : (c >> 2) * (4 * EPW) + (c & 3) * 16] = (uint8_t)v; }
     __device__ int bomb(int s) const { return (int)t[(ROW_BOMBS + s) * EPW]; }
     __device__ void put_bomb(int s, int v) { t[(ROW_BOMBS + s) * EPW] = (uint32_t)v; }
     __device__ int flame(int s) const { return (int)t[(ROW_FLAMES + s) * EPW]; }
@@ -145,22 +156,22 @@ struct StepParams {
 };
 
 /*
- * One env's start board (pom_boardgen.h), drawn by the whole wavefront into column `col` (= &tile[env_in_wave]) of an
+ * One env's start board (pom_boardgen.h), drawn by the whole wavefront into the column of env number `el` of an
  * [row][EPW] tile with ROWS rows.  `key` must be wave-uniform.  Lane l draws cells l and l+64; the two ballots of "wood" are
  * the wood set, so the flag pass runs on uniform values (scalar unit) and only its few cell writes touch a lane.
  */
 template <int EPW, int ROWS>
-__device__ __forceinline__ void pom_boardgen_wave(uint32_t* col, uint32_t key, int lane)
+__device__ __forceinline__ void pom_boardgen_wave(uint32_t* tile, int el, uint32_t key, int lane)
 {
-    uint8_t* cells = reinterpret_cast<uint8_t*>(col);
+    uint32_t* col = tile + el;
+    uint8_t* cells = reinterpret_cast<uint8_t*>(tile);
     const uint32_t k0 = pom_board_cell_kind(key, lane);
-    cells[(lane >> 2) * (4 * EPW) + (lane & 3)] = (uint8_t)pom_board_cell_code(k0);
-    const int c1 = lane + 64;
+    cells[tile_cell_byte<EPW>(el, lane)] = (uint8_t)pom_board_cell_code(k0);
+    const int c1 = lane + 64; /* cells 64..123: the three behind the board are 0, as pom_pack_state writes them */
     uint32_t k1 = 0u;
-    if (c1 < POM_CELLS) {
-        k1 = pom_board_cell_kind(key, c1);
-        if (c1 == POM_CELLS - 1) col[(c1 >> 2) * EPW] = (uint32_t)pom_board_cell_code(k1); /* the last dword's unused bytes: 0, as pom_pack_state writes them */
-        else cells[(c1 >> 2) * (4 * EPW) + (c1 & 3)] = (uint8_t)pom_board_cell_code(k1);
+    if (c1 < 4 * POM_REC_BOARD_DWORDS) {
+        k1 = c1 < POM_CELLS ? pom_board_cell_kind(key, c1) : 0u;
+        cells[tile_cell_byte<EPW>(el, c1)] = (uint8_t)pom_board_cell_code(k1);
     }
     const uint64_t w0 = __ballot(k0 == 2u), w1 = __ballot(k1 == 2u);
     const int r = POM_REC_TIMESTEP + lane;
@@ -196,12 +207,9 @@ __device__ __forceinline__ void pom_boardgen_wave(uint32_t* col, uint32_t key, i
             }
         }
     }
-    if ((ch0 >> lane) & 1) cells[(lane >> 2) * (4 * EPW) + (lane & 3)] = (uint8_t)pom_board_flag_code(key, lane);
-    if ((ch1 >> lane) & 1) cells[(c1 >> 2) * (4 * EPW) + (c1 & 3)] = (uint8_t)pom_board_flag_code(key, c1);
-    if (lane < POM_AGENT_COUNT) {
-        const int c = pom_corner_cell(lane);
-        cells[(c >> 2) * (4 * EPW) + (c & 3)] = (uint8_t)(POM_C_AGENT + lane);
-    }
+    if ((ch0 >> lane) & 1) cells[tile_cell_byte<EPW>(el, lane)] = (uint8_t)pom_board_flag_code(key, lane);
+    if ((ch1 >> lane) & 1) cells[tile_cell_byte<EPW>(el, c1)] = (uint8_t)pom_board_flag_code(key, c1);
+    if (lane < POM_AGENT_COUNT) cells[tile_cell_byte<EPW>(el, pom_corner_cell(lane))] = (uint8_t)(POM_C_AGENT + lane);
 }
 
 /*
@@ -296,12 +304,29 @@ __device__ __forceinline__ void store_tile16_x4(uint32_t* base, int64_t np, cons
  * tile column.  `src` = &snap[e * POM_REC_DWORDS]; ROWS = how many leading rows the caller needs.
  */
 template <int EPW, int ROWS = POM_REC_DWORDS>
-__device__ __forceinline__ void restart_column(uint32_t* col, const uint32_t* src, int lane)
+__device__ __forceinline__ void restart_column(uint32_t* tile, int el, const uint32_t* src, int lane)
 {
     const uint32_t v0 = src[lane];
     const uint32_t v1 = lane + 64 < ROWS ? src[lane + 64] : 0u;
-    col[lane * EPW] = v0;
-    if (lane + 64 < ROWS) col[(lane + 64) * EPW] = v1;
+    if (lane < POM_REC_BOARD_DWORDS) { /* a dense record holds four cells per dword, the tile lays the board out by cell */
+        uint8_t* cells = reinterpret_cast<uint8_t*>(tile);
+#pragma unroll
+        for (int j = 0; j < 4; j++) cells[tile_cell_byte<EPW>(el, 4 * lane + j)] = (uint8_t)(v0 >> (8 * j));
+    } else tile[lane * EPW + el] = v0;
+    if (lane + 64 < ROWS) tile[(lane + 64) * EPW + el] = v1;
+}
+/* the other way: env number el's column of the tile as a dense record (terminal buffer, snapshot) */
+template <int EPW>
+__device__ __forceinline__ void column_to_record(const uint32_t* tile, int el, uint32_t* dst, int lane)
+{
+    if (lane < POM_REC_BOARD_DWORDS) {
+        const uint8_t* cells = reinterpret_cast<const uint8_t*>(tile);
+        uint32_t v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) v |= (uint32_t)cells[tile_cell_byte<EPW>(el, 4 * lane + j)] << (8 * j);
+        dst[lane] = v;
+    } else dst[lane] = tile[lane * EPW + el];
+    if (lane + 64 < POM_REC_DWORDS) dst[lane + 64] = tile[(lane + 64) * EPW + el];
 }
 
 /* the register-resident rows (timeStep, meta, agents) of one env, out of / into its tile column */
@@ -318,6 +343,7 @@ __device__ __forceinline__ void lane_from_tile(PomLane& L, int& time_step, uint3
 
 /* the four lanes of an env as the SimpleAgent policy sees them (pom_policy_body.h): lane = agent, 16 envs per wavefront */
 struct PolicyStore {
+    const uint32_t* tile0; /* the wavefront's tile */
     const uint32_t* t; /* &tile[env_in_wave], row stride 16 dwords */
     uint8_t* dcol;     /* &danger[env_in_wave], a byte per cell, row stride 16 */
     uint32_t* scol;    /* &sets[env_in_wave], row stride 16 */
@@ -331,8 +357,13 @@ struct PolicyStore {
     __device__ void danger_put(int c, int tm) { dcol[c * 16] = (uint8_t)tm; }
     __device__ uint32_t setw(int k) const { return scol[k * 16]; }
     __device__ void set_put(int k, uint32_t bits) { scol[k * 16] = bits; }
-    __device__ uint32_t board_word(int k) const { return t[k * 16]; }
-    __device__ int cell(int c) const { return reinterpret_cast<const uint8_t*>(t)[(c >> 2) * 64 + (c & 3)]; }
+    /* (t = tile + env: the env's cell c is the tile's byte c * 16 + env, pom_packed.h) */
+    __device__ int cell(int c) const { return reinterpret_cast<const uint8_t*>(t)[c * 16 - 3 * (int)(t - tile0)]; }
+    __device__ uint32_t cells4(int k) const /* the codes of cells 4k .. 4k+3, a byte each */
+    {
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(tile0) + (t - tile0) + 64 * k;
+        return (uint32_t)b[0] | ((uint32_t)b[16] << 8) | ((uint32_t)b[32] << 16) | ((uint32_t)b[48] << 24);
+    }
     __device__ int bomb(int s) const { return (int)t[(POM_REC_BOMBS + s) * 16]; }
 };
 
@@ -725,8 +756,8 @@ __device__ __forceinline__ void pom_observe_stage(const uint32_t* tile, uint4* s
         for (int i = 0; i < ROW_IT; i++) {
             const int r = j + LPE * i;
             const int ok = (LPE * i + LPE - 1 < UNITS) | (int)(r < UNITS); /* (a lane past the board reads some other row of the tile) */
-            const uint32_t w = tile[(POM_REC_BOARD + (r >> 1)) * 16 + ec] >> (16 * (r & 1));
-            const int lo = (int)(w & 0xFF), hi = (int)((w >> 8) & 0xFF);
+            const uint8_t* tile_b = reinterpret_cast<const uint8_t*>(tile); /* the board by cell: cell c of env ec at byte c * 16 + ec */
+            const int lo = tile_b[(2 * r) * 16 + ec], hi = tile_b[(2 * r + 1) * 16 + ec];
             const int f0 = put(lo, 2 * r, ok);
             const int f1 = put(hi, 2 * r + 1, ok & (int)(r < UNITS - 1)); /* the board's last unit holds one cell */
             if (f0 | f1) {
@@ -1075,7 +1106,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     lane_from_tile(L, time_step, status, t, EPW);
     bool restarted = false;
 
-    LdsEnv<EPW, G> acc{t, member};
+    LdsEnv<EPW, G> acc(tile, ec, member);
     PomStepper<LdsEnv<EPW, G>> stepper(acc, L);
 #if defined(POM_TRUNC)
     L.trunc = p.trunc;
@@ -1107,7 +1138,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                 }
                 ep = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)ep, src));
                 const uint32_t key = pom_board_key(p.board_seed, (uint32_t)(p.env_offset + tile_id * EPW + ec_u), ep);
-                pom_boardgen_wave<EPW, POM_REC_DWORDS>(tile + ec_u, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), lane);
+                pom_boardgen_wave<EPW, POM_REC_DWORDS>(tile, ec_u, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), lane);
             }
             asm volatile("" ::: "memory"); /* other lanes wrote this lane's column: no read of it may be scheduled earlier */
             if (reload) lane_from_tile(L, time_step, status, t, EPW); /* the register-resident rows, from the new record */
@@ -1124,7 +1155,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                     const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)todo) - 1); /* an owner lane */
                     todo &= todo - 1;
                     const int ec_u = G == 1 ? src : src >> 2;
-                    restart_column<EPW>(tile + ec_u, p.snap + (tile_id * EPW + ec_u) * POM_REC_DWORDS, lane);
+                    restart_column<EPW>(tile, ec_u, p.snap + (tile_id * EPW + ec_u) * POM_REC_DWORDS, lane);
                 } while (todo);
                 asm volatile("" ::: "memory"); /* other lanes wrote this lane's column: no read of it may be scheduled earlier */
                 if (reload) lane_from_tile(L, time_step, status, t, EPW); /* the register-resident rows, from the new record */
@@ -1141,7 +1172,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
             }
             if (restarted) m0 = m1 = 0; /* a new game gets fresh agents */
             restarted = false;
-            PolicyStore st{t, danger + ec, sets + ec, member};
+            PolicyStore st{tile, t, danger + ec, sets + ec, member};
 #if defined(POM_TRUNC)
             st.trunc = p.trunc; /* cuts -4 .. -1: none of the policy, + clear, + fill, + safe (act and the tick skipped); 0: the whole policy */
             if (active) {
@@ -1208,9 +1239,9 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
             if (POLICY) {
                 /* a fresh view of the tile for the tick: keeps the compiler from computing the tick's addresses before the
                  * policy and carrying them through it (the fused kernel otherwise wants 170 VGPRs) */
-                uint32_t* t2 = t;
+                uint32_t* t2 = tile;
                 asm volatile("" : "+v"(t2));
-                LdsEnv<EPW, G> acc2{t2, member};
+                LdsEnv<EPW, G> acc2(t2, ec, member);
                 PomStepper<LdsEnv<EPW, G>> stepper2(acc2, L);
                 stepper2.step_packed(mvp);
             } else {
@@ -1252,8 +1283,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                     const int ec_u = G == 1 ? src : src >> 2;
                     const int64_t e_u = tile_id * EPW + ec_u;
                     uint32_t* tr = p.terminal + e_u * POM_REC_DWORDS;
-                    tr[lane] = tile[lane * EPW + ec_u];
-                    if (lane + 64 < POM_REC_DWORDS) tr[lane + 64] = tile[(lane + 64) * EPW + ec_u];
+                    column_to_record<EPW>(tile, ec_u, tr, lane);
                     if (FRESH) {
                         uint32_t ep = 0;
                         if (lane == src) {
@@ -1262,9 +1292,9 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                         }
                         ep = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)ep, src));
                         const uint32_t key = pom_board_key(p.board_seed, (uint32_t)(p.env_offset + e_u), ep);
-                        pom_boardgen_wave<EPW, POM_REC_DWORDS>(tile + ec_u, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), lane);
+                        pom_boardgen_wave<EPW, POM_REC_DWORDS>(tile, ec_u, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), lane);
                     } else {
-                        restart_column<EPW>(tile + ec_u, p.snap + e_u * POM_REC_DWORDS, lane);
+                        restart_column<EPW>(tile, ec_u, p.snap + e_u * POM_REC_DWORDS, lane);
                     }
                 } while (todo);
                 asm volatile("" ::: "memory");
@@ -1510,9 +1540,9 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
                 const uint32_t ep = p.episode[tile_id * 16 + ec_u] + 1u;
                 const uint32_t key = pom_board_key(p.board_seed, (uint32_t)(p.env_offset + tile_id * 16 + ec_u),
                                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)ep));
-                pom_boardgen_wave<16, POL_ROWS>(tile + ec_u, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), lane);
+                pom_boardgen_wave<16, POL_ROWS>(tile, ec_u, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), lane);
             } else {
-                restart_column<16, POL_ROWS>(tile + ec_u, p.snap + (tile_id * 16 + ec_u) * POM_REC_DWORDS, lane);
+                restart_column<16, POL_ROWS>(tile, ec_u, p.snap + (tile_id * 16 + ec_u) * POM_REC_DWORDS, lane);
             }
         }
         asm volatile("" ::: "memory");
@@ -1529,7 +1559,7 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
     E.bCnt = (int)((meta >> 16) & 0xFF);
     const bool frozen = env_mode && ((meta2 >> 8) & POM_ST_DONE); /* finished and not restarted: Environment::Step returns */
     int mv = POM_MOVE_IDLE;
-    PolicyStore st{t, danger + ec, sets + ec, id};
+    PolicyStore st{tile, t, danger + ec, sets + ec, id};
     POM_PSTAMP(POM_PP_LOAD);
     if (e < p.n && !frozen) { /* all four lanes of the env, dead agents' lanes included */
         pom_policy_prepare_clear(st);
@@ -1601,15 +1631,13 @@ __global__ __launch_bounds__(64) void pom_generate_kernel(uint32_t* state, uint3
         __syncthreads();
     }
     for (int ec = 0; ec < 16 && tile_id * 16 + ec < n; ec++)
-        pom_boardgen_wave<16, POM_REC_DWORDS>(tile + ec, pom_board_key(board_seed, (uint32_t)(env_offset + tile_id * 16 + ec), 0u), lane);
+        pom_boardgen_wave<16, POM_REC_DWORDS>(tile, ec, pom_board_key(board_seed, (uint32_t)(env_offset + tile_id * 16 + ec), 0u), lane);
     if (tile_id * 16 + lane < n && lane < 16) episode[tile_id * 16 + lane] = 0u;
     __syncthreads();
     /* whole tiles: the buffers hold n_pad columns; columns past n are blank records here, as after creation */
     store_tile16_x4(state + tile_id * POM_TILE_DWORDS, POM_TILE_ENVS, tile, lane);
     for (int ec = 0; ec < 16; ec++) { /* the snapshot: array of structs (restart_column); columns past n are blank like the state's */
-        uint32_t* rec = snap + (tile_id * 16 + ec) * POM_REC_DWORDS;
-        rec[lane] = tile[lane * 16 + ec];
-        if (lane + 64 < POM_REC_DWORDS) rec[lane + 64] = tile[(lane + 64) * 16 + ec];
+        column_to_record<16>(tile, ec, snap + (tile_id * 16 + ec) * POM_REC_DWORDS, lane);
     }
 }
 
@@ -1621,7 +1649,7 @@ __global__ void pom_pack_kernel(const int32_t* __restrict__ aos, int64_t first, 
     if (i >= count) return;
     uint32_t* col = state + pom_rec_col(first + i);
     const int64_t rs = POM_TILE_ENVS; /* row stride of a column */
-    int bad = pom_pack_state(aos + i * (POM_STATE_BYTES / 4), col, rs);
+    int bad = pom_pack_state(aos + i * (POM_STATE_BYTES / 4), col, rs, (int)((first + i) & 15));
     /* live bombs must sit on the board and belong to a real agent: they index cells and agents */
     {
         const uint32_t m = col[POM_REC_META * rs];
@@ -1635,18 +1663,20 @@ __global__ void pom_pack_kernel(const int32_t* __restrict__ aos, int64_t first, 
     }
     if (bad) {
         atomicMin(first_bad, (int)(i > INT_MAX - 1 ? INT_MAX - 1 : i));
-        for (int d = 0; d < POM_REC_DWORDS; d++) col[d * rs] = 0; /* inert blank board ... */
+        for (int c = 0; c < 4 * POM_REC_BOARD_DWORDS; c++) pom_rec_set_cell(col, rs, c, 0, (int)((first + i) & 15)); /* inert blank board ... */
+        for (int d = POM_REC_TIMESTEP; d < POM_REC_DWORDS; d++) col[d * rs] = 0;
         col[POM_REC_META2 * rs] = (uint32_t)POM_ST_DONE << 8;     /* ... that is never stepped in ENV mode */
     }
-    uint32_t* s = snap + (first + i) * POM_REC_DWORDS; /* the snapshot is array-of-structs (restart_column) */
-    for (int d = 0; d < POM_REC_DWORDS; d++) s[d] = col[d * rs];
+    uint32_t* s = snap + (first + i) * POM_REC_DWORDS; /* the snapshot is array-of-structs (restart_column): a dense record */
+    for (int c = 0; c < 4 * POM_REC_BOARD_DWORDS; c++) pom_rec_set_cell(s, 1, c, pom_rec_cell(col, rs, c, (int)((first + i) & 15)));
+    for (int d = POM_REC_TIMESTEP; d < POM_REC_DWORDS; d++) s[d] = col[d * rs];
 }
 
 __global__ void pom_unpack_kernel(const uint32_t* __restrict__ state, int64_t first, int64_t count, int64_t np, int32_t* aos)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    pom_unpack_state(state + pom_rec_col(first + i), POM_TILE_ENVS, aos + i * (POM_STATE_BYTES / 4));
+    pom_unpack_state(state + pom_rec_col(first + i), POM_TILE_ENVS, aos + i * (POM_STATE_BYTES / 4), (int)((first + i) & 15));
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -1693,9 +1723,9 @@ __global__ __launch_bounds__(64) void pom_step_one_kernel(StepOneParams q)
     {
         const int c = lane + 64, e0 = pom_cell_encode(st[lane], lane), e1 = c < POM_CELLS ? pom_cell_encode(st[c], c) : 0;
         bad |= (e0 < 0) | (e1 < 0);
-        uint8_t* cells = reinterpret_cast<uint8_t*>(tile);
-        cells[(lane >> 2) * 64 + (lane & 3)] = (uint8_t)e0; /* (the tile was zeroed: the three bytes past cell 120 stay 0) */
-        if (c < POM_CELLS) cells[(c >> 2) * 64 + (c & 3)] = (uint8_t)e1;
+        uint8_t* cells = reinterpret_cast<uint8_t*>(tile); /* env 0 of the tile: cell c at byte c * 16 */
+        cells[lane * 16] = (uint8_t)e0; /* (the tile was zeroed: the three bytes past cell 120 stay 0) */
+        if (c < POM_CELLS) cells[c * 16] = (uint8_t)e1;
     }
     const int32_t alive = st[122], bIdx = st[167], bCnt = st[168], fIdx = st[249], fCnt = st[250];
     if (lane == 61) {
@@ -1756,7 +1786,7 @@ __global__ __launch_bounds__(64) void pom_step_one_kernel(StepOneParams q)
 #if defined(POM_TRUNC)
     L.trunc = 990;
 #endif
-    LdsEnv<16, 4> acc{t, member};
+    LdsEnv<16, 4> acc(tile, ec, member);
     PomStepper<LdsEnv<16, 4>> stepper(acc, L);
     const bool env_mode = p.mode == POM_MODE_ENV;
     if (ec == 0) {
@@ -1783,8 +1813,8 @@ __global__ __launch_bounds__(64) void pom_step_one_kernel(StepOneParams q)
     /* unpack column 0 (pom_unpack_state, a few State dwords per lane) straight into host memory */
     int32_t* out = p.io + POM_ONE_OUT;
     const uint32_t m = tile[POM_REC_META * 16], m2 = tile[POM_REC_META2 * 16];
-    out[lane] = pom_cell_decode(pom_rec_cell(tile, 16, lane), lane);
-    if (lane + 64 < POM_CELLS) out[lane + 64] = pom_cell_decode(pom_rec_cell(tile, 16, lane + 64), lane + 64);
+    out[lane] = pom_cell_decode(pom_rec_cell(tile, 16, lane, 0), lane);
+    if (lane + 64 < POM_CELLS) out[lane + 64] = pom_cell_decode(pom_rec_cell(tile, 16, lane + 64, 0), lane + 64);
     if (lane == 61) {
         out[121] = (int32_t)tile[POM_REC_TIMESTEP * 16];
         out[122] = pom_sext8(m);
@@ -1868,10 +1898,13 @@ __global__ void pom_snapshot_kernel(const uint32_t* __restrict__ state, uint32_t
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= np) return;
-    for (int d = 0; d < POM_REC_DWORDS; d++) {
-        uint32_t v = state[pom_rec_col(e) + d * POM_TILE_ENVS];
+    const uint32_t* col = state + pom_rec_col(e);
+    uint32_t* rec = snap + e * POM_REC_DWORDS; /* array of structs (restart_column): a dense record */
+    for (int c = 0; c < 4 * POM_REC_BOARD_DWORDS; c++) pom_rec_set_cell(rec, 1, c, pom_rec_cell(col, POM_TILE_ENVS, c, (int)(e & 15)));
+    for (int d = POM_REC_TIMESTEP; d < POM_REC_DWORDS; d++) {
+        uint32_t v = col[d * POM_TILE_ENVS];
         if (d == POM_REC_META2) v &= 0xFFu; /* a snapshot starts an episode: status and flags clear */
-        snap[e * POM_REC_DWORDS + d] = v;    /* array of structs (restart_column) */
+        rec[d] = v;
     }
 }
 

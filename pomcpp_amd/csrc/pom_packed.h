@@ -3,15 +3,19 @@
  * lossless conversion from / to the 1004-byte boundary State (pom_state.h,
  * i.e. bboard::State, /root/reference/include/bboard.hpp:356-506).
  *
- * HBM layout: an array of 16-env TILES, struct-of-arrays inside a tile — dword d of env e lives at
- * buf[(e / 16) * 1312 + d * 16 + (e % 16)] (pom_rec_col, row stride POM_TILE_ENVS).  A tile is 5,248
+ * HBM layout: an array of 16-env TILES, struct-of-arrays inside a tile — dword d >= 31 of env e lives at
+ * buf[(e / 16) * 1312 + d * 16 + (e % 16)] (pom_rec_col, row stride POM_TILE_ENVS), and the board — the tile's first 31 rows,
+ * 1,984 bytes — is laid out BY CELL: cell c of env e is byte c * 16 + (e % 16) of the tile (cells 121..123: zero), so that the
+ * address of a cell in the wavefront's LDS copy of the tile is one shift-and-add of the cell number (round 5; with the cells of
+ * an env packed four to a dword it was four instructions, and the tick does little else with its vector ALU than look at cells).  A tile is 5,248
  * contiguous bytes (41 lines of 128 B): the wavefront that owns it moves it with five 1-KB instructions (16 bytes per lane)
  * and one of 128 bytes, every cache line full in both directions, and touches ONE region of memory instead of 82 rows that
  * lie n_pad * 4 bytes apart (rounds 1-2: 4.35 G env-steps/s at 524,288 envs against 6.5 G at 262,144 —
  * beyond the memory-side cache the strided rows cost DRAM and TLB locality).
  *
  * POM_REC_DWORDS = 82 dwords (328 B) per env instead of 251 (rounds 1-4: 112, with 16-bit cells):
- *   [0..30]    board, 121 cells of 8 bits (cell c in byte c&3 of dword c>>2; the last three bytes 0)
+ *   [0..30]    board, 121 cells of 8 bits (a dense record — snapshot, terminal, host tests: cell c in byte c&3 of dword c>>2, the
+ *              last three bytes 0; a tile: see above)
  *   [31]       timeStep
  *   [32]       aliveAgents:8 | bombs.index:8 | bombs.count:8 | flames.index:8
  *   [33]       flames.count:8 | status:8 | ubflags:16
@@ -118,8 +122,17 @@ POM_HD int pom_flame_origin(int e, int c)
     return c - d * (r == 0 ? 1 : r == 1 ? -1 : r == 2 ? POM_BOARD_SIZE : -POM_BOARD_SIZE);
 }
 
-/* cell c of a record addressed with a stride (a column of a device tile: POM_TILE_ENVS; a dense record: 1) */
-POM_HD int pom_rec_cell(const uint32_t* rec, int64_t stride, int c) { return (int)((rec[(POM_REC_BOARD + (c >> 2)) * stride] >> (8 * (c & 3))) & 0xFFu); }
+/* Where cell c of a record lives.  `rec` with stride 1: a dense record.  `rec` with stride POM_TILE_ENVS: the column of env
+ * number `lane` (0..15) of a tile, i.e. rec = tile + lane — its board is the tile's byte c * 16 + lane. */
+POM_HD int64_t pom_rec_cell_byte(int64_t stride, int lane, int c) { return stride == 1 ? (int64_t)c : (int64_t)c * POM_TILE_ENVS + lane - 4 * (int64_t)lane; }
+POM_HD int pom_rec_cell(const uint32_t* rec, int64_t stride, int c, int lane = 0)
+{
+    return reinterpret_cast<const uint8_t*>(rec)[pom_rec_cell_byte(stride, lane, c)];
+}
+POM_HD void pom_rec_set_cell(uint32_t* rec, int64_t stride, int c, int code, int lane = 0)
+{
+    reinterpret_cast<uint8_t*>(rec)[pom_rec_cell_byte(stride, lane, c)] = (uint8_t)code;
+}
 
 /*
  * Pack one boundary State into a record.  `rec` is addressed with a stride so
@@ -127,7 +140,7 @@ POM_HD int pom_rec_cell(const uint32_t* rec, int64_t stride, int c) { return (in
  * record in host-side tests (stride = 1).  Returns 0, or 1 if a field does not
  * fit the record (nothing is written in that case... the caller zero-fills).
  */
-POM_HD int pom_pack_state(const int32_t* st, uint32_t* rec, int64_t stride)
+POM_HD int pom_pack_state(const int32_t* st, uint32_t* rec, int64_t stride, int lane = 0)
 {
     const int32_t* board = st;                 /* @0    */
     const int32_t timeStep = st[121];          /* @484  */
@@ -137,14 +150,10 @@ POM_HD int pom_pack_state(const int32_t* st, uint32_t* rec, int64_t stride)
     const int32_t* flames = st + 169;          /* @676  */
     int bad = 0;
 
-    for (int k = 0; k < POM_REC_BOARD_DWORDS; k++) {
-        uint32_t w = 0;
-        for (int j = 0; j < 4 && 4 * k + j < POM_CELLS; j++) {
-            const int e = pom_cell_encode(board[4 * k + j], 4 * k + j);
-            bad |= e < 0;
-            w |= (uint32_t)(e & 0xFF) << (8 * j);
-        }
-        rec[(POM_REC_BOARD + k) * stride] = w;
+    for (int c = 0; c < 4 * POM_REC_BOARD_DWORDS; c++) {
+        const int e = c < POM_CELLS ? pom_cell_encode(board[c], c) : 0; /* (the three bytes behind the board: 0) */
+        bad |= e < 0;
+        pom_rec_set_cell(rec, stride, c, e & 0xFF, lane);
     }
     rec[POM_REC_TIMESTEP * stride] = (uint32_t)timeStep;
 
@@ -182,9 +191,9 @@ POM_HD int32_t pom_sext8(uint32_t v) { return (int32_t)(int8_t)(v & 0xFF); }
 POM_HD int32_t pom_sext16(uint32_t v) { return (int32_t)(int16_t)(v & 0xFFFF); }
 
 /* inverse of pom_pack_state; the two padding bytes of each agent come out 0 */
-POM_HD void pom_unpack_state(const uint32_t* rec, int64_t stride, int32_t* st)
+POM_HD void pom_unpack_state(const uint32_t* rec, int64_t stride, int32_t* st, int lane = 0)
 {
-    for (int c = 0; c < POM_CELLS; c++) st[c] = pom_cell_decode(pom_rec_cell(rec, stride, c), c);
+    for (int c = 0; c < POM_CELLS; c++) st[c] = pom_cell_decode(pom_rec_cell(rec, stride, c, lane), c);
     st[121] = (int32_t)rec[POM_REC_TIMESTEP * stride];
     const uint32_t m = rec[POM_REC_META * stride], m2 = rec[POM_REC_META2 * stride];
     st[122] = pom_sext8(m);

@@ -33,7 +33,7 @@
  *
  * Store interface P:  int cell(int c)            8-bit board code (pom_packed.h), c = y*11+x
  *                     int bomb(int slot)         raw bomb word of physical slot
- *                     uint32_t board_word(int k) board dword k = cells 4k .. 4k+3, a byte each; k up to 31 must be readable
+ *                     uint32_t cells4(int k)     the codes of cells 4k .. 4k+3, a byte each; k up to 31 must be readable
  *                     int danger(int c) / void danger_init(int c) / void danger_put(int c, int t)     per-env danger map, 128
  *                                                entries of at least 8 bits (c up to 127 must be readable)
  *                     uint32_t setw(int k) / void set_put(int k, uint32_t bits)   per-env cell sets, words
@@ -94,7 +94,7 @@ POM_HD uint32_t pom_gather_flags(uint32_t f, uint32_t acc, int hi)
 }
 
 /* Shared preparation, executed by all four lanes of an env.  The 121-bit sets are four words and the env has four lanes:
- * member m builds word m of every set (cells 32m .. 32m+31) with plain stores, from whole board dwords (four cells each).  The
+ * member m builds word m of every set (cells 32m .. 32m+31) with plain stores, four cells at a time.  The
  * danger map is cleared and rasterised by bombs m, m+4, ...  Three phases — every lane must have finished one before any lane
  * starts the next (on the device the wavefront runs them back to back in lock-step; a sequential host emulation runs each
  * phase for all four members in turn). */
@@ -118,8 +118,8 @@ POM_HD void pom_policy_prepare_fill(P& p, const PomPolicyEnv& E)
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
         uint32_t w0, g0, w1, g1;
-        pom_cells_walk_agent(p.board_word(8 * m + i), w0, g0); /* cells 32m + 4i .. + 3; m = 3 runs past the board ... */
-        pom_cells_walk_agent(p.board_word(8 * m + i + 1), w1, g1);
+        pom_cells_walk_agent(p.cells4(8 * m + i), w0, g0); /* cells 32m + 4i .. + 3; m = 3 runs past the board ... */
+        pom_cells_walk_agent(p.cells4(8 * m + i + 1), w1, g1);
         w |= pom_gather_flags(w1, pom_gather_flags(w0, 0u, 0), 1) << (4 * i);
         g |= pom_gather_flags(g1, pom_gather_flags(g0, 0u, 0), 1) << (4 * i);
     }

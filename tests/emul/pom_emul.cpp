@@ -83,17 +83,21 @@ int pom_emul_tile_roundtrip(const void* states_1004, int n, void* out_1004)
     for (int e = 0; e < n && !rc; e++) {
         const int64_t col = pom_rec_col(e);
         if (col / POM_TILE_DWORDS != e / POM_TILE_ENVS) rc = __LINE__;
-        if (pom_pack_state((const int32_t*)states_1004 + (size_t)e * 251, buf + col, POM_TILE_ENVS)) rc = __LINE__;
-        for (int d = 0; d < POM_REC_DWORDS && !rc; d++) {
+        if (pom_pack_state((const int32_t*)states_1004 + (size_t)e * 251, buf + col, POM_TILE_ENVS, e % POM_TILE_ENVS)) rc = __LINE__;
+        for (int d = POM_REC_TIMESTEP; d < POM_REC_DWORDS && !rc; d++) {
             const int64_t at = (int64_t)(e / POM_TILE_ENVS) * POM_TILE_DWORDS + d * POM_TILE_ENVS + e % POM_TILE_ENVS; /* the documented place */
             if (at != col + (int64_t)d * POM_TILE_ENVS || owner[at]) rc = __LINE__;
             owner[at] = (uint8_t)(e % 251 + 1);
         }
+        /* the board, by cell: cell c of env e is byte c * 16 + e % 16 of its tile */
+        const uint8_t* tile_b = (const uint8_t*)(buf + (int64_t)(e / POM_TILE_ENVS) * POM_TILE_DWORDS);
+        for (int c = 0; c < POM_CELLS && !rc; c++)
+            if (tile_b[c * POM_TILE_ENVS + e % POM_TILE_ENVS] != (uint8_t)pom_cell_encode(((const int32_t*)states_1004)[(size_t)e * 251 + c], c)) rc = __LINE__;
     }
     for (int e = 0; e < n && !rc; e++) {
         int32_t st[251];
         std::memset(st, 0, sizeof st);
-        pom_unpack_state(buf + pom_rec_col(e), POM_TILE_ENVS, st);
+        pom_unpack_state(buf + pom_rec_col(e), POM_TILE_ENVS, st, e % POM_TILE_ENVS);
         std::memcpy((char*)out_1004 + (size_t)e * POM_STATE_BYTES, st, POM_STATE_BYTES);
     }
     delete[] buf;

@@ -20,7 +20,7 @@ struct PolicyArrays {
     uint32_t setw(int k) const { return sets[k]; }
     void set_put(int k, uint32_t bits) { sets[k] = bits; }
     int cell(int c) const { return cells[c]; }
-    uint32_t board_word(int k) const { return (uint32_t)cells[4 * k] | ((uint32_t)cells[4 * k + 1] << 8) | ((uint32_t)cells[4 * k + 2] << 16) | ((uint32_t)cells[4 * k + 3] << 24); }
+    uint32_t cells4(int k) const { return (uint32_t)cells[4 * k] | ((uint32_t)cells[4 * k + 1] << 8) | ((uint32_t)cells[4 * k + 2] << 16) | ((uint32_t)cells[4 * k + 3] << 24); }
     int bomb(int s) const { return bombs[s]; }
 };
 
