@@ -297,6 +297,27 @@ def measure_traffic(args) -> dict | None:
             "fetch_correction": 2.0}
 
 
+def config_traffic(key: str, envs: int):
+    """HBM bytes per step of the workload `key` from the committed PMC passes (profiles/r05_traffic.json: one block per config, FETCH_SIZE x 2 +
+    WRITE_SIZE of ITS kernel on ITS workload, scripts/profile_configs.sh + scripts/traffic_json.py), scaled by envs only if the block was taken
+    at another batch size.  (bytes, what they are) — the packed record's footprint if the config has no block."""
+    try:
+        blk = json.load(open(os.path.join(ROOT, TRAFFIC_JSON)))["configs"][key]
+        b = blk["hbm_bytes_per_step"] * envs / blk["envs"]
+        kind = "pmc (" + key + ")" + ("" if blk["envs"] == envs else f", scaled from {blk['envs']} envs")
+        return int(round(b)), kind
+    except (OSError, KeyError, ValueError):
+        return PACKED_BYTES_PER_STEP * envs, "packed footprint (2 x 328 B per env)"
+
+
+def with_bytes(entry: dict, key: str, envs: int, ms_per_step: float) -> dict:
+    """`entry` plus its own bytes_per_step / achieved_GBps / frac (of the 8 TB/s peak), from ITS config's PMC block"""
+    b, kind = config_traffic(key, envs)
+    entry.update({"bytes_per_step": b, "bytes_kind": kind, "achieved_GBps": b / (ms_per_step * 1e-3) / 1e9,
+                  "frac": b / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+    return entry
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,7 +331,7 @@ def parse_args(argv=None):
     ap.add_argument("--ticks-per-launch", type=int, default=1)
     ap.add_argument("--max-steps", type=int, default=800)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--policy", default="random", choices=["random", "simple"],
+    ap.add_argument("--policy", default="random", choices=["random", "simple", "tape"],
                     help="random: Move[4] from the counter stream (--dist); simple: the device SimpleAgent policy (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config3", action="store_true", help="skip the other-config segments (profiling runs: one kernel shape only)")
@@ -410,6 +431,16 @@ def worker(args) -> None:
 
         def run_steps(k: int) -> None:  # k steps: k x launches_per_step launches, queued by one call into the library
             env.step_simple(args.seed, k)
+    elif args.policy == "tape":
+        # explicit Move[4] from a tape in device memory (pom_batch_step_device_many: chained launches, the tile's ticket picks the
+        # tape's tick) as the MAIN workload: what scripts/profile_configs.sh profiles as `tape`
+        if tpl != 1:
+            raise SystemExit("--policy tape runs one tick per launch")
+        tape_main = torch.randint(0, 6, (max(args.steps, args.warmup, args.burn_in, 1), plan["n_envs"], 4), dtype=torch.int32, device=device,
+                                  generator=torch.Generator(device=device).manual_seed(args.seed))
+
+        def run_steps(k: int) -> None:
+            env.step_device_many(tape_main[:k])
     else:
         def run_steps(k: int) -> None:
             env.step_random(args.seed, dist_id, ticks=k * tpl, ticks_per_launch=tpl)
@@ -528,9 +559,9 @@ def worker(args) -> None:
         ev3.record(stream)
         env.sync()
         ms_c = ev2.elapsed_time(ev3) / n_c
-        config3 = {"workload": f"{args.envs} envs, 4x SimpleAgent policy on the device + Step, games from the start, "
-                               "200 warm-up ticks", "value": plan["n_envs"] / (ms_c * 1e-3),
-                   "unit": "env-steps/s", "ms_per_step": ms_c, "steps": n_c}
+        config3 = with_bytes({"workload": f"{args.envs} envs, 4x SimpleAgent policy on the device + Step, games from the start, "
+                                          "200 warm-up ticks", "value": plan["n_envs"] / (ms_c * 1e-3),
+                              "unit": "env-steps/s", "ms_per_step": ms_c, "steps": n_c}, "c3", plan["n_envs"], ms_c)
     # BASELINE's other single-GPU configs, briefly (untimed region, default run only): config 2 (4,096 envs, random moves) and
     # config 5 (65,536 envs, kick / chain-explosion stress boards and move mix) — parity-test cases first, numbers for context —
     # and the explicit-moves path an RL loop uses (pom_batch_step_device: Move[4] read from device memory, every tick joined
@@ -553,7 +584,8 @@ def worker(args) -> None:
             ev5.record(stream)
             e2.sync()
             ms_o = ev4.elapsed_time(ev5) / n_o_steps
-            other[name] = {"value": n_o / (ms_o * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_o, "steps": n_o_steps}
+            other[name] = with_bytes({"value": n_o / (ms_o * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_o, "steps": n_o_steps},
+                                     "c2" if n_o == 4096 else "c5", n_o, ms_o)
             e2.close()
         # explicit moves from device memory, as an RL loop steps: auto_reset = RESET_AT_END (what is observed is what the next move
         # applies to), 8 pre-drawn Move[4] arrays cycled, one pom_batch_step_device per tick (one launch, joined with the
@@ -732,27 +764,25 @@ def worker(args) -> None:
         other["single_env_pom_step"] = {"value": 1e6 / us_l, "unit": "env-steps/s", "us_per_call": us_l, "calls": n_l, "native_threads": threads8,
                                         "note": "pom_step(State*, Move[4]) on ONE env: one launch reads the host State, steps it and writes "
                                                 "it back, blocking; the batch API is the product, this is the literal bboard::Step replacement"}
-        other["explicit_moves_device_chained_65536_envs"] = {
+        other["explicit_moves_device_chained_65536_envs"] = with_bytes({
             "value": plan["n_envs"] / (ms_tape * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_tape, "steps": n_tape,
-            "chain_tiles_recovered": tape_stats["tiles_recovered"],
+            "chain_tiles_recovered": tape_stats["tiles_recovered"]}, "tape", plan["n_envs"], ms_tape)
+        other["explicit_moves_device_chained_65536_envs"].update({
             "note": "pom_batch_step_device_many with auto_reset = POM_RESET_AT_END: a 200-tick Move[4] tape in device memory, chained launches "
-                    "(one launch over all tiles per tick on rotating streams, the tile's ticket picks the tape's tick)"}
+                    "(one launch over all tiles per tick on rotating streams, the tile's ticket picks the tape's tick)"})
         other["step_plus_observation_65536_envs"] = {
             "one_launch_us": ms_obs[True] * 1e3, "two_launches_us": ms_obs[False] * 1e3, "value": plan["n_envs"] / (ms_obs[True] * 1e-3),
             "unit": "env-steps/s (each with its uint8 [16][11][11] observation written)",
             "one_launch_codes_us": ms_obs["codes"] * 1e3, "value_codes": plan["n_envs"] / (ms_obs["codes"] * 1e-3),
             "note": "pom_batch_step_device_observe against pom_batch_step_device + pom_batch_observe, explicit moves, POM_RESET_AT_END; "
                     "*_codes: the compact observation (POM_OBS_CODES, uint8 [5][11][11]) in the same launch"}
-        other["explicit_moves_device_65536_envs"] = {
+        other["explicit_moves_device_65536_envs"] = with_bytes({
             "value": plan["n_envs"] / (ms_x * 1e-3), "unit": "env-steps/s", "ms_per_step": ms_x, "steps": n_x,
-            "note": "pom_batch_step_device with auto_reset = POM_RESET_AT_END: Move[4] from device memory, one launch per tick on the caller's stream"}
+            "note": "pom_batch_step_device with auto_reset = POM_RESET_AT_END: Move[4] from device memory, one launch per tick on the caller's stream"},
+            "head1", plan["n_envs"], ms_x)
     if other is not None:
         # what a LONG call reaches (the timed region above is the driver's shape, a few hundred microseconds from an idle device: a fifth
         # of it is the pipeline filling and draining): 500 steps in one call, HIP events on the launch stream
-        traffic_65536 = None
-        tjp = os.path.join(ROOT, TRAFFIC_JSON)
-        if os.path.exists(tjp):
-            traffic_65536 = json.load(open(tjp))["hbm_bytes_per_step"]
         evA, evB = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         env.make_game(start)  # (config 3 above left SimpleAgent games in the batch)
         env.set_tick(0)
@@ -764,13 +794,12 @@ def worker(args) -> None:
         evB.record(stream)
         env.sync()
         ms_500 = evA.elapsed_time(evB) / 500
-        moved_500 = traffic_65536 or PACKED_BYTES_PER_STEP * plan["n_envs"]
-        other["headline_500_steps"] = {
+        other["headline_500_steps"] = with_bytes({
             "value": plan["n_envs"] / (ms_500 * 1e-3), "unit": "env-steps/s", "us_per_step": ms_500 * 1e3, "steps": 500,
-            "bytes_per_step": moved_500, "achieved_GBps": moved_500 / (ms_500 * 1e-3) / 1e9, "frac": moved_500 / (ms_500 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "cache_resident": True,
             "note": "the headline workload in one 500-step call (chained launches, three streams); bytes = the committed PMC figure "
-                    "(L2 <-> fabric: FETCH_SIZE x 2 + WRITE_SIZE); state + snapshot (59 MB) sit inside the 256 MiB memory-side cache"}
+                    "(L2 <-> fabric: FETCH_SIZE x 2 + WRITE_SIZE); state + snapshot (43 MB) sit inside the 256 MiB memory-side cache"},
+            "headc", plan["n_envs"], ms_500)
         # beyond the memory-side cache: 1,048,576 envs = 470 MB of state (+ 470 MB of snapshots): every step streams the records from and
         # to HBM proper.  Boards drawn on the device (same distribution), snapshot replay, sub-batches on parallel streams.
         n_big = 1048576
@@ -789,13 +818,11 @@ def worker(args) -> None:
             ms_big = seg if ms_big is None else min(ms_big, seg)
         big_issue = eb.issue_info()
         eb.close()
-        moved_big = (traffic_65536 or PACKED_BYTES_PER_STEP * 65536) * (n_big // 65536)
-        other["headline_1048576_envs"] = {
+        other["headline_1048576_envs"] = with_bytes({
             "value": n_big / (ms_big * 1e-3), "unit": "env-steps/s", "us_per_step": ms_big * 1e3, "steps": 60, "best_of_segments": 3, "issue": big_issue[0],
-            "bytes_per_step": moved_big, "achieved_GBps": moved_big / (ms_big * 1e-3) / 1e9, "frac": moved_big / (ms_big * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "cache_resident": False,
-            "note": "1,048,576 envs: 470 MB of records, 4 x the memory-side cache — the fraction of the HBM peak proper; bytes = the "
-                    "65,536-env PMC figure per env"}
+            "note": "1,048,576 envs: 344 MB of records (+ as much of snapshots), beyond the 256 MiB memory-side cache — the fraction of the HBM "
+                    "peak proper; bytes = this size's own PMC passes"}, "big", n_big, ms_big)
     # like-for-like base of an N > 1 line: this rank's shard stepped while the other ranks' GPUs idle (same envs per GPU, same kernels)
     single_base = None
     if multi:
@@ -839,12 +866,18 @@ def worker(args) -> None:
             else:
                 traffic_failure = (live or {}).get("failed", "unknown")
                 print(f"bench.py: --measure-traffic FAILED ({traffic_failure}); falling back to the committed figure", file=sys.stderr)
-        if traffic is None and os.path.exists(tj) and headline_shape:
-            tjd = json.load(open(tj))
-            # per env: the committed passes ran 65,536 envs; the kernel's traffic per env does not depend on how many ranks share the job
-            traffic = int(round(tjd["hbm_bytes_per_step"] * plan["n_envs"] / tjd["envs"]))
-            traffic_source = TRAFFIC_JSON + " (rocprofv3 --pmc FETCH_SIZE x 2 / WRITE_SIZE in separate passes, one launch per step, " \
-                                            f"{tjd['envs']} envs, scaled to this rank's {plan['n_envs']}; committed, not measured in this run)"
+        if traffic is None and os.path.exists(tj) and tpl == 1 and not args.fresh_boards:
+            # the block of THIS workload (one per config, each from PMC passes over its own kernel and batch): bytes per env do not depend on how
+            # many ranks share the job, so a block taken at another batch size of the same kind is scaled by envs — and says so
+            key = ("c3" if args.policy == "simple" else "tape" if args.policy == "tape" else "c5" if args.kind == "stress" else
+                   None if not headline_shape else "c2" if plan["n_envs"] <= 8192 else "big" if plan["n_envs"] > 262144 else
+                   "headc" if issue == "chain" else "head1")
+            blk = json.load(open(tj)).get("configs", {}).get(key) if key else None
+            if blk:
+                traffic = int(round(blk["hbm_bytes_per_step"] * plan["n_envs"] / blk["envs"]))
+                traffic_source = (f"{TRAFFIC_JSON} configs.{key} (rocprofv3 --pmc FETCH_SIZE x 2 / WRITE_SIZE in separate passes over this workload, "
+                                  f"{blk['envs']} envs" + ("" if blk["envs"] == plan["n_envs"] else f", scaled to this rank's {plan['n_envs']}")
+                                  + "; committed, not measured in this run)")
         moved = traffic if traffic is not None else footprint
         hbm = moved / (ms_per_step * 1e-3) / 1e9
         c4 = world > 1 and plan["global_envs"] == 262144

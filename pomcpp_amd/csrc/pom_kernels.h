@@ -26,8 +26,8 @@
 
 /* ---------------------------------------------------------------------------------------------
  * LDS tile of one wavefront, [row][EPW] dwords.  Rows 0..81 mirror the HBM record row for row (pom_packed.h), so the
- * whole record moves in groups of 64/EPW rows; then 5 rows of bomb-destination bytes and 21 rows of
- * explosion frames: 108 rows = 27.6 / 13.8 / 6.9 KB for 64 / 32 / 16 envs per wavefront.
+ * whole record moves in groups of 64/EPW rows; then 5 rows of bomb-destination bytes, 21 rows of
+ * explosion frames and 31 rows of per-cell counters: 139 rows = 35.6 / 17.8 / 8.9 KB for 64 / 32 / 16 envs per wavefront.
  * ------------------------------------------------------------------------------------------- */
 enum {
     ROW_BOARD = POM_REC_BOARD,    /* 31 rows: four 8-bit cells per dword            */
@@ -35,7 +35,8 @@ enum {
     ROW_FLAMES = POM_REC_FLAMES,  /* 20 rows                                        */
     ROW_BDEST = POM_REC_DWORDS,   /*  5 rows: 20 bytes, bomb destination snapshot   */
     ROW_STACK = POM_REC_DWORDS + 5, /* 21 rows: explosion frames                    */
-    LDS_ROWS = POM_REC_DWORDS + 26
+    ROW_CLAIMS = POM_REC_DWORDS + 26, /* 31 rows: a byte per cell and env, [env][124] (PomStepper::loop_b_todo) */
+    LDS_ROWS = POM_REC_DWORDS + 57
 };
 static_assert(POM_REC_DWORDS % 2 == 0, "the one-lane shapes move the record in groups of 1 or 2 rows");
 
@@ -62,7 +63,10 @@ struct LdsEnv {
     uint32_t* t; /* &tile[env_in_wave] */
     int sub_;    /* lane's index within its env's group; 0 = owner */
     uint8_t* b;  /* the env's cell 0 (tile_cell_byte) */
-    __device__ LdsEnv(uint32_t* tile, int el, int sub) : t(tile + el), sub_(sub), b(reinterpret_cast<uint8_t*>(tile) + tile_cell_byte<EPW>(el, 0)) {}
+    uint8_t* cm; /* the env's cell counters */
+    __device__ LdsEnv(uint32_t* tile, int el, int sub)
+        : t(tile + el), sub_(sub), b(reinterpret_cast<uint8_t*>(tile) + tile_cell_byte<EPW>(el, 0)),
+          cm(reinterpret_cast<uint8_t*>(tile + ROW_CLAIMS * EPW) + el * 124) {}
     __device__ int sub() const { return G == 1 ? 0 : sub_; }
     __device__ bool owner() const { return G == 1 || sub_ == 0; }
     /* quad reductions: lane ^ 1, then lane ^ 2 */
@@ -106,6 +110,19 @@ struct LdsEnv {
     __device__ int bdest(int i) const { return reinterpret_cast<const uint8_t*>(t + ROW_BDEST * EPW)[(i >> 2) * (4 * EPW) + (i & 3)]; }
     __device__ void put_bdest(int i, int v) { reinterpret_cast<uint8_t*>(t + ROW_BDEST * EPW)[(i >> 2) * (4 * EPW) + (i & 3)] = (uint8_t)v; }
     __device__ int frame(int d) const { return (int)t[(ROW_STACK + d) * EPW]; }
+    /* the env's cell counters (loop_b_todo): 124 bytes of its own behind the frames, env after env.  Cleared by the env's lanes
+     * together, a dword each per round; counted up with LDS atomics (two lanes of an env may count the same cell) */
+    __device__ void claims_clear()
+    {
+#pragma unroll
+        for (int k = 0; k < (31 + G - 1) / G; k++)
+            if (G * k + G - 1 < 31 || sub() + G * k < 31) reinterpret_cast<uint32_t*>(cm)[sub() + G * k] = 0u;
+    }
+    __device__ void claim(int c)
+    {
+        __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(cm + (c & ~3)), 1u << (8 * (c & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ int claims(int c) const { return cm[c]; }
     /* replicated code: all G lanes get here with the same value, the owner writes */
     __device__ void set_cell(int c, int v) { if (owner()) put_cell(c, v); }
     __device__ void set_bomb(int s, int v) { if (owner()) put_bomb(s, v); }
@@ -998,12 +1015,13 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     static_assert(!POLICY || G == 4, "the policy runs one agent per lane of the quad");
     static_assert(!ATEND || G == 4, "the end-of-tick reset is built for the quad shape only");
     /* POLICY: the danger map (32 rows of bytes) and the cell sets (12 rows) live where the tick keeps its bomb destinations
-     * and explosion frames (26 rows) — the policy of a tick is over before its tick begins.  156 rows = 9,984 B: 16
-     * wavefronts per CU, i.e. all of 65,536 envs resident at once. */
+     * and explosion frames — the policy of a tick is over before its tick begins.  139 rows = 8,896 B: 17 wavefronts per
+     * CU would fit, 16 (all of 65,536 envs resident at once) are needed. */
     /* OBS: the staging area — one env's planes (1,936 + 16 B) or four envs' code planes (2,420 B: 38 rows) — lies over the same
-     * scratch rows — the tick is over when the observation begins: 150 rows = 9,600 B, still 16 wavefronts per CU */
+     * scratch rows — the tick is over when the observation begins */
     constexpr int OBS_ROWS = (OBS_STAGE_VECS * 16 + EPW * 4 - 1) / (EPW * 4);
-    constexpr int ROWS = POLICY ? POM_REC_DWORDS + 44 : OBS ? POM_REC_DWORDS + (OBS_ROWS > 26 ? OBS_ROWS : 26) : LDS_ROWS;
+    constexpr int OVERLAY = POLICY ? 44 : OBS ? OBS_ROWS : 0; /* rows behind the record that the policy / the export use when the tick does not */
+    constexpr int ROWS = POM_REC_DWORDS + OVERLAY > LDS_ROWS ? POM_REC_DWORDS + OVERLAY : LDS_ROWS;
     static_assert(ROWS >= LDS_ROWS, "the tick's scratch rows fit under the overlay");
     __shared__ __attribute__((aligned(16))) uint32_t tiles_[POM_WPB][ROWS * EPW];
     uint32_t* const tile = tiles_[POM_WPB == 1 ? 0 : threadIdx.x >> 6];

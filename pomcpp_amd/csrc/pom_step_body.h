@@ -41,6 +41,9 @@
  *   int  flame(int slot) / void set_flame(int slot, int v)  packed x|y<<8|time<<16|strength<<24
  *   int  bdest(int i) / void set_bdest(int i, int v)        byte: snapshot of bomb destinations
  *   int  frame(int d) / void set_frame(int d, int v)        explosion stack
+ *   void claims_clear() / void claim(int c) / int claims(int c)   a counter per cell (loop_b_todo): cleared by the env's lanes together
+ *                                                                 (split), counted up by any of them (an atomic add on the device), read
+ *                                                                 after a sync()
  */
 #ifndef POM_STEP_BODY_H_
 #define POM_STEP_BODY_H_
@@ -895,6 +898,7 @@ struct PomStepper {
             if (ag > -1) {
                 const int m = (mvp >> (4 * ag)) & 0xF;
                 if (m != POM_MOVE_IDLE && m != POM_MOVE_BOMB) {
+                    unforeseen_ = 1; /* (loop B's selection of bombs, loop_b_todo, does not cover what a bounce moves) */
                     chain_reversion(mvp, ag);
                     /* the bomb word is re-read: the chain may have moved this very bomb */
                     const int cur = bomb_at(k);
@@ -1081,6 +1085,85 @@ struct PomStepper {
         dstp = 0; /* FixSwitchMove may have changed them */
 #pragma unroll
         for (int i = 0; i < 4; i++) dstp |= (uint32_t)(((dx[i] + 1) & 0xF) | (((dy[i] + 1) & 0xF) << 4)) << (8 * i);
+    }
+
+    /* Which bombs does loop B (step.cpp:230-278) have to visit?  A RESTING bomb's turn is: HasBombCollision over the bombs from itself
+     * on — some bomb with another word whose DesiredPosition is this bomb's cell — and, without one, the test of its own cell (PASSAGE
+     * becomes BOMB, a flame sets it off).  Nothing happens on that turn, and nothing any other bomb's turn does can make something
+     * happen on it, if the bomb's cell shows neither PASSAGE nor a flame and NO other bomb stands on or heads for that cell: a bomb
+     * that is never moved, never idled, and whose cell nobody writes.  Those are skipped; the rest — every bomb with a direction, every
+     * bomb whose cell is "ripe", every bomb whose cell is claimed twice (positions and targets of all bombs counted in a byte map in
+     * LDS) — are visited in queue order as before.  What the selection cannot foresee — an explosion inside the loop (cells and queue
+     * change), a bounced agent (AgentBombChainReversion moves agents and bombs) — sets `unforeseen_`, and the loop then visits every
+     * bomb after the current one.  Stress boards: 12 -> 7 trips of the loop per wavefront-tick (round 5). */
+    int unforeseen_ = 0;
+    POM_HD uint32_t loop_b_todo()
+    {
+        a.claims_clear();
+        a.sync();
+        POM_NOUNROLL
+        for (int k = a.sub(); k < L.bCnt; k += A::G) {
+            const int b = bomb_at(k);
+            const int d = pb_dir(b);
+            const int bx = pb_x(b), by = pb_y(b), tx = bx + mv_dx(d), ty = by + mv_dy(d);
+            a.claim(by * POM_N + bx);
+            if ((int)(d != 0) & !oob(tx, ty) & (int)((mv_dx(d) | mv_dy(d)) != 0)) a.claim(ty * POM_N + tx);
+        }
+        a.sync();
+        uint32_t f = 0;
+        POM_NOUNROLL
+        for (int k = a.sub(); k < L.bCnt; k += A::G) {
+            const int b = bomb_at(k);
+            const int c = pb_y(b) * POM_N + pb_x(b);
+            const int e = a.cell(c);
+            f |= (uint32_t)((int)(pb_dir(b) != 0) | (int)(e == POM_C_PASSAGE) | pc_is_flame(e) | (int)(a.claims(c) >= 2)) << k;
+        }
+        return (uint32_t)a.gor((int)f);
+    }
+    /* one bomb of loop B, step.cpp:232-277 */
+    POM_HD void loop_b_bomb(uint32_t mvp, int k)
+    {
+        int b = bomb_at(k);
+        const int bx = pb_x(b), by = pb_y(b), d = pb_dir(b);
+        int tx = bx, ty = by; /* where a flame may set a bomb off at the end of this iteration */
+        if (d == 0) {
+            if (bomb_collision(mvp, k)) return;
+            /* A resting bomb "moves" onto its own cell (step.cpp:243-272 with target == position): its word does not
+             * change, its old cell still holds a bomb (itself), so all that is left is the cell test — PASSAGE becomes
+             * BOMB, a flame sets off the first bomb queued on the cell (GetBombIndex: possibly an earlier one, SURVEY
+             * Q8); a static item there makes the reference set the already resting bomb to rest. */
+            const int c = by * POM_N + bx;
+            const int e = a.cell(c);
+            if (e == POM_C_PASSAGE) a.set_cell(c, POM_C_BOMB);
+            if (!pc_is_flame(e)) return;
+        } else {
+            tx = bx + mv_dx(d);
+            ty = by + mv_dy(d);
+            int free_way = !oob(tx, ty);
+            int tc = 0, te = 0;
+            if (free_way) {
+                tc = ty * POM_N + tx;
+                te = a.cell(tc);
+                free_way = !pc_is_static_block(te);
+            }
+            if (!free_way) {
+                set_bomb_at(k, pb_set(b, 0xF00000u, 0));
+                return;
+            }
+            if (bomb_collision(mvp, k)) return;
+            b = bomb_at(k);
+            set_bomb_at(k, pb_set(b, 0xFFu, (uint32_t)tx + ((uint32_t)ty << 4)));
+            if (bomb_index(bx | (by << 4)) < 0 && a.cell(by * POM_N + bx) == POM_C_BOMB)
+                a.set_cell(by * POM_N + bx, POM_C_PASSAGE);
+            te = a.cell(tc);
+            if (pc_is_walkable(te)) a.set_cell(tc, POM_C_BOMB);
+            if (!pc_is_flame(te)) return;
+        }
+        /* ExplodeBombAt(GetBombIndex(target)), bboard.cpp:111-118 */
+        const int j = bomb_index(tx | (ty << 4));
+        const int jb = bomb_at(j);
+        unforeseen_ = 1;
+        explode(pb_x(jb), pb_y(jb), owner_strength(jb), j);
     }
 
     /* everything between the flame pops and the top-bomb explosions; returns the head of the bomb queue after the timer
@@ -1492,49 +1575,19 @@ struct PomStepper {
                     general = 1;
                 }
             }
-            if (general)
-            POM_NOUNROLL
-            for (int k = 0; k < L.bCnt; k++) {
-                int b = bomb_at(k);
-                const int bx = pb_x(b), by = pb_y(b), d = pb_dir(b);
-                int tx = bx, ty = by; /* where a flame may set a bomb off at the end of this iteration */
-                if (d == 0) {
-                    if (bomb_collision(mvp, k)) continue;
-                    /* A resting bomb "moves" onto its own cell (step.cpp:243-272 with target == position): its word does not
-                     * change, its old cell still holds a bomb (itself), so all that is left is the cell test — PASSAGE becomes
-                     * BOMB, a flame sets off the first bomb queued on the cell (GetBombIndex: possibly an earlier one, SURVEY
-                     * Q8); a static item there makes the reference set the already resting bomb to rest. */
-                    const int c = by * POM_N + bx;
-                    const int e = a.cell(c);
-                    if (e == POM_C_PASSAGE) a.set_cell(c, POM_C_BOMB);
-                    if (!pc_is_flame(e)) continue;
-                } else {
-                    tx = bx + mv_dx(d);
-                    ty = by + mv_dy(d);
-                    int free_way = !oob(tx, ty);
-                    int tc = 0, te = 0;
-                    if (free_way) {
-                        tc = ty * POM_N + tx;
-                        te = a.cell(tc);
-                        free_way = !pc_is_static_block(te);
-                    }
-                    if (!free_way) {
-                        set_bomb_at(k, pb_set(b, 0xF00000u, 0));
-                        continue;
-                    }
-                    if (bomb_collision(mvp, k)) continue;
-                    b = bomb_at(k);
-                    set_bomb_at(k, pb_set(b, 0xFFu, (uint32_t)tx + ((uint32_t)ty << 4)));
-                    if (bomb_index(bx | (by << 4)) < 0 && a.cell(by * POM_N + bx) == POM_C_BOMB)
-                        a.set_cell(by * POM_N + bx, POM_C_PASSAGE);
-                    te = a.cell(tc);
-                    if (pc_is_walkable(te)) a.set_cell(tc, POM_C_BOMB);
-                    if (!pc_is_flame(te)) continue;
+            if (general) {
+                /* the queue in order (step.cpp:230-278) — but only the bombs loop B can do anything for or with (loop_b_todo); once
+                 * something happens that the selection did not foresee, every bomb from there on */
+                uint32_t todo = loop_b_todo();
+                POM_NOUNROLL
+                while (todo) {
+                    const int k = __builtin_ctz(todo);
+                    todo &= todo - 1u;
+                    if (k >= L.bCnt) break;
+                    unforeseen_ = 0;
+                    loop_b_bomb(mvp, k);
+                    if (unforeseen_) todo = k + 1 < POM_Q ? ((1u << POM_Q) - 1u) & ~((2u << k) - 1u) : 0u; /* offsets k+1 .. 19 (the count ends the loop) */
                 }
-                /* ExplodeBombAt(GetBombIndex(target)), bboard.cpp:111-118 */
-                const int j = bomb_index(tx | (ty << 4));
-                const int jb = bomb_at(j);
-                explode(pb_x(jb), pb_y(jb), owner_strength(jb), j);
             }
             POM_STAMP(L, POM_PH_BOMB_B);
             POM_CUT(L, 70);

@@ -8,10 +8,14 @@
 #   c5      config 5: 65,536 envs, kick / chain-explosion stress boards and move mix
 #   c3      config 3: 65,536 envs, 4x SimpleAgent policy fused with the tick
 #   c2      config 2: 4,096 envs, random moves
+#   tape    explicit Move[4] from a tape in device memory (pom_batch_step_device_many), chained launches
+#   big     the headline at 1,048,576 envs: records beyond the 256 MiB memory-side cache, sub-batch launches
+# Every config gets the byte counters (FETCH_SIZE / WRITE_SIZE, a pass each): scripts/traffic_json.py turns them into
+# profiles/<tag>_traffic.json, one block per config, which bench.py prices each line with.
 # Kernel traces and PMC passes are separate runs (never combined with sys/hip traces).  Output: gpurun_out/prof_<tag>/<cfg>/.
 set -u
 TAG=$1; shift
-WHICH=${*:-headc head1 head3 c5 c3 c2}
+WHICH=${*:-headc head1 c5 c3 c2 tape big}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 TOP=$REPO/gpurun_out/prof_$TAG
 mkdir -p $TOP
@@ -24,7 +28,9 @@ for CFG in $WHICH; do
     head3) ARGS="--steps 200 --warmup 20 --no-cpu-baseline --no-config3 --streams 3"; export POM_ISSUE=threads ;;
     c5)    ARGS="--steps 200 --warmup 60 --kind stress --dist stress $COMMON" ;;
     c3)    ARGS="--steps 200 --warmup 200 --policy simple $COMMON" ;;
-    c2)    ARGS="--steps 400 --warmup 60 --envs 4096 $COMMON" ;;
+    c2)    ARGS="--steps 400 --warmup 60 --envs 4096 --no-cpu-baseline --no-config3" ;;
+    tape)  ARGS="--steps 200 --warmup 20 --policy tape --no-cpu-baseline --no-config3" ;;
+    big)   ARGS="--steps 40 --warmup 10 --envs 1048576 --burn-in 100 --no-cpu-baseline --no-config3" ;;
     *) echo "unknown config $CFG"; exit 2 ;;
   esac
   [ "$CFG" = head3 ] || unset POM_ISSUE
@@ -42,9 +48,11 @@ for CFG in $WHICH; do
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq1 -- python3 $REPO/bench.py $ARGS > $OUT/sq1.log 2>&1 || { echo "sq1 pass failed"; tail -5 $OUT/sq1.log; exit 1; }
   rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/sq2 -- python3 $REPO/bench.py $ARGS > $OUT/sq2.log 2>&1 || { echo "sq2 pass failed"; tail -5 $OUT/sq2.log; exit 1; }
   # instruction fetch / branches (round 3): the I-cache counters live in the SQC block, the fetch / branch / SALU-cycle counters in the SQ
+  if [ "${POM_PROFILE_ICACHE:-0}" = 1 ]; then
   rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_ICACHE_BUSY_CYCLES --output-format csv -d $OUT/ic1 -- python3 $REPO/bench.py $ARGS > $OUT/ic1.log 2>&1 || { echo "ic1 pass failed"; tail -5 $OUT/ic1.log; }
   rocprofv3 --pmc SQ_IFETCH SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/ic2 -- python3 $REPO/bench.py $ARGS > $OUT/ic2.log 2>&1 || { echo "ic2 pass failed"; tail -5 $OUT/ic2.log; }
-  if [ "$CFG" = head1 ] || [ "$CFG" = headc ] || [ "${POM_PROFILE_BYTES:-0}" = 1 ]; then
+  fi
+  if [ "${POM_PROFILE_BYTES:-1}" = 1 ]; then
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $REPO/bench.py $ARGS > $OUT/fetch.log 2>&1 || exit 1
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $REPO/bench.py $ARGS > $OUT/write.log 2>&1 || exit 1
   fi

@@ -13,6 +13,7 @@ struct ArrayEnv {
     uint8_t cells[124];
     int bombs[20], flames[20], stack[POM_STACK_DEPTH];
     uint8_t bd[20];
+    int cnt[124];
     static constexpr int G = 1; /* one lane per env: the split sections degenerate to plain loops */
     int sub() const { return 0; }
     int gor(int v) const { return v; }
@@ -34,6 +35,9 @@ struct ArrayEnv {
     void set_bdest(int i, int v) { bd[i] = (uint8_t)v; }
     int frame(int d) const { return stack[d]; }
     void set_frame(int d, int v) { stack[d] = v; }
+    void claims_clear() { std::memset(cnt, 0, sizeof cnt); }
+    void claim(int c) { cnt[c]++; }
+    int claims(int c) const { return cnt[c]; }
 };
 
 extern "C" {

@@ -46,6 +46,9 @@ struct Quad {
     int ov[4][N_ADDR];          /* per lane: pending writes */
     unsigned char kind[4][N_ADDR];
     int dirty_list[4][N_ADDR], n_dirty[4];
+    int claim_mem[124];         /* the cell counters (loop_b_todo): committed values ... */
+    int claim_add[4][124];      /* ... and what each lane has counted since the last rendezvous (atomic adds on the device: they sum) */
+    int claim_clear[4];         /* a lane has cleared its share since the last rendezvous */
     int xval[2][4], xop[2][4];  /* exchange slots, double-buffered by the parity of the rendezvous count */
     std::atomic<int> arrived{0};
     std::atomic<unsigned> generation{0};
@@ -127,6 +130,23 @@ struct QuadLaneEnv {
             for (int i = 0; i < q->n_dirty[l]; i++) q->kind[l][q->dirty_list[l][i]] = W_NONE;
             q->n_dirty[l] = 0;
         }
+        /* the cell counters: a lane's share is dwords l, l + 4, ... of the 31; clears first (a clear and a count of the same cell in
+         * one interval would race on the device: flagged), then the counts, which add up */
+        for (int l = 0; l < 4; l++) {
+            if (!q->claim_clear[l]) continue;
+            for (int d = l; d < 31; d += 4)
+                for (int c = 4 * d; c < 4 * d + 4; c++) {
+                    for (int m = 0; m < 4; m++)
+                        if (q->claim_add[m][c]) flag(2, 10000 + c);
+                    q->claim_mem[c] = 0;
+                }
+            q->claim_clear[l] = 0;
+        }
+        for (int l = 0; l < 4; l++)
+            for (int c = 0; c < 124; c++) {
+                q->claim_mem[c] += q->claim_add[l][c];
+                q->claim_add[l][c] = 0;
+            }
     }
     int rendezvous(int op, int v) const
     {
@@ -174,6 +194,13 @@ struct QuadLaneEnv {
     void set_bdest(int i, int v) { wr(A_BDEST + i, v & 0xFF, set_kind()); }
     int frame(int d) const { return rd(A_STACK + d); }
     void set_frame(int d, int v) { wr(A_STACK + d, v, set_kind()); }
+    void claims_clear() { q->claim_clear[sub_] = 1; }
+    void claim(int c) { q->claim_add[sub_][c]++; }
+    int claims(int c) const /* read after a sync(): nothing of this lane's own may be pending (the device reads what is committed) */
+    {
+        if (q->claim_add[sub_][c] || q->claim_clear[sub_]) flag(2, 20000 + c);
+        return q->claim_mem[c];
+    }
 };
 
 void run_lane(Quad& q, int sub)
@@ -266,6 +293,9 @@ uint32_t pom_emul_quad_step(void* state_1004, const int32_t* moves, int env_mode
     std::memset(q.mem, 0, sizeof q.mem);
     std::memset(q.kind, 0, sizeof q.kind);
     std::memset(q.n_dirty, 0, sizeof q.n_dirty);
+    std::memset(q.claim_mem, 0x55, sizeof q.claim_mem); /* whatever the last tick left there */
+    std::memset(q.claim_add, 0, sizeof q.claim_add);
+    std::memset(q.claim_clear, 0, sizeof q.claim_clear);
     q.diverged.store(0);
     for (int c = 0; c < POM_CELLS; c++) q.mem[A_CELL + c] = pom_rec_cell(rec, 1, c);
     for (int k = 0; k < 20; k++) {
