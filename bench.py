@@ -19,11 +19,11 @@ The JSON line carries
   roofline     — `achieved` / `frac`: the bytes the kernel REALLY moves per step (`traffic`: rocprofv3 PMC FETCH_SIZE x 2 +
                  WRITE_SIZE of this workload — the figure committed under profiles/, or measured by this very run with
                  --measure-traffic; `traffic_source` / `traffic_measured_in_run` say which; the packed record's footprint
-                 2 x 328 B per env for workloads without a PMC figure) over the SAME clock as `value` (ms_per_step), against
+                 2 x 320 B per env for workloads without a PMC figure) over the SAME clock as `value` (ms_per_step), against
                  the 8 TB/s HBM3E peak: a physical utilisation, never above 1;
                  `contract_achieved` / `contract_frac`: SURVEY §8(d)'s contract bytes (2024 B per env-step: the reference's
                  1004-B State read and written + Move[4]) over the same clock — bytes the kernel does not move (the device
-                 record is packed to 328 B), kept for comparison with rounds 1-2, not a utilisation;
+                 record is packed to 320 B), kept for comparison with rounds 1-2, not a utilisation;
                  `launch`: one launch's bytes and mean duration from HIP events attached to the dispatch (what rocprofv3's
                  kernel trace reports as AverageNs); `limited_by`: what actually bounds the kernel (profiles/).
   cpu_baseline — the unmodified reference bboard::Step (oracle/_ref, built where /root/reference lies) or the restatement,
@@ -48,7 +48,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_STEP = 2024  # 1004 B State read + 1004 B State write + 16 B Move[4]  (SURVEY.md §8d): the contract figure
-PACKED_BYTES_PER_STEP = 2 * 328  # what the device record moves per env-step: 82 dwords read + written (pom_packed.h)
+PACKED_BYTES_PER_STEP = 2 * 320  # what the device record moves per env-step: 80 dwords read + written (pom_packed.h)
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 TRAFFIC_JSON = os.path.join("profiles", "r05_traffic.json")
 # BASELINE's metric: 64k envs per GPU.  Round 4: the same with several GPUs — weak scaling with the per-GPU work really fixed, so that
@@ -307,7 +307,7 @@ def config_traffic(key: str, envs: int):
         kind = "pmc (" + key + ")" + ("" if blk["envs"] == envs else f", scaled from {blk['envs']} envs")
         return int(round(b)), kind
     except (OSError, KeyError, ValueError):
-        return PACKED_BYTES_PER_STEP * envs, "packed footprint (2 x 328 B per env)"
+        return PACKED_BYTES_PER_STEP * envs, "packed footprint (2 x 320 B per env)"
 
 
 def with_bytes(entry: dict, key: str, envs: int, ms_per_step: float) -> dict:
@@ -852,7 +852,7 @@ def worker(args) -> None:
         contract = algo_bytes / (ms_per_step * 1e-3) / 1e9  # same clock as `value`
         # PMC-derived HBM bytes per step: the committed rocprofv3 passes over this very workload (profiles/, taken with
         # scripts/profile_configs.sh), or --measure-traffic: the same two passes as child runs of this script.  Workloads without a
-        # PMC figure are priced with the packed record's footprint (the kernel reads and writes each 328-B record once).
+        # PMC figure are priced with the packed record's footprint (the kernel reads and writes each 320-B record once).
         traffic, traffic_source, measured_in_run, traffic_failure = None, None, False, None
         tj = os.path.join(ROOT, TRAFFIC_JSON)
         headline_shape = (tpl == 1 and args.kind == "ffa" and args.dist == "random" and args.policy == "random" and not args.fresh_boards)
@@ -925,10 +925,10 @@ def worker(args) -> None:
                 "cache_resident": 2 * footprint < 256 * 2**20,
                 "traffic": traffic, "traffic_source": traffic_source, "traffic_measured_in_run": measured_in_run,
                 "traffic_fallback": bool(args.measure_traffic and not measured_in_run), "traffic_failure": traffic_failure,
-                "hbm_bytes_per_step": moved, "hbm_bytes_kind": "pmc" if traffic is not None else "packed footprint (2 x 328 B per env)",
+                "hbm_bytes_per_step": moved, "hbm_bytes_kind": "pmc" if traffic is not None else "packed footprint (2 x 320 B per env)",
                 "footprint_bytes_per_step": footprint, "traffic_over_footprint": (traffic / footprint) if traffic else None,
                 # SURVEY §8(d)'s contract figure: 2024 B per env-step (the reference's 1004-B State read and written + Move[4]) over the
-                # same clock.  Bytes the kernel does not move — the device record is packed to 328 B — so not a utilisation (it can
+                # same clock.  Bytes the kernel does not move — the device record is packed to 320 B — so not a utilisation (it can
                 # pass 1.0); kept because rounds 1-2 reported it as `frac`.
                 "contract_achieved": contract, "contract_frac": contract / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": algo_bytes,
                 "limited_by": ("with chained launches a tile's next tick no longer waits for the slowest wavefront of the whole launch; what is "

@@ -5,7 +5,7 @@
  * On gfx950 (pom_boardgen_wave in pom_kernels.h) a whole wavefront draws one env's board: lane l takes cells l and l+64
  * (pom_board_cell_kind), two ballots of "is wood" ARE the 121-bit wood set; every lane also computes its cells' selection
  * thresholds and flags (pom_board_threshold / pom_board_flag_code, two hashes each), so that the sequential part of the flag
- * pass — selection sampling over ~17 woods — is a countdown over ready-made numbers; lanes 0..50 write the other 51 dwords of
+ * pass — selection sampling over ~17 woods — is a countdown over ready-made numbers; lanes 0..48 write the other 49 dwords of
  * the fresh record (pom_fresh_row).  The host emulation does the same countdown with pom_board_flags.
  */
 #ifndef POM_BOARDGEN_BODY_H_
@@ -56,15 +56,14 @@ POM_HD void pom_board_flags(uint32_t key, uint64_t w0, uint64_t w1, Put put)
  * PutAgentsInCorners, bboard.cpp:322-333), and the corner cells themselves */
 POM_HD uint32_t pom_fresh_row(int r)
 {
-    if (r == POM_REC_META) return 4u; /* aliveAgents 4, both queues empty */
     if (r >= POM_REC_AGENTS && r < POM_REC_BOMBS) {
         const int i = (r - POM_REC_AGENTS) >> 1;
-        if ((r - POM_REC_AGENTS) & 1) return 1u | (1u << 16); /* maxBombCount 1, bombStrength 1 */
+        if ((r - POM_REC_AGENTS) & 1) return 1u | (1u << 16); /* maxBombCount 1, bombStrength 1; top byte (flames.count / status / flags): 0 */
         const uint32_t x = (i == 1 || i == 2) ? POM_N - 1 : 0, y = (i == 2 || i == 3) ? POM_N - 1 : 0;
-        return x | (y << 8);
+        return x | (y << 4) | (i == 0 ? 4u << 24 : 0u); /* agent 0's top byte: aliveAgents 4; the others' (queue indices and counts): 0 */
     }
     if (r >= POM_REC_FLAMES) return 4u << 16; /* Flame::timeLeft = 4 in every slot, live or not */
-    return 0u;                                /* timeStep, META2 (no flames, status clear), bomb slots */
+    return 0u;                                /* timeStep, bomb slots */
 }
 POM_HD int pom_corner_cell(int agent) { return agent == 0 ? 0 : agent == 1 ? POM_N - 1 : agent == 2 ? POM_CELLS - 1 : POM_CELLS - POM_N; }
 

@@ -25,9 +25,9 @@
 #include "pom_step_body.h"
 
 /* ---------------------------------------------------------------------------------------------
- * LDS tile of one wavefront, [row][EPW] dwords.  Rows 0..81 mirror the HBM record row for row (pom_packed.h), so the
+ * LDS tile of one wavefront, [row][EPW] dwords.  Rows 0..79 mirror the HBM record row for row (pom_packed.h), so the
  * whole record moves in groups of 64/EPW rows; then 5 rows of bomb-destination bytes, 21 rows of
- * explosion frames and 31 rows of per-cell counters: 139 rows = 35.6 / 17.8 / 8.9 KB for 64 / 32 / 16 envs per wavefront.
+ * explosion frames and 31 rows of per-cell counters: 137 rows = 35.1 / 17.5 / 8.8 KB for 64 / 32 / 16 envs per wavefront.
  * ------------------------------------------------------------------------------------------- */
 enum {
     ROW_BOARD = POM_REC_BOARD,    /* 31 rows: four 8-bit cells per dword            */
@@ -269,8 +269,8 @@ __device__ __forceinline__ void store_tile(uint32_t* col, int64_t np, const uint
 }
 /* EPW = 16: the same movement in 16-byte pieces (gfx950's global_load_lds_dwordx4 / dwordx4 stores).  A tile row is 16 envs
  * = 64 contiguous bytes in HBM and in LDS, so lane l takes envs 4(l%4)..+3 of row r0 + l/4 and one instruction covers 16 rows:
- * for the 82 rows of a record five whole instructions and one in which only the lanes of rows 80 and 81 take part (5 + 1 instead
- * of 82 / 4 per direction).  `base` = the tile's first dword, np = the row stride: with the buffers laid out tile by tile
+ * for the 80 rows of a record five whole instructions per direction (a row count that is no multiple of 16 ends with one in which
+ * only the lanes of the remaining rows take part).  `base` = the tile's first dword, np = the row stride: with the buffers laid out tile by tile
  * (pom_packed.h) np = 16 and a whole instruction moves 1,024 contiguous bytes. */
 /* AUX: the instruction's cache policy bits (16 = sc1: served by the L2, never by this CU's vector cache) */
 template <int ROWS = POM_REC_DWORDS, int AUX = 0>
@@ -352,10 +352,8 @@ __device__ __forceinline__ void lane_from_tile(PomLane& L, int& time_step, uint3
     uint32_t ag[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) ag[k] = t[(POM_REC_AGENTS + k) * epw];
-    const uint32_t m2 = t[POM_REC_META2 * epw];
-    pom_lane_load(L, t[POM_REC_META * epw], m2, ag);
+    pom_lane_load(L, ag, status);
     time_step = (int)t[POM_REC_TIMESTEP * epw];
-    status = (m2 >> 8) & 0xFF;
 }
 
 /* the four lanes of an env as the SimpleAgent policy sees them (pom_policy_body.h): lane = agent, 16 envs per wavefront */
@@ -709,7 +707,7 @@ __device__ __forceinline__ void pom_observe_stage(const uint32_t* tile, uint4* s
         const int idx = lane + 64 * i;
         const int ok = (64 * i + 63 < E * POM_Q) | (int)(idx < E * POM_Q);
         const int ei = E == 1 ? 0 : (idx * 3277) >> 16 /* idx / 20 for idx < 128 */, k = idx - ei * POM_Q, ec = q * E + (ok ? ei : 0);
-        const uint32_t m = tile[POM_REC_META * 16 + ec], m2 = tile[POM_REC_META2 * 16 + ec];
+        const uint32_t m = pom_rec_meta(tile + ec, 16), m2 = pom_rec_meta2(tile + ec, 16);
         const int bIdx = (int)((m >> 8) & 0xFF), bCnt = (int)((m >> 16) & 0xFF), fIdx = (int)(m >> 24), fCnt = (int)(m2 & 0xFF);
         const int kk = ok ? k : 0;
         const uint32_t f = tile[(POM_REC_FLAMES + wrap20(fIdx + kk)) * 16 + ec];
@@ -749,7 +747,7 @@ __device__ __forceinline__ void pom_observe_stage(const uint32_t* tile, uint4* s
         constexpr int UNITS = (POM_CELLS + 1) / 2; /* 61 */
         constexpr int LPE = 64 / E, ROW_IT = (UNITS + LPE - 1) / LPE; /* lanes per env; rounds over the 61 two-cell units */
         const int ei = E == 1 ? 0 : lane & (E - 1), j = E == 1 ? lane : lane / E, ec = q * E + ei;
-        const int fIdx = (int)(tile[POM_REC_META * 16 + ec] >> 24);
+        const int fIdx = (int)(tile[(POM_REC_AGENTS + 6) * 16 + ec] >> 24); /* flames.index: the top byte of agent 3's first word */
         auto put = [&](int code, int c, int ok) { /* the cell's byte; returns whether the cell is a flame */
             /* What the cell's code (pom_packed.h: 0 passage, 1 rigid, 2 bomb, 3..5 power-ups, 6..10 wood, 11..14 agents, 15.. flames) sets.
              * The 16 planes: passage 0, rigid 1, wood (any flag) 2, Item::BOMB 3, flames 4, the three power-ups 5, 6, 7, agent i 8 + i.
@@ -858,13 +856,13 @@ __device__ __forceinline__ void pom_observe_tile(const ObserveParams& p, const u
     const int64_t e = tile_id * 16 + ec;
     if (e < p.n && p.agent_attrs) {
         const uint32_t a0 = tile[(POM_REC_AGENTS + 2 * id) * 16 + ec], a1 = tile[(POM_REC_AGENTS + 2 * id + 1) * 16 + ec];
-        const int bc = pom_sext8(a0 >> 16), mx = pom_sext16(a1);
+        const int bc = ag_bombcount((int)a0), mx = ag_max_bombs((int)a1);
         int4* o = reinterpret_cast<int4*>(p.agent_attrs + (e * 4 + id) * POM_OBS_AGENT_ATTRS);
-        o[0] = make_int4((int)(a0 & 0xFF), (int)((a0 >> 8) & 0xFF), (int)!((a0 >> 25) & 1), mx - bc);
-        o[1] = make_int4(bc, mx, (int)(a1 >> 16), (int)((a0 >> 24) & 1));
+        o[0] = make_int4(ag_x((int)a0), ag_y((int)a0), !ag_dead((int)a0), mx - bc);
+        o[1] = make_int4(bc, mx, ag_strength((int)a1), ag_kick((int)a0));
     }
     if (lane < 16 && tile_id * 16 + lane < p.n && p.env_attrs) {
-        const uint32_t m = tile[POM_REC_META * 16 + lane], st = (tile[POM_REC_META2 * 16 + lane] >> 8) & 0xFF;
+        const uint32_t m = pom_rec_meta(tile + lane, 16), st = (pom_rec_meta2(tile + lane, 16) >> 8) & 0xFF;
         const int status = (int)((st & POM_ST_DONE) ? 1 : 0) | (int)((st & POM_ST_DRAW) ? 2 : 0) | (int)((st & POM_ST_TIMEOUT) ? 4 : 0) |
                            (int)((st & POM_ST_RESTARTED) ? 8 : 0);
         reinterpret_cast<int4*>(p.env_attrs)[tile_id * 16 + lane] =
@@ -1286,13 +1284,8 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                 c_resets += __popcll(todo);
                 if (newly_done && owner) { /* the register-resident rows of the final record */
                     t[POM_REC_TIMESTEP * EPW] = (uint32_t)time_step;
-                    t[POM_REC_META * EPW] = pom_lane_meta(L);
-                    t[POM_REC_META2 * EPW] = pom_lane_meta2(L, status);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        t[(POM_REC_AGENTS + 2 * i) * EPW] = (uint32_t)L.a0[i];
-                        t[(POM_REC_AGENTS + 2 * i + 1) * EPW] = (uint32_t)L.a1[i];
-                    }
+                    for (int k = 0; k < 8; k++) t[(POM_REC_AGENTS + k) * EPW] = pom_lane_agent_word(L, status, k);
                 }
                 asm volatile("" ::: "memory");
                 do {
@@ -1332,13 +1325,8 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     /* write back: the owner puts the register-resident rows into the tile, then the whole record leaves in row groups */
     if (owner) {
         t[POM_REC_TIMESTEP * EPW] = (uint32_t)time_step;
-        t[POM_REC_META * EPW] = pom_lane_meta(L);
-        t[POM_REC_META2 * EPW] = pom_lane_meta2(L, status);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            t[(POM_REC_AGENTS + 2 * i) * EPW] = (uint32_t)L.a0[i];
-            t[(POM_REC_AGENTS + 2 * i + 1) * EPW] = (uint32_t)L.a1[i];
-        }
+        for (int k = 0; k < 8; k++) t[(POM_REC_AGENTS + k) * EPW] = pom_lane_agent_word(L, status, k);
     }
     if (EPW == 16) {
         /* the store addresses are functions of the lane id and the arguments only: left alone the compiler computes them at
@@ -1498,7 +1486,7 @@ __global__ void pom_chain_verify_kernel(const unsigned long long* tile_seq, int6
  * next step will restart is read from its snapshot column — or, with fresh boards, drawn here exactly as the tick will draw
  * it — and gets fresh (zero) agent memory, so policy and tick see the same game.
  * ------------------------------------------------------------------------------------------- */
-enum { POL_ROWS = POM_REC_FLAMES, POL_LOAD_ROWS = 64 }; /* the policy reads rows 0..61 (board, meta, agents, bombs); they arrive 16 rows per instruction */
+enum { POL_ROWS = POM_REC_FLAMES, POL_LOAD_ROWS = 64 }; /* the policy reads rows 0..59 (board, timeStep, agents, bombs); they arrive 16 rows per instruction */
 static_assert(POL_ROWS <= POL_LOAD_ROWS && POL_LOAD_ROWS <= POM_REC_DWORDS, "policy rows");
 
 
@@ -1546,7 +1534,7 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
     /* an env the tick is about to restart is judged on the board it will restart on: its snapshot record (array of structs,
      * fetched by the whole wavefront: restart_column) or, with fresh boards, the board the tick kernel is about to draw for it
      * (the tick counts the episode) */
-    const bool restart = e < p.n && env_mode && p.auto_reset == POM_RESET_AT_START && ((tile[POM_REC_META2 * 16 + ec] >> 8) & POM_ST_DONE);
+    const bool restart = e < p.n && env_mode && p.auto_reset == POM_RESET_AT_START && ((pom_rec_meta2(tile + ec, 16) >> 8) & POM_ST_DONE);
     if (restart) m0 = m1 = 0; /* a new game gets fresh agents */
     {
         uint64_t todo = __ballot(restart && id == 0);
@@ -1572,7 +1560,7 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
         E.a0[i] = (int)t[(POM_REC_AGENTS + 2 * i) * 16];
         E.a1[i] = (int)t[(POM_REC_AGENTS + 2 * i + 1) * 16];
     }
-    const uint32_t meta = t[POM_REC_META * 16], meta2 = t[POM_REC_META2 * 16];
+    const uint32_t meta = pom_rec_meta(t, 16), meta2 = pom_rec_meta2(t, 16);
     E.bIdx = (int)((meta >> 8) & 0xFF);
     E.bCnt = (int)((meta >> 16) & 0xFF);
     const bool frozen = env_mode && ((meta2 >> 8) & POM_ST_DONE); /* finished and not restarted: Environment::Step returns */
@@ -1670,7 +1658,7 @@ __global__ void pom_pack_kernel(const int32_t* __restrict__ aos, int64_t first, 
     int bad = pom_pack_state(aos + i * (POM_STATE_BYTES / 4), col, rs, (int)((first + i) & 15));
     /* live bombs must sit on the board and belong to a real agent: they index cells and agents */
     {
-        const uint32_t m = col[POM_REC_META * rs];
+        const uint32_t m = pom_rec_meta(col, rs);
         const int bIdx = (m >> 8) & 0xFF, bCnt = (m >> 16) & 0xFF;
         if (!bad) {
             for (int k = 0; k < bCnt; k++) {
@@ -1683,7 +1671,7 @@ __global__ void pom_pack_kernel(const int32_t* __restrict__ aos, int64_t first, 
         atomicMin(first_bad, (int)(i > INT_MAX - 1 ? INT_MAX - 1 : i));
         for (int c = 0; c < 4 * POM_REC_BOARD_DWORDS; c++) pom_rec_set_cell(col, rs, c, 0, (int)((first + i) & 15)); /* inert blank board ... */
         for (int d = POM_REC_TIMESTEP; d < POM_REC_DWORDS; d++) col[d * rs] = 0;
-        col[POM_REC_META2 * rs] = (uint32_t)POM_ST_DONE << 8;     /* ... that is never stepped in ENV mode */
+        pom_rec_set_meta(col, rs, 0u, (uint32_t)POM_ST_DONE << 8); /* ... that is never stepped in ENV mode */
     }
     uint32_t* s = snap + (first + i) * POM_REC_DWORDS; /* the snapshot is array-of-structs (restart_column): a dense record */
     for (int c = 0; c < 4 * POM_REC_BOARD_DWORDS; c++) pom_rec_set_cell(s, 1, c, pom_rec_cell(col, rs, c, (int)((first + i) & 15)));
@@ -1751,8 +1739,6 @@ __global__ __launch_bounds__(64) void pom_step_one_kernel(StepOneParams q)
         bad |= (bIdx < 0) | (bIdx >= POM_MAX_BOMBS) | (bCnt < 0) | (bCnt > POM_MAX_BOMBS);
         bad |= (fIdx < 0) | (fIdx >= POM_MAX_BOMBS) | (fCnt < 0) | (fCnt > 255);
         tile[POM_REC_TIMESTEP * 16] = (uint32_t)st[121];
-        tile[POM_REC_META * 16] = ((uint32_t)alive & 0xFF) | ((uint32_t)bIdx << 8) | ((uint32_t)bCnt << 16) | ((uint32_t)fIdx << 24);
-        tile[POM_REC_META2 * 16] = (uint32_t)fCnt & 0xFF;
     }
     if (lane < POM_AGENT_COUNT) {
         const int32_t* a = st + 123 + 6 * lane;
@@ -1761,9 +1747,12 @@ __global__ __launch_bounds__(64) void pom_step_one_kernel(StepOneParams q)
         bad |= (a[0] < 0) | (a[0] >= POM_BOARD_SIZE) | (a[1] < 0) | (a[1] >= POM_BOARD_SIZE);
         bad |= (a[2] < -128) | (a[2] > 127);
         bad |= (a[3] < -32768) | (a[3] > 32767) | (a[4] < 0) | (a[4] > 255);
-        tile[(POM_REC_AGENTS + 2 * lane) * 16] =
-            (uint32_t)a[0] | ((uint32_t)a[1] << 8) | (((uint32_t)a[2] & 0xFF) << 16) | ((uint32_t)kick << 24) | ((uint32_t)dead << 25);
-        tile[(POM_REC_AGENTS + 2 * lane + 1) * 16] = ((uint32_t)a[3] & 0xFFFF) | ((uint32_t)a[4] << 16);
+        /* the top bytes: aliveAgents, bombs.index, bombs.count, flames.index in the agents' first words; flames.count (and the clear
+         * status and flags) in their second words (pom_packed.h) */
+        const uint32_t m0 = (uint32_t)(lane == 0 ? alive : lane == 1 ? bIdx : lane == 2 ? bCnt : fIdx) & 0xFFu, m1 = lane == 0 ? (uint32_t)fCnt & 0xFFu : 0u;
+        tile[(POM_REC_AGENTS + 2 * lane) * 16] = ((uint32_t)a[0] & 0xF) | (((uint32_t)a[1] & 0xF) << 4) | (((uint32_t)a[2] & 0xFF) << 8) |
+                                                 (kick ? (uint32_t)POM_AG_KICK : 0u) | (dead ? (uint32_t)POM_AG_DEAD : 0u) | (m0 << 24);
+        tile[(POM_REC_AGENTS + 2 * lane + 1) * 16] = ((uint32_t)a[3] & 0xFFFF) | (((uint32_t)a[4] & 0xFF) << 16) | (m1 << 24);
     }
     if (lane >= 20 && lane < 20 + POM_MAX_BOMBS) {
         const int k = lane - 20;
@@ -1817,20 +1806,15 @@ __global__ __launch_bounds__(64) void pom_step_one_kernel(StepOneParams q)
         }
         if (member == 0) { /* the register-resident rows */
             t[POM_REC_TIMESTEP * 16] = (uint32_t)time_step;
-            t[POM_REC_META * 16] = pom_lane_meta(L);
-            t[POM_REC_META2 * 16] = pom_lane_meta2(L, status);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                t[(POM_REC_AGENTS + 2 * i) * 16] = (uint32_t)L.a0[i];
-                t[(POM_REC_AGENTS + 2 * i + 1) * 16] = (uint32_t)L.a1[i];
-            }
+            for (int k = 0; k < 8; k++) t[(POM_REC_AGENTS + k) * 16] = pom_lane_agent_word(L, status, k);
         }
     }
     __syncthreads();
 
     /* unpack column 0 (pom_unpack_state, a few State dwords per lane) straight into host memory */
     int32_t* out = p.io + POM_ONE_OUT;
-    const uint32_t m = tile[POM_REC_META * 16], m2 = tile[POM_REC_META2 * 16];
+    const uint32_t m = pom_rec_meta(tile, 16), m2 = pom_rec_meta2(tile, 16);
     out[lane] = pom_cell_decode(pom_rec_cell(tile, 16, lane, 0), lane);
     if (lane + 64 < POM_CELLS) out[lane + 64] = pom_cell_decode(pom_rec_cell(tile, 16, lane + 64, 0), lane + 64);
     if (lane == 61) {
@@ -1850,12 +1834,12 @@ __global__ __launch_bounds__(64) void pom_step_one_kernel(StepOneParams q)
     if (lane < POM_AGENT_COUNT) {
         const uint32_t a0 = tile[(POM_REC_AGENTS + 2 * lane) * 16], a1 = tile[(POM_REC_AGENTS + 2 * lane + 1) * 16];
         int32_t* a = out + 123 + 6 * lane;
-        a[0] = (int32_t)(a0 & 0xFF);
-        a[1] = (int32_t)((a0 >> 8) & 0xFF);
-        a[2] = pom_sext8(a0 >> 16);
-        a[3] = pom_sext16(a1);
-        a[4] = (int32_t)(a1 >> 16);
-        a[5] = (int32_t)(((a0 >> 24) & 1) | (((a0 >> 25) & 1) << 8));
+        a[0] = ag_x((int)a0);
+        a[1] = ag_y((int)a0);
+        a[2] = ag_bombcount((int)a0);
+        a[3] = ag_max_bombs((int)a1);
+        a[4] = ag_strength((int)a1);
+        a[5] = ag_kick((int)a0) | (ag_dead((int)a0) << 8);
     }
     if (lane >= 20 && lane < 20 + POM_MAX_BOMBS) out[147 + lane - 20] = (int32_t)tile[(POM_REC_BOMBS + lane - 20) * 16];
     if (lane >= 40 && lane < 40 + POM_MAX_BOMBS) {
@@ -1878,7 +1862,7 @@ __global__ void pom_status_kernel(const uint32_t* __restrict__ state, int64_t fi
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint32_t* col = state + pom_rec_col(first + i);
-    const uint32_t m = col[POM_REC_META * POM_TILE_ENVS], m2 = col[POM_REC_META2 * POM_TILE_ENVS];
+    const uint32_t m = pom_rec_meta(col, POM_TILE_ENVS), m2 = pom_rec_meta2(col, POM_TILE_ENVS);
     const uint32_t st = (m2 >> 8) & 0xFF;
     out[0 * count + i] = (st & POM_ST_DONE) ? 1 : 0;
     out[1 * count + i] = (int)((st >> POM_ST_WINNER_SHIFT) & 7) - 1;
@@ -1895,14 +1879,14 @@ __global__ void pom_results_kernel(const uint32_t* __restrict__ state, const uin
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const uint32_t now = (state[pom_rec_col(first + i) + POM_REC_META2 * POM_TILE_ENVS] >> 8) & 0xFF;
+    const uint32_t now = (pom_rec_meta2(state + pom_rec_col(first + i), POM_TILE_ENVS) >> 8) & 0xFF;
     const uint32_t* rec = terminal + (first + i) * POM_REC_DWORDS;
-    const uint32_t st = (rec[POM_REC_META2] >> 8) & 0xFF;
+    const uint32_t st = (pom_rec_meta2(rec, 1) >> 8) & 0xFF;
     out[0 * count + i] = (now & POM_ST_RESTARTED) ? 1 : 0;
     out[1 * count + i] = (int)((st >> POM_ST_WINNER_SHIFT) & 7) - 1;
     out[2 * count + i] = (st & POM_ST_DRAW) ? 1 : 0;
     out[3 * count + i] = (int32_t)rec[POM_REC_TIMESTEP];
-    out[4 * count + i] = (st & POM_ST_DONE) ? pom_sext8(rec[POM_REC_META]) : 0;
+    out[4 * count + i] = (st & POM_ST_DONE) ? pom_sext8(pom_rec_meta(rec, 1)) : 0;
 }
 
 __global__ void pom_unpack_aos_kernel(const uint32_t* __restrict__ recs, int64_t first, int64_t count, int32_t* aos)
@@ -1920,10 +1904,9 @@ __global__ void pom_snapshot_kernel(const uint32_t* __restrict__ state, uint32_t
     uint32_t* rec = snap + e * POM_REC_DWORDS; /* array of structs (restart_column): a dense record */
     for (int c = 0; c < 4 * POM_REC_BOARD_DWORDS; c++) pom_rec_set_cell(rec, 1, c, pom_rec_cell(col, POM_TILE_ENVS, c, (int)(e & 15)));
     for (int d = POM_REC_TIMESTEP; d < POM_REC_DWORDS; d++) {
-        uint32_t v = col[d * POM_TILE_ENVS];
-        if (d == POM_REC_META2) v &= 0xFFu; /* a snapshot starts an episode: status and flags clear */
-        rec[d] = v;
+        rec[d] = col[d * POM_TILE_ENVS];
     }
+    pom_rec_set_meta(rec, 1, pom_rec_meta(rec, 1), pom_rec_meta2(rec, 1) & 0xFFu); /* a snapshot starts an episode: status and flags clear */
 }
 
 __global__ __launch_bounds__(1024) void pom_reduce_counters_kernel(const int64_t* __restrict__ wc, int64_t n_waves, int64_t* out)

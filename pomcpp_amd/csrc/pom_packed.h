@@ -4,25 +4,26 @@
  * i.e. bboard::State, /root/reference/include/bboard.hpp:356-506).
  *
  * HBM layout: an array of 16-env TILES, struct-of-arrays inside a tile — dword d >= 31 of env e lives at
- * buf[(e / 16) * 1312 + d * 16 + (e % 16)] (pom_rec_col, row stride POM_TILE_ENVS), and the board — the tile's first 31 rows,
+ * buf[(e / 16) * 1280 + d * 16 + (e % 16)] (pom_rec_col, row stride POM_TILE_ENVS), and the board — the tile's first 31 rows,
  * 1,984 bytes — is laid out BY CELL: cell c of env e is byte c * 16 + (e % 16) of the tile (cells 121..123: zero), so that the
  * address of a cell in the wavefront's LDS copy of the tile is one shift-and-add of the cell number (round 5; with the cells of
- * an env packed four to a dword it was four instructions, and the tick does little else with its vector ALU than look at cells).  A tile is 5,248
- * contiguous bytes (41 lines of 128 B): the wavefront that owns it moves it with five 1-KB instructions (16 bytes per lane)
- * and one of 128 bytes, every cache line full in both directions, and touches ONE region of memory instead of 82 rows that
+ * an env packed four to a dword it was four instructions, and the tick does little else with its vector ALU than look at cells).  A tile is 5,120
+ * contiguous bytes (40 lines of 128 B): the wavefront that owns it moves it with five 1-KB instructions (16 bytes per lane),
+ * every cache line full in both directions, and touches ONE region of memory instead of 80 rows that
  * lie n_pad * 4 bytes apart (rounds 1-2: 4.35 G env-steps/s at 524,288 envs against 6.5 G at 262,144 —
  * beyond the memory-side cache the strided rows cost DRAM and TLB locality).
  *
- * POM_REC_DWORDS = 82 dwords (328 B) per env instead of 251 (rounds 1-4: 112, with 16-bit cells):
+ * POM_REC_DWORDS = 80 dwords (320 B) per env instead of 251 (rounds 1-4: 112, with 16-bit cells):
  *   [0..30]    board, 121 cells of 8 bits (a dense record — snapshot, terminal, host tests: cell c in byte c&3 of dword c>>2, the
  *              last three bytes 0; a tile: see above)
  *   [31]       timeStep
- *   [32]       aliveAgents:8 | bombs.index:8 | bombs.count:8 | flames.index:8
- *   [33]       flames.count:8 | status:8 | ubflags:16
- *   [34..41]   agents: A0[i] = x:8 | y:8 | bombCount:8 (signed) | canKick@24 | dead@25
- *                      A1[i] = maxBombCount:16 | bombStrength:16
- *   [42..61]   bombs.queue raw (all 20 slots: stale slots are state)
- *   [62..81]   flames.queue: x:8 | y:8 | timeLeft:8 (signed) | strength:8
+ *   [32..39]   agents: A0[i] = x:4 | y:4 | bombCount:8 (signed) @8 | canKick@16 | dead@17 | M0[i]:8 @24
+ *                      A1[i] = maxBombCount:16 | bombStrength:8 @16 | M1[i]:8 @24
+ *              The top bytes of the eight agent words carry what does not belong to an agent (two dwords saved: exactly five 1-KB
+ *              moves per tile and direction):  M0 = aliveAgents (signed), bombs.index, bombs.count, flames.index
+ *                                              M1 = flames.count, status, ubflags low byte, ubflags high byte
+ *   [40..59]   bombs.queue raw (all 20 slots: stale slots are state)
+ *   [60..79]   flames.queue: x:8 | y:8 | timeLeft:8 (signed) | strength:8
  *
  * Cell code (8 bit) for board value v (Item, bboard.hpp:54-71) — every value a game can reach from a valid start has one, and
  * the 256 codes are exactly used up:
@@ -51,15 +52,38 @@ enum {
     POM_REC_BOARD = 0,
     POM_REC_BOARD_DWORDS = 31,
     POM_REC_TIMESTEP = 31,
-    POM_REC_META = 32,
-    POM_REC_META2 = 33,
-    POM_REC_AGENTS = 34,
-    POM_REC_BOMBS = 42,
-    POM_REC_FLAMES = 62,
-    POM_REC_DWORDS = 82,
+    POM_REC_AGENTS = 32,
+    POM_REC_BOMBS = 40,
+    POM_REC_FLAMES = 60,
+    POM_REC_DWORDS = 80,
     POM_TILE_ENVS = 16,                              /* envs per tile of the device buffers = row stride of a column, in dwords */
-    POM_TILE_DWORDS = POM_REC_DWORDS * POM_TILE_ENVS /* 1312 */
+    POM_TILE_DWORDS = POM_REC_DWORDS * POM_TILE_ENVS /* 1280 */
 };
+/* agent words */
+enum { POM_AG_KICK = 1 << 16, POM_AG_DEAD = 1 << 17 };
+
+/* The two "meta" words a record used to have, put together from / spread over the top bytes of its agent words:
+ *   meta  = aliveAgents:8 | bombs.index:8 | bombs.count:8 | flames.index:8     (M0 of agents 0..3)
+ *   meta2 = flames.count:8 | status:8 | ubflags:16                             (M1 of agents 0..3) */
+POM_HD uint32_t pom_rec_meta(const uint32_t* rec, int64_t stride)
+{
+    return (rec[(POM_REC_AGENTS + 0) * stride] >> 24) | ((rec[(POM_REC_AGENTS + 2) * stride] >> 24) << 8) |
+           ((rec[(POM_REC_AGENTS + 4) * stride] >> 24) << 16) | ((rec[(POM_REC_AGENTS + 6) * stride] >> 24) << 24);
+}
+POM_HD uint32_t pom_rec_meta2(const uint32_t* rec, int64_t stride)
+{
+    return (rec[(POM_REC_AGENTS + 1) * stride] >> 24) | ((rec[(POM_REC_AGENTS + 3) * stride] >> 24) << 8) |
+           ((rec[(POM_REC_AGENTS + 5) * stride] >> 24) << 16) | ((rec[(POM_REC_AGENTS + 7) * stride] >> 24) << 24);
+}
+POM_HD void pom_rec_set_meta(uint32_t* rec, int64_t stride, uint32_t meta, uint32_t meta2)
+{
+    for (int i = 0; i < 4; i++) {
+        uint32_t& a0 = rec[(POM_REC_AGENTS + 2 * i) * stride];
+        uint32_t& a1 = rec[(POM_REC_AGENTS + 2 * i + 1) * stride];
+        a0 = (a0 & 0x00FFFFFFu) | (((meta >> (8 * i)) & 0xFFu) << 24);
+        a1 = (a1 & 0x00FFFFFFu) | (((meta2 >> (8 * i)) & 0xFFu) << 24);
+    }
+}
 
 /* status byte of META2 */
 enum {
@@ -161,8 +185,6 @@ POM_HD int pom_pack_state(const int32_t* st, uint32_t* rec, int64_t stride, int 
     bad |= (alive < -128) | (alive > 127);
     bad |= (bIdx < 0) | (bIdx >= POM_MAX_BOMBS) | (bCnt < 0) | (bCnt > POM_MAX_BOMBS);
     bad |= (fIdx < 0) | (fIdx >= POM_MAX_BOMBS) | (fCnt < 0) | (fCnt > 255);
-    rec[POM_REC_META * stride] = ((uint32_t)alive & 0xFF) | ((uint32_t)bIdx << 8) | ((uint32_t)bCnt << 16) | ((uint32_t)fIdx << 24);
-    rec[POM_REC_META2 * stride] = (uint32_t)fCnt & 0xFF; /* status, ubflags start clear */
 
     for (int i = 0; i < POM_AGENT_COUNT; i++) {
         const int32_t* a = agents + 6 * i;
@@ -172,9 +194,11 @@ POM_HD int pom_pack_state(const int32_t* st, uint32_t* rec, int64_t stride, int 
         bad |= (a[2] < -128) | (a[2] > 127);
         bad |= (a[3] < -32768) | (a[3] > 32767) | (a[4] < 0) | (a[4] > 255);
         rec[(POM_REC_AGENTS + 2 * i) * stride] =
-            (uint32_t)a[0] | ((uint32_t)a[1] << 8) | (((uint32_t)a[2] & 0xFF) << 16) | ((uint32_t)kick << 24) | ((uint32_t)dead << 25);
-        rec[(POM_REC_AGENTS + 2 * i + 1) * stride] = ((uint32_t)a[3] & 0xFFFF) | ((uint32_t)a[4] << 16);
+            ((uint32_t)a[0] & 0xF) | (((uint32_t)a[1] & 0xF) << 4) | (((uint32_t)a[2] & 0xFF) << 8) | (kick ? (uint32_t)POM_AG_KICK : 0u) | (dead ? (uint32_t)POM_AG_DEAD : 0u);
+        rec[(POM_REC_AGENTS + 2 * i + 1) * stride] = ((uint32_t)a[3] & 0xFFFF) | (((uint32_t)a[4] & 0xFF) << 16);
     }
+    pom_rec_set_meta(rec, stride, ((uint32_t)alive & 0xFF) | (((uint32_t)bIdx & 0xFF) << 8) | (((uint32_t)bCnt & 0xFF) << 16) | (((uint32_t)fIdx & 0xFF) << 24),
+                     (uint32_t)fCnt & 0xFF); /* status, ubflags start clear */
     for (int k = 0; k < POM_MAX_BOMBS; k++)
         rec[(POM_REC_BOMBS + k) * stride] = (uint32_t)bombs[k];
     for (int k = 0; k < POM_MAX_BOMBS; k++) {
@@ -195,17 +219,17 @@ POM_HD void pom_unpack_state(const uint32_t* rec, int64_t stride, int32_t* st, i
 {
     for (int c = 0; c < POM_CELLS; c++) st[c] = pom_cell_decode(pom_rec_cell(rec, stride, c, lane), c);
     st[121] = (int32_t)rec[POM_REC_TIMESTEP * stride];
-    const uint32_t m = rec[POM_REC_META * stride], m2 = rec[POM_REC_META2 * stride];
+    const uint32_t m = pom_rec_meta(rec, stride), m2 = pom_rec_meta2(rec, stride);
     st[122] = pom_sext8(m);
     for (int i = 0; i < POM_AGENT_COUNT; i++) {
         uint32_t a0 = rec[(POM_REC_AGENTS + 2 * i) * stride], a1 = rec[(POM_REC_AGENTS + 2 * i + 1) * stride];
         int32_t* a = st + 123 + 6 * i;
-        a[0] = (int32_t)(a0 & 0xFF);
-        a[1] = (int32_t)((a0 >> 8) & 0xFF);
-        a[2] = pom_sext8(a0 >> 16);
+        a[0] = (int32_t)(a0 & 0xF);
+        a[1] = (int32_t)((a0 >> 4) & 0xF);
+        a[2] = pom_sext8(a0 >> 8);
         a[3] = pom_sext16(a1);
-        a[4] = (int32_t)(a1 >> 16);
-        a[5] = (int32_t)(((a0 >> 24) & 1) | (((a0 >> 25) & 1) << 8));
+        a[4] = (int32_t)((a1 >> 16) & 0xFF);
+        a[5] = (int32_t)(((a0 & POM_AG_KICK) ? 1u : 0u) | ((a0 & POM_AG_DEAD) ? 0x100u : 0u));
     }
     for (int k = 0; k < POM_MAX_BOMBS; k++)
         st[147 + k] = (int32_t)rec[(POM_REC_BOMBS + k) * stride];

@@ -578,7 +578,7 @@ struct PomSimplePolicy {
     {
         const int av = sel4(id, E.a0), a1v = sel4(id, E.a1);
         danger_ = in_danger(sx, sy);
-        can_bomb_ = pom_sext8((uint32_t)av >> 16) < pom_sext16((uint32_t)a1v);
+        can_bomb_ = ag_bombcount(av) < ag_max_bombs(a1v);
         adj1_ = adjacent_enemy(1);
         near_ = adjacent_enemy(7);
         looping_ = has_rp_loop();

@@ -88,8 +88,8 @@ enum { POM_PH_LOAD = 0, POM_PH_FLAMES, POM_PH_AGENT_PREP, POM_PH_AGENT_LOOP, POM
        POM_PH_X_SCAN, POM_PH_X_COMMIT, POM_PH_X_EPILOGUE, POM_PH_X_NEST, POM_PH_X_SHORT, POM_PH_RESTART, POM_PH_FLAMES_DEC, POM_PH_N }; /* X_*: inside explode_long / explode (their time is NOT in the phase that called them) */
 
 struct PomLane { /* the register-resident part of one env */
-    int a0[4];   /* x:8 | y:8 | bombCount:8 | canKick@24 | dead@25 — only ever indexed statically */
-    int a1[4];   /* maxBombCount:16 | bombStrength:16 */
+    int a0[4];   /* x:4 | y:4 | bombCount:8 @8 | canKick@16 | dead@17 (the record's top byte is left as it came: pom_packed.h) — only ever indexed statically */
+    int a1[4];   /* maxBombCount:16 | bombStrength:8 @16 (top byte as it came) */
     int alive, bIdx, bCnt, fIdx, fCnt;
     uint32_t ub;
 #if defined(POM_DIAG)
@@ -168,12 +168,19 @@ POM_HD void put4(int i, int v[4], int x)
     v[2] = i == 2 ? x : v[2];
     v[3] = i == 3 ? x : v[3];
 }
-POM_HD int ag_x(int a0) { return a0 & 0xFF; }
-POM_HD int ag_y(int a0) { return (a0 >> 8) & 0xFF; }
-POM_HD int ag_dead(int a0) { return (a0 >> 25) & 1; }
-POM_HD int ag_kick(int a0) { return (a0 >> 24) & 1; }
-POM_HD int ag_setpos(int a0, int x, int y) { return (a0 & ~0xFFFF) | x | (y << 8); }
-POM_HD int ag_bombcount_add(int a0, int d) { return (a0 & ~0xFF0000) | (int)(((uint32_t)a0 + ((uint32_t)d << 16)) & 0xFF0000u); } /* d may be -1: unsigned arithmetic */
+POM_HD int ag_x(int a0) { return a0 & 0xF; }
+POM_HD int ag_y(int a0) { return (a0 >> 4) & 0xF; }
+POM_HD int ag_pos(int a0) { return a0 & 0xFF; } /* x | y << 4 */
+POM_HD int ag_dead(int a0) { return (a0 >> 17) & 1; }
+POM_HD int ag_kick(int a0) { return (a0 >> 16) & 1; }
+POM_HD int ag_setpos(int a0, int x, int y) { return (a0 & ~0xFF) | x | (y << 4); }
+POM_HD int ag_bombcount(int a0) { return pom_sext8((uint32_t)a0 >> 8); }
+POM_HD int ag_bombcount_add(int a0, int d) { return (a0 & ~0xFF00) | (int)(((uint32_t)a0 + ((uint32_t)d << 8)) & 0xFF00u); } /* d may be -1: unsigned arithmetic */
+POM_HD int ag_max_bombs(int a1) { return pom_sext16((uint32_t)a1); }
+POM_HD int ag_strength(int a1) { return (a1 >> 16) & 0xFF; }
+/* ConsumePowerup's bombStrength++ (step_utility.cpp:255): the record holds 8 bits of it — 255 stays 255 (a game would need 254 of
+ * the range power-ups; the reference's int goes on counting) */
+POM_HD int ag_strength_inc(int a1) { return ag_strength(a1) == 0xFF ? a1 : a1 + (1 << 16); }
 
 POM_HD int wrap20(int p) /* 0 <= p < 40 */
 {
@@ -256,11 +263,11 @@ struct PomStepper {
 
     POM_HD int get_agent(int x, int y) const /* bboard.cpp:289-299 */
     {
-        const int want = x | (y << 8);
+        const int want = x | (y << 4);
         int r = -1;
 #pragma unroll
         for (int i = 3; i >= 0; i--)
-            r = ((!ag_dead(L.a0[i])) & (int)((L.a0[i] & 0xFFFF) == want)) ? i : r;
+            r = ((!ag_dead(L.a0[i])) & (int)(ag_pos(L.a0[i]) == want)) ? i : r;
         return r;
     }
 
@@ -272,7 +279,7 @@ struct PomStepper {
         }
         int v = sel4(id, L.a0);
         if (!ag_dead(v)) {
-            put4(id, L.a0, v | (1 << 25));
+            put4(id, L.a0, v | POM_AG_DEAD);
             L.alive--;
         }
     }
@@ -320,7 +327,7 @@ struct PomStepper {
     POM_HD int owner_strength(int b) /* agents[BMB_ID(b)].bombStrength: the owner's CURRENT strength, SURVEY Q3 */
     {
         const int owner = pb_id(b);
-        if (owner < POM_AGENT_COUNT) return (sel4(owner, L.a1) >> 16) & 0xFFFF;
+        if (owner < POM_AGENT_COUNT) return ag_strength(sel4(owner, L.a1));
         L.ub |= POM_UB_BAD_INDEX;
         return 0;
     }
@@ -386,7 +393,7 @@ struct PomStepper {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int hit = (victims >> j) & 1 & !ag_dead(L.a0[j]);
-            L.a0[j] |= hit << 25;
+            L.a0[j] |= hit << 17;
             L.alive -= hit;
         }
     }
@@ -1002,7 +1009,7 @@ struct PomStepper {
             const int mvm = (int)((mvp >> (4 * m)) & 0xF);
             const int pxm = ag_x(av), pym = ag_y(av);
             const int dxm = pxm + mv_dx(mvm), dym = pym + mv_dy(mvm);
-            const int pos8 = pxm | (pym << 4);
+            const int pos8 = ag_pos(av);
             oldp = (uint32_t)a.template gbcast<0>(pos8) | ((uint32_t)a.template gbcast<1>(pos8) << 8) |
                    ((uint32_t)a.template gbcast<2>(pos8) << 16) | ((uint32_t)a.template gbcast<3>(pos8) << 24);
             const int d8 = ((dxm + 1) & 0xF) | (((dym + 1) & 0xF) << 4);
@@ -1254,7 +1261,7 @@ struct PomStepper {
                 /* plants: PlantBombModifiedLife(x, y, m, 11), bboard.cpp:125-146 — independent of everybody's movement */
                 /* (bitwise & on 0 / 1 values here and below, not &&: on lane-varying operands hipcc turns the short-circuit forms into
                  * nested exec-mask branches — a dozen scalar instructions and two jumps for three compares) */
-                const int wants = live & (int)(mvm == POM_MOVE_BOMB) & (int)(pom_sext8((uint32_t)av >> 16) < pom_sext16((uint32_t)a1v));
+                const int wants = live & (int)(mvm == POM_MOVE_BOMB) & (int)(ag_bombcount(av) < ag_max_bombs(a1v));
                 const int w_all = a.gor(wants << m);
                 int slot_off = 0; /* planters visited before me */
 #pragma unroll
@@ -1268,7 +1275,7 @@ struct PomStepper {
                     planted_moving = pb_dir(b) != 0;
                     b = pb_set(b, 0xF00u, (uint32_t)m << 8);
                     b = pb_set(b, 0xFFu, (uint32_t)ag_x(av) + ((uint32_t)ag_y(av) << 4));
-                    b = pb_set(b, 0xF000u, (uint32_t)((a1v >> 16) & 0xFFFF) << 12);
+                    b = pb_set(b, 0xF000u, (uint32_t)ag_strength(a1v) << 12);
                     b = pb_set(b, 0xF0000u, (uint32_t)(POM_BOMB_LIFETIME + 1) << 16);
                     a.put_bomb(slot, b);
                     av = ag_bombcount_add(av, 1);
@@ -1306,13 +1313,13 @@ struct PomStepper {
                     if (act) {
                         if (pc_is_flame(item)) { /* step.cpp:84-99 */
                             died = 1;
-                            av |= 1 << 25;
+                            av |= POM_AG_DEAD;
                             if (shows_me) a.put_cell(oc, vacated);
                         } else if (!collide) {
                             if (pc_is_powerup(item)) { /* ConsumePowerup, step_utility.cpp:247-262 */
                                 if (item == POM_C_EXTRABOMB) a1v = (a1v & ~0xFFFF) | ((a1v + 1) & 0xFFFF);
-                                else if (item == POM_C_INCRRANGE) a1v += 1 << 16;
-                                else av |= 1 << 24;
+                                else if (item == POM_C_INCRRANGE) a1v = ag_strength_inc(a1v);
+                                else av |= POM_AG_KICK;
                                 item = POM_C_PASSAGE;
                             }
                             if (item == POM_C_PASSAGE) { /* step.cpp:120-140 */
@@ -1377,7 +1384,7 @@ struct PomStepper {
                 const int x = ag_x(av), y = ag_y(av);
                 if (m == POM_MOVE_BOMB) { /* PlantBombModifiedLife(x, y, i, 11), bboard.cpp:125-146 */
                     const int a1v = sel4(i, L.a1);
-                    const int bomb_count = pom_sext8((uint32_t)av >> 16), max_bombs = pom_sext16((uint32_t)a1v);
+                    const int bomb_count = ag_bombcount(av), max_bombs = ag_max_bombs(a1v);
                     if (bomb_count < max_bombs) {
                         if (L.bCnt >= POM_Q) {
                             L.ub |= POM_UB_QUEUE_OVERFLOW; /* step.cpp:191 would overrun bombDestinations[20] */
@@ -1386,13 +1393,13 @@ struct PomStepper {
                             int b = a.bomb(slot); /* stale bits of the slot survive: SURVEY Q1 */
                             b = pb_set(b, 0xF00u, (uint32_t)i << 8);
                             b = pb_set(b, 0xFFu, (uint32_t)x + ((uint32_t)y << 4));
-                            b = pb_set(b, 0xF000u, (uint32_t)((a1v >> 16) & 0xFFFF) << 12);
+                            b = pb_set(b, 0xF000u, (uint32_t)ag_strength(a1v) << 12);
                             b = pb_set(b, 0xF0000u, (uint32_t)(POM_BOMB_LIFETIME + 1) << 16);
                             a.set_bomb(slot, b);
                             put4(i, L.a0, ag_bombcount_add(av, 1));
                             L.bCnt++;
 #pragma unroll
-                            for (int j = 0; j < 4; j++) on_bomb |= ((L.a0[j] & 0xFFFF) == (av & 0xFFFF)) << j;
+                            for (int j = 0; j < 4; j++) on_bomb |= (ag_pos(L.a0[j]) == ag_pos(av)) << j;
                         }
                     }
                     i = next;
@@ -1431,9 +1438,9 @@ struct PomStepper {
                         const int a1v = sel4(i, L.a1);
                         put4(i, L.a1, (a1v & ~0xFFFF) | ((a1v + 1) & 0xFFFF));
                     } else if (item == POM_C_INCRRANGE) {
-                        put4(i, L.a1, sel4(i, L.a1) + (1 << 16));
+                        put4(i, L.a1, ag_strength_inc(sel4(i, L.a1)));
                     } else {
-                        put4(i, L.a0, sel4(i, L.a0) | (1 << 24));
+                        put4(i, L.a0, sel4(i, L.a0) | POM_AG_KICK);
                     }
                     item = POM_C_PASSAGE;
                 }
@@ -1611,26 +1618,28 @@ struct PomStepper {
 };
 
 /* ---- record <-> lane registers ----------------------------------------- */
-POM_HD void pom_lane_load(PomLane& L, const uint32_t meta, const uint32_t meta2, const uint32_t* ag /* 8 dwords */)
+POM_HD void pom_lane_load(PomLane& L, const uint32_t* ag /* the record's 8 agent dwords */, uint32_t& status)
 {
-    L.alive = pom_sext8(meta);
-    L.bIdx = (int)((meta >> 8) & 0xFF);
-    L.bCnt = (int)((meta >> 16) & 0xFF);
-    L.fIdx = (int)(meta >> 24);
-    L.fCnt = (int)(meta2 & 0xFF);
-    L.ub = meta2 >> 16;
+    /* what is not an agent's travels in the top bytes of the agent words (pom_packed.h) */
+    L.alive = (int)ag[0] >> 24; /* (signed) */
+    L.bIdx = (int)(ag[2] >> 24);
+    L.bCnt = (int)(ag[4] >> 24);
+    L.fIdx = (int)(ag[6] >> 24);
+    L.fCnt = (int)(ag[1] >> 24);
+    status = ag[3] >> 24;
+    L.ub = (ag[5] >> 24) | ((ag[7] >> 24) << 8);
     for (int i = 0; i < 4; i++) {
         L.a0[i] = (int)ag[2 * i];
         L.a1[i] = (int)ag[2 * i + 1];
     }
 }
-POM_HD uint32_t pom_lane_meta(const PomLane& L)
+/* the record's agent dword k (0..7) as it is stored: the lane's agent word with this tick's counts, status and flags in its top byte */
+POM_HD uint32_t pom_lane_agent_word(const PomLane& L, uint32_t status, int k)
 {
-    return ((uint32_t)L.alive & 0xFF) | ((uint32_t)L.bIdx << 8) | ((uint32_t)L.bCnt << 16) | ((uint32_t)L.fIdx << 24);
-}
-POM_HD uint32_t pom_lane_meta2(const PomLane& L, uint32_t status)
-{
-    return ((uint32_t)L.fCnt & 0xFF) | ((status & 0xFF) << 8) | ((L.ub & 0xFFFF) << 16);
+    const uint32_t body = (uint32_t)((k & 1) ? L.a1[k >> 1] : L.a0[k >> 1]) & 0x00FFFFFFu;
+    const uint32_t top = k == 0 ? (uint32_t)L.alive : k == 2 ? (uint32_t)L.bIdx : k == 4 ? (uint32_t)L.bCnt : k == 6 ? (uint32_t)L.fIdx :
+                         k == 1 ? (uint32_t)L.fCnt : k == 3 ? status : k == 5 ? L.ub : L.ub >> 8;
+    return body | (top << 24);
 }
 
 /* Environment::Step's bookkeeping after bboard::Step (environment.cpp:150-168); returns the new status byte */

@@ -10,7 +10,7 @@ import os
 import sys
 
 top, out = sys.argv[1], sys.argv[2]
-PACKED = 2 * 328
+PACKED = 2 * 320
 blocks = {}
 for cfg in sorted(os.listdir(top)):
     d = os.path.join(top, cfg)

@@ -55,7 +55,8 @@ int pom_emul_prep(const void* state_1004, const int32_t* moves, int32_t* dest_xy
     ArrayEnv env;
     std::memset(&env, 0, sizeof env);
     PomLane L;
-    pom_lane_load(L, rec[POM_REC_META], rec[POM_REC_META2], rec + POM_REC_AGENTS);
+    uint32_t status_unused = 0;
+    pom_lane_load(L, rec + POM_REC_AGENTS, status_unused);
     PomStepper<ArrayEnv> st(env, L);
     const uint32_t mvp = PomStepper<ArrayEnv>::pack_moves(moves);
     uint32_t oldp = 0, dstp = 0, dep = 0xFFFF, roots = 0x3210;
@@ -123,7 +124,8 @@ uint32_t pom_emul_step(void* state_1004, const int32_t* moves, int env_mode, int
         env.flames[k] = (int)rec[POM_REC_FLAMES + k];
     }
     PomLane L;
-    pom_lane_load(L, rec[POM_REC_META], rec[POM_REC_META2], rec + POM_REC_AGENTS);
+    uint32_t status_rec = 0;
+    pom_lane_load(L, rec + POM_REC_AGENTS, status_rec);
     int time_step = (int)rec[POM_REC_TIMESTEP];
     uint32_t status = status_io ? *status_io : 0;
     L.ub = 0;
@@ -139,12 +141,7 @@ uint32_t pom_emul_step(void* state_1004, const int32_t* moves, int env_mode, int
         rec[POM_REC_BOARD + r] = (uint32_t)env.cells[4 * r] | ((uint32_t)env.cells[4 * r + 1] << 8) | ((uint32_t)env.cells[4 * r + 2] << 16) |
                                  ((uint32_t)env.cells[4 * r + 3] << 24); /* (cells 121..123 stay 0) */
     rec[POM_REC_TIMESTEP] = (uint32_t)time_step;
-    rec[POM_REC_META] = pom_lane_meta(L);
-    rec[POM_REC_META2] = pom_lane_meta2(L, status);
-    for (int i = 0; i < 4; i++) {
-        rec[POM_REC_AGENTS + 2 * i] = (uint32_t)L.a0[i];
-        rec[POM_REC_AGENTS + 2 * i + 1] = (uint32_t)L.a1[i];
-    }
+    for (int k = 0; k < 8; k++) rec[POM_REC_AGENTS + k] = pom_lane_agent_word(L, status, k);
     for (int k = 0; k < 20; k++) {
         rec[POM_REC_BOMBS + k] = (uint32_t)env.bombs[k];
         rec[POM_REC_FLAMES + k] = (uint32_t)env.flames[k];

@@ -305,7 +305,8 @@ uint32_t pom_emul_quad_step(void* state_1004, const int32_t* moves, int env_mode
     int time_step = (int)rec[POM_REC_TIMESTEP];
     uint32_t status = status_io ? *status_io : 0;
     for (int l = 0; l < 4; l++) {
-        pom_lane_load(q.lanes[l], rec[POM_REC_META], rec[POM_REC_META2], rec + POM_REC_AGENTS);
+        uint32_t status_rec = 0;
+        pom_lane_load(q.lanes[l], rec + POM_REC_AGENTS, status_rec);
         q.lanes[l].ub = 0;
         q.moves[l] = moves[l];
     }
@@ -328,12 +329,7 @@ uint32_t pom_emul_quad_step(void* state_1004, const int32_t* moves, int env_mode
         rec[POM_REC_BOARD + r] = (uint32_t)q.mem[A_CELL + 4 * r] | ((uint32_t)q.mem[A_CELL + 4 * r + 1] << 8) |
                                  ((uint32_t)q.mem[A_CELL + 4 * r + 2] << 16) | ((uint32_t)q.mem[A_CELL + 4 * r + 3] << 24);
     rec[POM_REC_TIMESTEP] = (uint32_t)time_step;
-    rec[POM_REC_META] = pom_lane_meta(L);
-    rec[POM_REC_META2] = pom_lane_meta2(L, status);
-    for (int i = 0; i < 4; i++) {
-        rec[POM_REC_AGENTS + 2 * i] = (uint32_t)L.a0[i];
-        rec[POM_REC_AGENTS + 2 * i + 1] = (uint32_t)L.a1[i];
-    }
+    for (int k = 0; k < 8; k++) rec[POM_REC_AGENTS + k] = pom_lane_agent_word(L, status, k);
     for (int k = 0; k < 20; k++) {
         rec[POM_REC_BOMBS + k] = (uint32_t)q.mem[A_BOMB + k];
         rec[POM_REC_FLAMES + k] = (uint32_t)q.mem[A_FLAME + k];

@@ -117,7 +117,7 @@ int pom_emul_window_check(void)
         for (int sx = 0; sx < POM_N; sx++) {
             PomPolicyEnv E;
             std::memset(&E, 0, sizeof E);
-            E.a0[0] = sx | (sy << 8);
+            E.a0[0] = sx | (sy << 4);
             PomSimplePolicy<PolicyArrays> pol(st, E, 0, 0u, 0u);
             for (int radius = 0; radius <= 15; radius++) {
                 const PomCells w = pol.window(radius);
@@ -147,8 +147,8 @@ int pom_emul_simple_act(const void* state_1004, int id, int32_t* mem16, int draw
         E.a0[i] = (int)rec[POM_REC_AGENTS + 2 * i];
         E.a1[i] = (int)rec[POM_REC_AGENTS + 2 * i + 1];
     }
-    E.bIdx = (int)((rec[POM_REC_META] >> 8) & 0xFF);
-    E.bCnt = (int)((rec[POM_REC_META] >> 16) & 0xFF);
+    E.bIdx = (int)((pom_rec_meta(rec, 1) >> 8) & 0xFF);
+    E.bCnt = (int)((pom_rec_meta(rec, 1) >> 16) & 0xFF);
     /* 16-int memory -> 2 dwords */
     uint32_t m0 = 0, m1 = 0;
     for (int i = 0; i < 4; i++) m0 |= (uint32_t)((mem16[2 * i] & 0xF) | ((mem16[2 * i + 1] & 0xF) << 4)) << (8 * i);
