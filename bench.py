@@ -388,7 +388,10 @@ def worker(args) -> None:
     multi = world > 1 or os.environ.get("POM_BENCH_RCCL_SOLO") == "1"
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
+        if "MASTER_PORT" not in os.environ:  # (a launcher sets it; a lone POM_BENCH_RCCL_SOLO run takes a port nobody holds)
+            with socket.socket() as s_port:
+                s_port.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_port.getsockname()[1])
         backend = "gloo" if rehearsal else "nccl"
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -100,7 +100,14 @@ enum {
                               several ticks per launch, one stream), launches are issued as with POM_ISSUE_THREADS.  A wavefront
                               that cannot play its tile (its predecessor did not show up within 2 s of wall-clock time) leaves
                               the tile alone; the next call that reads or changes the batch finds it and replays the tile's
-                              missing ticks with ordinary launches (pom_batch_chain_stats counts such events: expected 0) */
+                              missing ticks with ordinary launches (pom_batch_chain_stats counts such events: expected 0).
+                              That check is ONE host synchronisation of the handle's stream: the first call after chained launches
+                              that is not itself a chained call of the same kind — a step of another kind (pom_batch_step_device,
+                              _step_device_observe, _step_device_range, _policy_simple, several ticks per launch), pom_batch_observe,
+                              _snapshot, _generate, _reset_counters, _device_view, _set_streams, and every call that reads results
+                              back — blocks the calling thread until the chained launches have finished.  pom_batch_flush,
+                              _moves_device and _counters_device do NOT run it (they only join the streams): what they hand out may
+                              lag by the ticks of a tile left behind until the next call that does */
 };
 
 enum { POM_RESET_OFF = 0, POM_RESET_AT_START = 1, POM_RESET_AT_END = 2 };

@@ -665,7 +665,6 @@ static int chain_settle(PomBatch* h)
         c->log.clear();
         return POM_OK;
     }
-    HIPCHK(hipMemsetAsync(c->aux, 0, 4, h->stream));
     if ((flags & POM_CHAIN_E_UNEVEN) || bad > (uint32_t)tiles) { /* not a tile left behind: launches that did not cover the tiles as assumed */
         c->ok = false;
         c->log.clear();
@@ -683,6 +682,19 @@ static int chain_settle(PomBatch* h)
         uint32_t* p;
         ~Free() { delete[] p; }
     } free_list{list};
+    /* from here on a failing runtime call leaves tiles half caught up: the handle says so instead of pretending otherwise (a retry
+     * would replay from the old counts and play ticks twice) */
+    struct Undefined {
+        PomChain* c;
+        bool armed;
+        ~Undefined()
+        {
+            if (armed) {
+                c->ok = false;
+                c->log.clear();
+            }
+        }
+    } undefined{c, true};
     if (bad) HIPCHK(hipMemcpy(list, c->aux + 2, (size_t)bad * 8, hipMemcpyDeviceToHost));
     if (getenv("POM_CHAIN_VERBOSE"))
         fprintf(stderr, "pom: chained launches left %u tile(s) behind (flags %u: %s%s%s); replaying their ticks\n", bad, flags,
@@ -696,8 +708,6 @@ static int chain_settle(PomBatch* h)
             for (const PomChainCall& e : c->log)
                 if (v - e.visit0 < e.launches) call = &e;
             if (!call) { /* cannot happen: every chained launch since the last settle is in the log */
-                c->ok = false;
-                c->log.clear();
                 snprintf(g_err, sizeof g_err, "a tile left behind by chained launches cannot be replayed: the batch is in an undefined state");
                 return POM_E_HIP;
             }
@@ -720,8 +730,10 @@ static int chain_settle(PomBatch* h)
         }
         c->stat_tiles_recovered++;
     }
-    /* the words start over: every tile is level again */
+    /* the words start over: every tile is level again; only now are the flags that asked for this forgotten */
     HIPCHK(hipMemsetAsync(c->tile_seq, 0, (size_t)tiles * 8 * POM_CHAIN_WORD_STRIDE, h->stream));
+    HIPCHK(hipMemsetAsync(c->aux, 0, 4, h->stream));
+    undefined.armed = false;
     c->visits = 0;
     c->log.clear();
     if (flags & (POM_CHAIN_E_XCD | POM_CHAIN_E_TAPE)) c->ok = false; /* structural, not a matter of timing: no more chained launches on this handle */

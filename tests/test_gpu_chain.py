@@ -398,6 +398,21 @@ for ticks in (30, 45, 7):
     ora.run_random(ref, start, ticks, 8, 0, done, 1, 800)
     done += ticks
 assert _same(env.get_state(), ref)
+# the ordinary RL loop step_random(K) -> observe(): the planes are those of the state a download returns, for every element type — a
+# tile left behind by the chained launches is caught up before it is looked at (pom_batch_observe settles; advisor, round 4)
+env.step_random(8, 1, ticks=9)
+ora.run_random(ref, start, 9, 8, 0, done, 1, 800)
+done += 9
+first = {dt: env.observe(dtype=dt, attrs=False)[0].cpu().numpy() for dt in ("uint8",)}
+assert _same(env.get_state(), ref)
+from tests.test_observe import _oracle as _observe_oracle
+assert np.array_equal(first["uint8"], _observe_oracle().observe(env.get_state())[0])
+for dt in ("uint8", "float16", "float32", "codes"):
+    again = env.observe(dtype=dt, attrs=False)[0].cpu().numpy()
+    if dt in first:
+        assert np.array_equal(first[dt], again), dt
+    if dt != "codes":
+        assert np.array_equal(again.astype(np.uint8), first["uint8"]), dt
 env.step_random(8, 1, ticks=12)
 env.step_simple(8, 20)
 env.step_random(9, 1, ticks=6)
