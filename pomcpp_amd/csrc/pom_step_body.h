@@ -419,33 +419,49 @@ struct PomStepper {
             int chain_key = 0; /* this lane's ray stopped at a cell with a queued bomb: distance << 12 | agent there | his id << 1 */
             uint32_t lens = 0; /* reach of ray r in nibble r */
             uint32_t ends = 0; /* power-up flag of the wood a ray ends on, 2 bits per ray (only a ray's last cell can be wood) */
-            /* (cell by cell: with one or two cells per ray the four-at-a-time classification of scan_ray costs more than it saves —
-             * measured, 1,011 -> 1,084 VALU per wavefront-tick on the headline) */
+            /* A ray of such a blast is one or two cells: both are read up front and judged without a loop (SpawnFlameItem's order, bboard.cpp:
+             * 24-57: a queued bomb under a BOMB / agent item stops the look AT the cell, rigid before it, wood on it).  (Round 5; until then
+             * two nested loops with a branch per cell — twice the instructions.  The four-at-a-time classification of scan_ray does not
+             * pay for so few cells: measured, 1,011 -> 1,084 VALU per wavefront-tick on the headline.) */
             POM_NOUNROLL
             for (int r = a.sub(); r < 4; r += A::G) {
-                const int lim = ray_room(x, y, s, r);
-                int len = 0;
-                POM_NOUNROLL
-                for (int i = 1; i <= lim; i++) {
-                    const int c = ray_cell(c0, r, i);
-                    const int e = a.cell(c);
-                    if ((int)(e == POM_C_BOMB) | pc_is_agent(e)) {
-                        /* SpawnFlameItem explodes the first queued bomb on this cell, if there is one (bboard.cpp:30-40) */
-                        const int cy = div11(c);
-                        if (bomb_index_alone((c - cy * POM_N) | (cy << 4)) >= 0) {
-                            chains = 1;
-                            chain_key = (i << 12) | pc_is_agent(e) | ((pc_agent_id(e) & 3) << 1);
-                            break;
-                        }
-                        if (pc_is_agent(e)) victims |= 1 << pc_agent_id(e); /* killed, the ray goes on (bboard.cpp:26-29) */
+                const int lim = ray_room(x, y, s, r); /* 0, 1 or 2 cells */
+                const int on1 = lim >= 1, on2 = lim >= 2;
+                const int c1 = ray_cell(c0, r, on1); /* (no cell: the origin again, ignored) */
+                const int e1 = a.cell(c1);
+                const int ag1 = pc_is_agent(e1);
+                int q1 = 0; /* a queued bomb sits under the item of cell 1 */
+                if (on1 & ((int)(e1 == POM_C_BOMB) | ag1)) {
+                    const int cy = div11(c1);
+                    q1 = bomb_index_alone((c1 - cy * POM_N) | (cy << 4)) >= 0;
+                }
+                const int took1 = on1 & !q1 & (int)(e1 != POM_C_RIGID);
+                const int wood1 = took1 & pc_is_wood(e1);
+                int len = took1, vict = (took1 & ag1) << (pc_agent_id(e1) & 3), flag = wood1 ? pc_wood_flag(e1) : 0;
+                if (q1) {
+                    chains = 1;
+                    chain_key = (1 << 12) | ag1 | ((pc_agent_id(e1) & 3) << 1);
+                }
+                if (took1 & !wood1 & on2) { /* the ray reaches its second cell (a blast of strength 2: skipped by a wavefront without one) */
+                    const int c2 = ray_cell(c0, r, 2);
+                    const int e2 = a.cell(c2);
+                    const int ag2 = pc_is_agent(e2);
+                    int q2 = 0;
+                    if ((int)(e2 == POM_C_BOMB) | ag2) {
+                        const int cy = div11(c2);
+                        q2 = bomb_index_alone((c2 - cy * POM_N) | (cy << 4)) >= 0;
                     }
-                    if (e == POM_C_RIGID) break;
-                    len = i;
-                    if (pc_is_wood(e)) {
-                        ends |= (uint32_t)pc_wood_flag(e) << (2 * r);
-                        break;
+                    const int took2 = (int)(q2 == 0) & (int)(e2 != POM_C_RIGID);
+                    len += took2;
+                    vict |= (took2 & ag2) << (pc_agent_id(e2) & 3);
+                    flag = (took2 & pc_is_wood(e2)) ? pc_wood_flag(e2) : flag;
+                    if (q2) {
+                        chains = 1;
+                        chain_key = (2 << 12) | ag2 | ((pc_agent_id(e2) & 3) << 1);
                     }
                 }
+                victims |= vict; /* killed, the ray goes on (bboard.cpp:26-29) */
+                ends |= (uint32_t)flag << (2 * r);
                 lens |= (uint32_t)len << (4 * r);
             }
             if (__builtin_expect(!a.gor(chains), 1)) {
@@ -453,11 +469,10 @@ struct PomStepper {
                 const int killed = a.gor(victims);
                 if (killed) kill_set(killed); /* Kill, bboard.hpp:474-481, for every agent a ray met */
                 POM_NOUNROLL
-                for (int r = a.sub(); r < 4; r += A::G) { /* no reads: the scan has seen every cell it writes */
-                    const int len = (lens >> (4 * r)) & 0xF;
-                    POM_NOUNROLL
-                    for (int i = 1; i <= len; i++)
-                        a.put_cell(ray_cell(c0, r, i), pc_flame_code(c0, r, i, i == len ? (int)((ends >> (2 * r)) & 3u) : 0));
+                for (int r = a.sub(); r < 4; r += A::G) { /* no reads: the look has seen every cell it writes (at most two per ray) */
+                    const int len = (lens >> (4 * r)) & 0xF, f = (int)((ends >> (2 * r)) & 3u);
+                    if (len >= 1) a.put_cell(ray_cell(c0, r, 1), pc_flame_code(c0, r, 1, len == 1 ? f : 0));
+                    if (len >= 2) a.put_cell(ray_cell(c0, r, 2), pc_flame_code(c0, r, 2, f));
                 }
                 a.sync(); /* the next blast's scan looks at cells other lanes' rays have just written */
                 if (rem == REM_TOP && top_word != -1) { /* nothing touched the queue: the head is still the word the caller saw */
@@ -801,8 +816,13 @@ struct PomStepper {
                 POM_NOUNROLL
                 for (int r = a.sub(); r < 4; r += A::G) {
                     const int lim = ray_room(x, y, s, r);
+                    { /* the arm's first cell without a loop: most flames are of strength 1 */
+                        const int c = ray_cell(c0, r, lim >= 1); /* (no cell: the centre again, ignored) */
+                        const int to = pc_flame_pops_to(a.cell(c), c0, r, 1);
+                        if ((int)(lim >= 1) & (int)(to >= 0)) a.put_cell(c, to);
+                    }
                     POM_NOUNROLL
-                    for (int i = 1; i <= lim; i++) {
+                    for (int i = 2; i <= lim; i++) {
                         const int c = ray_cell(c0, r, i);
                         const int to = pc_flame_pops_to(a.cell(c), c0, r, i);
                         if (to >= 0) a.put_cell(c, to);
