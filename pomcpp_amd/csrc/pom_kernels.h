@@ -63,10 +63,12 @@ struct LdsEnv {
     uint32_t* t; /* &tile[env_in_wave] */
     int sub_;    /* lane's index within its env's group; 0 = owner */
     uint8_t* b;  /* the env's cell 0 (tile_cell_byte) */
-    uint8_t* cm; /* the env's cell counters */
+    uint32_t* tile0; /* the wavefront's tile (wave-uniform) */
     __device__ LdsEnv(uint32_t* tile, int el, int sub)
-        : t(tile + el), sub_(sub), b(reinterpret_cast<uint8_t*>(tile) + tile_cell_byte<EPW>(el, 0)),
-          cm(reinterpret_cast<uint8_t*>(tile + ROW_CLAIMS * EPW) + el * 124) {}
+        : t(tile + el), sub_(sub), b(reinterpret_cast<uint8_t*>(tile) + tile_cell_byte<EPW>(el, 0)), tile0(tile) {}
+    /* the env's cell counters: 124 bytes of its own behind the frames, env after env — worked out where they are needed (loop B of a
+     * tick with moving bombs) instead of living in a register through the whole tick */
+    __device__ uint8_t* claim_map() const { return reinterpret_cast<uint8_t*>(tile0 + ROW_CLAIMS * EPW) + (int)(t - tile0) * 124; }
     __device__ int sub() const { return G == 1 ? 0 : sub_; }
     __device__ bool owner() const { return G == 1 || sub_ == 0; }
     /* quad reductions: lane ^ 1, then lane ^ 2 */
@@ -110,19 +112,23 @@ struct LdsEnv {
     __device__ int bdest(int i) const { return reinterpret_cast<const uint8_t*>(t + ROW_BDEST * EPW)[(i >> 2) * (4 * EPW) + (i & 3)]; }
     __device__ void put_bdest(int i, int v) { reinterpret_cast<uint8_t*>(t + ROW_BDEST * EPW)[(i >> 2) * (4 * EPW) + (i & 3)] = (uint8_t)v; }
     __device__ int frame(int d) const { return (int)t[(ROW_STACK + d) * EPW]; }
-    /* the env's cell counters (loop_b_todo): 124 bytes of its own behind the frames, env after env.  Cleared by the env's lanes
-     * together, a dword each per round; counted up with LDS atomics (two lanes of an env may count the same cell) */
+    __device__ int ag1(int i) const { return (int)t[(POM_REC_AGENTS + 2 * i + 1) * EPW]; }
+    __device__ void put_ag1(int i, int v) { t[(POM_REC_AGENTS + 2 * i + 1) * EPW] = (uint32_t)v; }
+    __device__ void set_ag1(int i, int v) { if (owner()) put_ag1(i, v); }
+    /* (loop_b_todo) cleared by the env's lanes together, a dword each per round; counted up with LDS atomics (two lanes of an env
+     * may count the same cell) */
     __device__ void claims_clear()
     {
+        uint32_t* cm = reinterpret_cast<uint32_t*>(claim_map());
 #pragma unroll
         for (int k = 0; k < (31 + G - 1) / G; k++)
-            if (G * k + G - 1 < 31 || sub() + G * k < 31) reinterpret_cast<uint32_t*>(cm)[sub() + G * k] = 0u;
+            if (G * k + G - 1 < 31 || sub() + G * k < 31) cm[sub() + G * k] = 0u;
     }
     __device__ void claim(int c)
     {
-        __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(cm + (c & ~3)), 1u << (8 * (c & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(claim_map() + (c & ~3)), 1u << (8 * (c & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    __device__ int claims(int c) const { return cm[c]; }
+    __device__ int claims(int c) const { return claim_map()[c]; }
     /* replicated code: all G lanes get here with the same value, the owner writes */
     __device__ void set_cell(int c, int v) { if (owner()) put_cell(c, v); }
     __device__ void set_bomb(int s, int v) { if (owner()) put_bomb(s, v); }
@@ -1004,7 +1010,7 @@ __device__ __forceinline__ uint32_t pom_load_shared(const uint32_t* ptr)
 /* OBS: the launch also writes the observation of the state it leaves behind (pom_observe_tile) — an RL tick is then one launch
  * and one read of the record instead of two of each. */
 template <int EPW, int G, bool FRESH, bool POLICY = false, bool ATEND = false, bool SINGLE = false, bool CHAIN = false, bool OBS = false>
-__global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 4 : EPW == 32 ? 2 : 1)) void pom_step_kernel(StepParams p)
+__global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES : EPW == 16 ? 3 : EPW == 32 ? 2 : 1)) void pom_step_kernel(StepParams p)
 {
     static_assert(!CHAIN || SINGLE, "chained launches play one tick each");
     static_assert(!OBS || (SINGLE && !CHAIN && !POLICY && POM_WPB == 1), "the fused observation exists for the one-tick explicit-move shape");
@@ -1167,11 +1173,14 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
             uint64_t todo = __ballot(reload && owner);
             if (todo) {
                 c_resets += __popcll(todo);
+                int lane_now = lane; /* (as at the end of the tick: addresses worked out where they are used — a launch of several ticks
+                                        would carry them from tick to tick) */
+                if (!SINGLE) asm volatile("" : "+v"(lane_now));
                 do {
                     const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)todo) - 1); /* an owner lane */
                     todo &= todo - 1;
                     const int ec_u = G == 1 ? src : src >> 2;
-                    restart_column<EPW>(tile, ec_u, p.snap + (tile_id * EPW + ec_u) * POM_REC_DWORDS, lane);
+                    restart_column<EPW>(tile, ec_u, p.snap + (tile_id * EPW + ec_u) * POM_REC_DWORDS, lane_now);
                 } while (todo);
                 asm volatile("" ::: "memory"); /* other lanes wrote this lane's column: no read of it may be scheduled earlier */
                 if (reload) lane_from_tile(L, time_step, status, t, EPW); /* the register-resident rows, from the new record */
@@ -1193,19 +1202,19 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
             st.trunc = p.trunc; /* cuts -4 .. -1: none of the policy, + clear, + fill, + safe (act and the tick skipped); 0: the whole policy */
             if (active) {
                 if (p.trunc > -4) pom_policy_prepare_clear(st);
-                if (p.trunc > -3) pom_policy_prepare_fill(st, PomPolicyEnv{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {L.a1[0], L.a1[1], L.a1[2], L.a1[3]}, L.bIdx, L.bCnt});
+                if (p.trunc > -3) pom_policy_prepare_fill(st, PomPolicyEnv{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {acc.ag1(0), acc.ag1(1), acc.ag1(2), acc.ag1(3)}, L.bIdx, L.bCnt});
                 if (p.trunc > -2) pom_policy_prepare_safe(st);
             }
             if (p.trunc > -1)
 #else
             if (active) { /* all four lanes of the env, dead agents' lanes included */
                 pom_policy_prepare_clear(st);
-                pom_policy_prepare_fill(st, PomPolicyEnv{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {L.a1[0], L.a1[1], L.a1[2], L.a1[3]}, L.bIdx, L.bCnt});
+                pom_policy_prepare_fill(st, PomPolicyEnv{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {acc.ag1(0), acc.ag1(1), acc.ag1(2), acc.ag1(3)}, L.bIdx, L.bCnt});
                 pom_policy_prepare_safe(st);
             }
 #endif
             { /* act() is only asked of live agents (environment.cpp:139-146); the wavefront's searches run together: every lane goes in */
-                const PomPolicyEnv E{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {L.a1[0], L.a1[1], L.a1[2], L.a1[3]}, L.bIdx, L.bCnt};
+                const PomPolicyEnv E{{L.a0[0], L.a0[1], L.a0[2], L.a0[3]}, {acc.ag1(0), acc.ag1(1), acc.ag1(2), acc.ag1(3)}, L.bIdx, L.bCnt};
                 const uint32_t r = pom_rng_draw_half(p.seed, env_key, tick0 + (uint32_t)tk, member >> 1);
                 const bool actor = active && !ag_dead(sel4(member, L.a0));
 #if defined(POM_DIAG)
@@ -1244,8 +1253,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                 }
                 mvp = stepper.pack_moves(mv);
             }
-            const uint32_t ub_before = L.ub;
-            L.ub = 0;
+            L.ub = 0; /* this tick's flags; the record's (in the top bytes of two agent words, untouched by the tick) are added afterwards */
             status &= ~(uint32_t)POM_ST_RESTARTED;
             POM_STAMP(L, POM_PH_RESTART); /* diagnostic builds: the restarts and the move draw */
 #if defined(POM_TRUNC)
@@ -1264,9 +1272,11 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                 stepper.step_packed(mvp);
             }
             new_ub = L.ub != 0;
-            L.ub |= ub_before;
+            L.ub |= (t[(POM_REC_AGENTS + 5) * EPW] >> 24) | ((t[(POM_REC_AGENTS + 7) * EPW] >> 24) << 8);
             if (env_mode) {
-                time_step++;
+                /* timeStep is looked at here only: read back from the tile instead of living in a register through the tick */
+                time_step = (int)t[POM_REC_TIMESTEP * EPW] + 1;
+                if (owner) t[POM_REC_TIMESTEP * EPW] = (uint32_t)time_step;
                 status = pom_env_epilogue(L, time_step, p.max_steps, status);
                 newly_done = (status & POM_ST_DONE) != 0;
             }
@@ -1282,19 +1292,21 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
             uint64_t todo = __ballot(newly_done && owner);
             if (todo) {
                 c_resets += __popcll(todo);
-                if (newly_done && owner) { /* the register-resident rows of the final record */
-                    t[POM_REC_TIMESTEP * EPW] = (uint32_t)time_step;
+                if (newly_done && owner) { /* the register-resident rows of the final record (timeStep is in the tile already) */
 #pragma unroll
-                    for (int k = 0; k < 8; k++) t[(POM_REC_AGENTS + k) * EPW] = pom_lane_agent_word(L, status, k);
+                    for (int k = 0; k < 8; k++) t[(POM_REC_AGENTS + k) * EPW] = pom_lane_agent_word(L, status, k, t[(POM_REC_AGENTS + k) * EPW]);
                 }
                 asm volatile("" ::: "memory");
+                int lane_end = lane; /* (a lane id the compiler cannot see through: the global addresses below are worked out here, not at
+                                        the top of the kernel and carried through the tick) */
+                asm volatile("" : "+v"(lane_end));
                 do {
                     const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)todo) - 1); /* an owner lane */
                     todo &= todo - 1;
                     const int ec_u = G == 1 ? src : src >> 2;
                     const int64_t e_u = tile_id * EPW + ec_u;
                     uint32_t* tr = p.terminal + e_u * POM_REC_DWORDS;
-                    column_to_record<EPW>(tile, ec_u, tr, lane);
+                    column_to_record<EPW>(tile, ec_u, tr, lane_end);
                     if (FRESH) {
                         uint32_t ep = 0;
                         if (lane == src) {
@@ -1303,9 +1315,9 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                         }
                         ep = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)ep, src));
                         const uint32_t key = pom_board_key(p.board_seed, (uint32_t)(p.env_offset + e_u), ep);
-                        pom_boardgen_wave<EPW, POM_REC_DWORDS>(tile, ec_u, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), lane);
+                        pom_boardgen_wave<EPW, POM_REC_DWORDS>(tile, ec_u, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), lane_end);
                     } else {
-                        restart_column<EPW>(tile, ec_u, p.snap + e_u * POM_REC_DWORDS, lane);
+                        restart_column<EPW>(tile, ec_u, p.snap + e_u * POM_REC_DWORDS, lane_end);
                     }
                 } while (todo);
                 asm volatile("" ::: "memory");
@@ -1313,8 +1325,10 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
                     lane_from_tile(L, time_step, status, t, EPW);
                     status |= POM_ST_RESTARTED;
                     if (POLICY) { /* a new game gets fresh agents */
-                        p.agent_mem[tile_id * 64 + lane] = 0u;
-                        p.agent_mem[4 * np + tile_id * 64 + lane] = 0u;
+                        int lane_here = lane; /* (a lane id the compiler cannot see through: the two addresses are worked out here, not carried through the tick) */
+                        asm volatile("" : "+v"(lane_here));
+                        p.agent_mem[tile_id * 64 + lane_here] = 0u;
+                        p.agent_mem[4 * np + tile_id * 64 + lane_here] = 0u;
                     }
                 }
             }
@@ -1323,10 +1337,9 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
     }
 
     /* write back: the owner puts the register-resident rows into the tile, then the whole record leaves in row groups */
-    if (owner) {
-        t[POM_REC_TIMESTEP * EPW] = (uint32_t)time_step;
+    if (owner) { /* (timeStep went into the tile with the tick's epilogue) */
 #pragma unroll
-        for (int k = 0; k < 8; k++) t[(POM_REC_AGENTS + k) * EPW] = pom_lane_agent_word(L, status, k);
+        for (int k = 0; k < 8; k++) t[(POM_REC_AGENTS + k) * EPW] = pom_lane_agent_word(L, status, k, (k & 1) ? t[(POM_REC_AGENTS + k) * EPW] : 0u);
     }
     if (EPW == 16) {
         /* the store addresses are functions of the lane id and the arguments only: left alone the compiler computes them at
@@ -1807,7 +1820,7 @@ __global__ __launch_bounds__(64) void pom_step_one_kernel(StepOneParams q)
         if (member == 0) { /* the register-resident rows */
             t[POM_REC_TIMESTEP * 16] = (uint32_t)time_step;
 #pragma unroll
-            for (int k = 0; k < 8; k++) t[(POM_REC_AGENTS + k) * 16] = pom_lane_agent_word(L, status, k);
+            for (int k = 0; k < 8; k++) t[(POM_REC_AGENTS + k) * 16] = pom_lane_agent_word(L, status, k, (k & 1) ? t[(POM_REC_AGENTS + k) * 16] : 0u);
         }
     }
     __syncthreads();

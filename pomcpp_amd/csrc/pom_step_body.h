@@ -41,6 +41,8 @@
  *   int  flame(int slot) / void set_flame(int slot, int v)  packed x|y<<8|time<<16|strength<<24
  *   int  bdest(int i) / void set_bdest(int i, int v)        byte: snapshot of bomb destinations
  *   int  frame(int d) / void set_frame(int d, int v)        explosion stack
+ *   int  ag1(int i) / void set_ag1(int i, int v) / void put_ag1(int i, int v)   agent i's second word (maxBombCount | bombStrength << 16; the
+ *                                                                 record's top byte is not the tick's business: kept as it is)
  *   void claims_clear() / void claim(int c) / int claims(int c)   a counter per cell (loop_b_todo): cleared by the env's lanes together
  *                                                                 (split), counted up by any of them (an atomic add on the device), read
  *                                                                 after a sync()
@@ -89,7 +91,8 @@ enum { POM_PH_LOAD = 0, POM_PH_FLAMES, POM_PH_AGENT_PREP, POM_PH_AGENT_LOOP, POM
 
 struct PomLane { /* the register-resident part of one env */
     int a0[4];   /* x:4 | y:4 | bombCount:8 @8 | canKick@16 | dead@17 (the record's top byte is left as it came: pom_packed.h) — only ever indexed statically */
-    int a1[4];   /* maxBombCount:16 | bombStrength:8 @16 (top byte as it came) */
+                 /* (the agents' second words — maxBombCount:16 | bombStrength:8 @16 — stay in the store, a.ag1(i): the tick looks at them
+                  * when a bomb is planted, when one goes off by another's flame, when a power-up is picked up — four registers too many for that) */
     int alive, bIdx, bCnt, fIdx, fCnt;
     uint32_t ub;
 #if defined(POM_DIAG)
@@ -327,7 +330,7 @@ struct PomStepper {
     POM_HD int owner_strength(int b) /* agents[BMB_ID(b)].bombStrength: the owner's CURRENT strength, SURVEY Q3 */
     {
         const int owner = pb_id(b);
-        if (owner < POM_AGENT_COUNT) return ag_strength(sel4(owner, L.a1));
+        if (owner < POM_AGENT_COUNT) return ag_strength(a.ag1(owner));
         L.ub |= POM_UB_BAD_INDEX;
         return 0;
     }
@@ -1274,7 +1277,8 @@ struct PomStepper {
             if (par) {
                 agents_done = 1;
                 const int m = a.sub();
-                int av = sel4(m, L.a0), a1v = sel4(m, L.a1);
+                int av = sel4(m, L.a0), a1v = a.ag1(m);
+                const int a1_before = a1v;
                 const int mvm = (mvp >> (4 * m)) & 0xF;
                 const int live = !ag_dead(av);
                 const int myrank = (int)((rankp >> (4 * m)) & 0xF), mydepth = (int)((depthp >> (4 * m)) & 0xF);
@@ -1373,8 +1377,7 @@ struct PomStepper {
                 /* back to identical registers in all four lanes */
                 L.a0[0] = a.template gbcast<0>(av); L.a0[1] = a.template gbcast<1>(av);
                 L.a0[2] = a.template gbcast<2>(av); L.a0[3] = a.template gbcast<3>(av);
-                L.a1[0] = a.template gbcast<0>(a1v); L.a1[1] = a.template gbcast<1>(a1v);
-                L.a1[2] = a.template gbcast<2>(a1v); L.a1[3] = a.template gbcast<3>(a1v);
+                if (a1v != a1_before) a.put_ag1(m, a1v); /* (a power-up picked up: rare) */
                 L.alive -= a.gadd(died_sum);
                 L.bCnt += a.gadd(fits);
                 L.ub |= (uint32_t)a.gor(ubm);
@@ -1403,7 +1406,7 @@ struct PomStepper {
                 }
                 const int x = ag_x(av), y = ag_y(av);
                 if (m == POM_MOVE_BOMB) { /* PlantBombModifiedLife(x, y, i, 11), bboard.cpp:125-146 */
-                    const int a1v = sel4(i, L.a1);
+                    const int a1v = a.ag1(i);
                     const int bomb_count = ag_bombcount(av), max_bombs = ag_max_bombs(a1v);
                     if (bomb_count < max_bombs) {
                         if (L.bCnt >= POM_Q) {
@@ -1455,10 +1458,10 @@ struct PomStepper {
                 }
                 if (pc_is_powerup(item)) { /* ConsumePowerup, step_utility.cpp:247-262 */
                     if (item == POM_C_EXTRABOMB) {
-                        const int a1v = sel4(i, L.a1);
-                        put4(i, L.a1, (a1v & ~0xFFFF) | ((a1v + 1) & 0xFFFF));
+                        const int a1v = a.ag1(i);
+                        a.set_ag1(i, (a1v & ~0xFFFF) | ((a1v + 1) & 0xFFFF));
                     } else if (item == POM_C_INCRRANGE) {
-                        put4(i, L.a1, ag_strength_inc(sel4(i, L.a1)));
+                        a.set_ag1(i, ag_strength_inc(a.ag1(i)));
                     } else {
                         put4(i, L.a0, sel4(i, L.a0) | POM_AG_KICK);
                     }
@@ -1648,15 +1651,13 @@ POM_HD void pom_lane_load(PomLane& L, const uint32_t* ag /* the record's 8 agent
     L.fCnt = (int)(ag[1] >> 24);
     status = ag[3] >> 24;
     L.ub = (ag[5] >> 24) | ((ag[7] >> 24) << 8);
-    for (int i = 0; i < 4; i++) {
-        L.a0[i] = (int)ag[2 * i];
-        L.a1[i] = (int)ag[2 * i + 1];
-    }
+    for (int i = 0; i < 4; i++) L.a0[i] = (int)ag[2 * i];
 }
-/* the record's agent dword k (0..7) as it is stored: the lane's agent word with this tick's counts, status and flags in its top byte */
-POM_HD uint32_t pom_lane_agent_word(const PomLane& L, uint32_t status, int k)
+/* the record's agent dword k (0..7) as it is stored: the agent word with this tick's counts, status and flags in its top byte.  Even k:
+ * the lane's a0 words; odd k: `stored` is the second word as it stands in the store (the tick keeps those there) */
+POM_HD uint32_t pom_lane_agent_word(const PomLane& L, uint32_t status, int k, uint32_t stored = 0)
 {
-    const uint32_t body = (uint32_t)((k & 1) ? L.a1[k >> 1] : L.a0[k >> 1]) & 0x00FFFFFFu;
+    const uint32_t body = ((k & 1) ? stored : (uint32_t)L.a0[k >> 1]) & 0x00FFFFFFu;
     const uint32_t top = k == 0 ? (uint32_t)L.alive : k == 2 ? (uint32_t)L.bIdx : k == 4 ? (uint32_t)L.bCnt : k == 6 ? (uint32_t)L.fIdx :
                          k == 1 ? (uint32_t)L.fCnt : k == 3 ? status : k == 5 ? L.ub : L.ub >> 8;
     return body | (top << 24);

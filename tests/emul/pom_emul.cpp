@@ -14,6 +14,7 @@ struct ArrayEnv {
     int bombs[20], flames[20], stack[POM_STACK_DEPTH];
     uint8_t bd[20];
     int cnt[124];
+    int a1w[4];
     static constexpr int G = 1; /* one lane per env: the split sections degenerate to plain loops */
     int sub() const { return 0; }
     int gor(int v) const { return v; }
@@ -35,6 +36,9 @@ struct ArrayEnv {
     void set_bdest(int i, int v) { bd[i] = (uint8_t)v; }
     int frame(int d) const { return stack[d]; }
     void set_frame(int d, int v) { stack[d] = v; }
+    int ag1(int i) const { return a1w[i]; }
+    void set_ag1(int i, int v) { a1w[i] = v; }
+    void put_ag1(int i, int v) { a1w[i] = v; }
     void claims_clear() { std::memset(cnt, 0, sizeof cnt); }
     void claim(int c) { cnt[c]++; }
     int claims(int c) const { return cnt[c]; }
@@ -123,6 +127,7 @@ uint32_t pom_emul_step(void* state_1004, const int32_t* moves, int env_mode, int
         env.bombs[k] = (int)rec[POM_REC_BOMBS + k];
         env.flames[k] = (int)rec[POM_REC_FLAMES + k];
     }
+    for (int i = 0; i < 4; i++) env.a1w[i] = (int)rec[POM_REC_AGENTS + 2 * i + 1];
     PomLane L;
     uint32_t status_rec = 0;
     pom_lane_load(L, rec + POM_REC_AGENTS, status_rec);
@@ -141,7 +146,7 @@ uint32_t pom_emul_step(void* state_1004, const int32_t* moves, int env_mode, int
         rec[POM_REC_BOARD + r] = (uint32_t)env.cells[4 * r] | ((uint32_t)env.cells[4 * r + 1] << 8) | ((uint32_t)env.cells[4 * r + 2] << 16) |
                                  ((uint32_t)env.cells[4 * r + 3] << 24); /* (cells 121..123 stay 0) */
     rec[POM_REC_TIMESTEP] = (uint32_t)time_step;
-    for (int k = 0; k < 8; k++) rec[POM_REC_AGENTS + k] = pom_lane_agent_word(L, status, k);
+    for (int k = 0; k < 8; k++) rec[POM_REC_AGENTS + k] = pom_lane_agent_word(L, status, k, (k & 1) ? (uint32_t)env.a1w[k >> 1] : 0u);
     for (int k = 0; k < 20; k++) {
         rec[POM_REC_BOMBS + k] = (uint32_t)env.bombs[k];
         rec[POM_REC_FLAMES + k] = (uint32_t)env.flames[k];

@@ -37,9 +37,9 @@ namespace {
 
 enum { OP_OR = 1, OP_MIN, OP_ADD, OP_BCAST, OP_SYNC = OP_BCAST + 4, OP_END };
 enum { W_NONE = 0, W_PUT = 1, W_SET_OWNER = 2, W_SET_SHADOW = 3 };
-enum { N_CELL = 124, N_SLOT = 20, N_STACK = POM_STACK_DEPTH, N_ADDR = N_CELL + 3 * N_SLOT + N_STACK };
+enum { N_CELL = 124, N_SLOT = 20, N_STACK = POM_STACK_DEPTH, N_ADDR = N_CELL + 3 * N_SLOT + N_STACK + 4 };
 /* one address space for the merge: cells, bombs, flames, bomb destinations, frames */
-enum { A_CELL = 0, A_BOMB = N_CELL, A_FLAME = A_BOMB + N_SLOT, A_BDEST = A_FLAME + N_SLOT, A_STACK = A_BDEST + N_SLOT };
+enum { A_CELL = 0, A_BOMB = N_CELL, A_FLAME = A_BOMB + N_SLOT, A_BDEST = A_FLAME + N_SLOT, A_STACK = A_BDEST + N_SLOT, A_AG1 = A_STACK + N_STACK };
 
 struct Quad {
     int mem[N_ADDR];            /* the committed tile */
@@ -194,6 +194,9 @@ struct QuadLaneEnv {
     void set_bdest(int i, int v) { wr(A_BDEST + i, v & 0xFF, set_kind()); }
     int frame(int d) const { return rd(A_STACK + d); }
     void set_frame(int d, int v) { wr(A_STACK + d, v, set_kind()); }
+    int ag1(int i) const { return rd(A_AG1 + i); }
+    void put_ag1(int i, int v) { wr(A_AG1 + i, v, W_PUT); }
+    void set_ag1(int i, int v) { wr(A_AG1 + i, v, set_kind()); }
     void claims_clear() { q->claim_clear[sub_] = 1; }
     void claim(int c) { q->claim_add[sub_][c]++; }
     int claims(int c) const /* read after a sync(): nothing of this lane's own may be pending (the device reads what is committed) */
@@ -302,6 +305,7 @@ uint32_t pom_emul_quad_step(void* state_1004, const int32_t* moves, int env_mode
         q.mem[A_BOMB + k] = (int)rec[POM_REC_BOMBS + k];
         q.mem[A_FLAME + k] = (int)rec[POM_REC_FLAMES + k];
     }
+    for (int i = 0; i < 4; i++) q.mem[A_AG1 + i] = (int)rec[POM_REC_AGENTS + 2 * i + 1];
     int time_step = (int)rec[POM_REC_TIMESTEP];
     uint32_t status = status_io ? *status_io : 0;
     for (int l = 0; l < 4; l++) {
@@ -329,7 +333,7 @@ uint32_t pom_emul_quad_step(void* state_1004, const int32_t* moves, int env_mode
         rec[POM_REC_BOARD + r] = (uint32_t)q.mem[A_CELL + 4 * r] | ((uint32_t)q.mem[A_CELL + 4 * r + 1] << 8) |
                                  ((uint32_t)q.mem[A_CELL + 4 * r + 2] << 16) | ((uint32_t)q.mem[A_CELL + 4 * r + 3] << 24);
     rec[POM_REC_TIMESTEP] = (uint32_t)time_step;
-    for (int k = 0; k < 8; k++) rec[POM_REC_AGENTS + k] = pom_lane_agent_word(L, status, k);
+    for (int k = 0; k < 8; k++) rec[POM_REC_AGENTS + k] = pom_lane_agent_word(L, status, k, (k & 1) ? (uint32_t)q.mem[A_AG1 + (k >> 1)] : 0u);
     for (int k = 0; k < 20; k++) {
         rec[POM_REC_BOMBS + k] = (uint32_t)q.mem[A_BOMB + k];
         rec[POM_REC_FLAMES + k] = (uint32_t)q.mem[A_FLAME + k];
