@@ -732,7 +732,10 @@ struct PomStepper {
                         a.put_cell(ray_cell(c0, r, d), pc_flame_code(c0, r, d, (rwood[q] && d == rlen[q]) ? rends[q] : 0));
                 }
             }
-            kill_set(a.gor(victims));
+            {
+                const int killed = a.gor(victims);
+                if (killed) kill_set(killed); /* (mostly nobody stands in the blast: a wavefront without a victim skips the sixteen instructions) */
+            }
             }
             POM_STAMP(L, POM_PH_X_COMMIT);
             if (rstar == 4) { /* the blast is complete: the caller's bookkeeping, then back into the parent */
