@@ -668,7 +668,8 @@ enum {
     OBS_CODE_PLANES = 5,                              /* POM_OBS_CODES: board codes, bomb strength / life / direction, flame life */
     OBS_CODE_ENV_BYTES = OBS_CODE_PLANES * POM_CELLS, /* 605 */
     OBS_CODE_PASS_ENVS = 4,                           /* 4 x 605 B = 605 dwords: a pass's output starts on a dword */
-    OBS_CODE_STAGE_VECS = (OBS_CODE_PASS_ENVS * OBS_CODE_ENV_BYTES + 15) / 16,
+    OBS_CODE_SHIFT_MAX = 12,                          /* a pass is staged 0 / 4 / 8 / 12 bytes into the area: where its output lies relative to a 16-byte line */
+    OBS_CODE_STAGE_VECS = (OBS_CODE_PASS_ENVS * OBS_CODE_ENV_BYTES + OBS_CODE_SHIFT_MAX + 8 + 15) / 16,
     OBS_PLANE_STAGE_VECS = OBS_PASS_ENVS * OBS_ENV_BYTES / 16 + 1, /* + 16 B: the byte funnel reads one dword past a run */
     OBS_STAGE_VECS = OBS_PLANE_STAGE_VECS > OBS_CODE_STAGE_VECS ? OBS_PLANE_STAGE_VECS : OBS_CODE_STAGE_VECS
 };
@@ -690,62 +691,129 @@ static_assert(POM_OBS_CODE_PLANES == OBS_CODE_PLANES, "pom_batch.h");
 __device__ __forceinline__ void obs_lds_order() { asm volatile("" ::: "memory"); }
 
 template <bool CODES>
-__device__ __forceinline__ void pom_observe_stage(const uint32_t* tile, uint4* stage, int q, int lane)
+__device__ __forceinline__ void pom_observe_stage(const uint32_t* tile, uint4* stage, int q, int lane, int shift = 0)
 {
     constexpr int E = CODES ? (int)OBS_CODE_PASS_ENVS : (int)OBS_PASS_ENVS, EB = CODES ? (int)OBS_CODE_ENV_BYTES : (int)OBS_ENV_BYTES;
     constexpr int P_STRENGTH = CODES ? 1 : 12, P_DIR = P_STRENGTH + 2, P_FLAME = P_STRENGTH + 3;
-    constexpr int VECS = (E * EB + 15) / 16, SLOT_IT = (E * POM_Q + 63) / 64;
+    constexpr int VECS = (E * EB + (CODES ? (int)OBS_CODE_SHIFT_MAX + 8 : 0) + 15) / 16, SLOT_IT = (E * POM_Q + 63) / 64;
     static_assert((E & (E - 1)) == 0, "lanes per env");
-    static_assert(OBS_STAGE_VECS * 16 >= E * EB + 8, "eight bytes behind the planes take the writes of lanes that have nothing to write");
+    static_assert(OBS_STAGE_VECS * 16 >= E * EB + 8 + (CODES ? (int)OBS_CODE_SHIFT_MAX : 0), "eight bytes behind the planes take the writes of lanes that have nothing to write");
     /* The phases below are written without branches where a lane-varying `if` would do (hipcc makes exec-mask forests of those, and
      * the kernel is bound by the instructions it issues, scalar ones included): a lane with nothing to write writes to `dump`. */
     const int dump = E * EB + (lane & 7);
-    uint8_t* stage_b = reinterpret_cast<uint8_t*>(stage);
-    const uint16_t* tile_h = reinterpret_cast<const uint16_t*>(tile);
+    uint8_t* stage_b = reinterpret_cast<uint8_t*>(stage) + shift;
 #pragma unroll
     for (int i = 0; i < (VECS + 63) / 64; i++)
         if (64 * i + 63 < VECS || lane + 64 * i < VECS) stage[lane + 64 * i] = make_uint4(0, 0, 0, 0);
     obs_lds_order();
-    /* the queue slots' keys */
-    int key_f[SLOT_IT], key_b[SLOT_IT], bomb[SLOT_IT]; /* where a live slot's key goes (byte offset in the staging area; `dump`: not live) */
+    /* the queue slots' keys.  Code planes: lane -> (env lane / 16, slot lane % 16) of the pass's four envs; the slots 16 .. 19 get a second
+     * round only if some queue of the pass is that long (round 5; until then two full rounds over 80 slots every pass) */
+    constexpr int SLOT_ROUNDS = CODES ? 2 : 1;
+    static_assert(!CODES || (E == 4 && POM_Q == 20), "the slot rounds of the code planes");
+    static_assert(CODES || SLOT_IT == 1, "an env's slots are one round");
+    auto slot = [&](int i, int& ei, int& k, int& ok) {
+        if (CODES) {
+            ei = i == 0 ? lane >> 4 : (lane >> 2) & 3;
+            k = i == 0 ? lane & 15 : 16 + (lane & 3);
+            ok = i == 0 ? 1 : (int)(lane < 16);
+        } else {
+            ei = 0;
+            k = lane;
+            ok = (int)(lane < POM_Q);
+        }
+    };
+    int key_f[SLOT_ROUNDS], key_b[SLOT_ROUNDS], bomb[SLOT_ROUNDS]; /* where a live slot's key goes (byte offset in the staging area; `dump`: not live) */
+    bool tail = false; /* the second round is needed */
 #pragma unroll
-    for (int i = 0; i < SLOT_IT; i++) {
-        const int idx = lane + 64 * i;
-        const int ok = (64 * i + 63 < E * POM_Q) | (int)(idx < E * POM_Q);
-        const int ei = E == 1 ? 0 : (idx * 3277) >> 16 /* idx / 20 for idx < 128 */, k = idx - ei * POM_Q, ec = q * E + (ok ? ei : 0);
-        const uint32_t m = pom_rec_meta(tile + ec, 16), m2 = pom_rec_meta2(tile + ec, 16);
-        const int bIdx = (int)((m >> 8) & 0xFF), bCnt = (int)((m >> 16) & 0xFF), fIdx = (int)(m >> 24), fCnt = (int)(m2 & 0xFF);
-        const int kk = ok ? k : 0;
-        const uint32_t f = tile[(POM_REC_FLAMES + wrap20(fIdx + kk)) * 16 + ec];
-        const int b = (int)tile[(POM_REC_BOMBS + wrap20(bIdx + kk)) * 16 + ec];
-        bomb[i] = b;
-        const int fc = (int)(f & 0xFF) + POM_N * (int)((f >> 8) & 0xFF);
-        key_f[i] = (ok & (int)(k < fCnt) & (int)(fc < POM_CELLS)) ? ei * EB + P_DIR * POM_CELLS + fc : dump;
-        key_b[i] = (ok & (int)(k < bCnt) & (int)(pb_x(b) < POM_N) & (int)(pb_y(b) < POM_N)) ? ei * EB + P_STRENGTH * POM_CELLS + pb_y(b) * POM_N + pb_x(b) : dump;
-        stage_b[key_f[i]] = (uint8_t)(k + 1);
-        stage_b[key_b[i]] = (uint8_t)(k + 1);
+    for (int i = 0; i < SLOT_ROUNDS; i++) {
+        key_f[i] = key_b[i] = dump;
+        bomb[i] = 0;
+        if (i == 0 || tail) {
+            int ei, k, ok;
+            slot(i, ei, k, ok);
+            const int ec = q * E + ei, kk = ok ? k : 0;
+            /* the queues' indices and counts: the top bytes of four agent words (pom_packed.h) */
+            const int bIdx = (int)(tile[(POM_REC_AGENTS + 2) * 16 + ec] >> 24), bCnt = (int)(tile[(POM_REC_AGENTS + 4) * 16 + ec] >> 24),
+                      fIdx = (int)(tile[(POM_REC_AGENTS + 6) * 16 + ec] >> 24), fCnt = (int)(tile[(POM_REC_AGENTS + 1) * 16 + ec] >> 24);
+            if (CODES && i == 0) tail = __any((int)(bCnt > 16) | (int)(fCnt > 16)) != 0;
+            const uint32_t f = tile[(POM_REC_FLAMES + wrap20(fIdx + kk)) * 16 + ec];
+            const int b = (int)tile[(POM_REC_BOMBS + wrap20(bIdx + kk)) * 16 + ec];
+            bomb[i] = b;
+            const int fc = (int)(f & 0xFF) + POM_N * (int)((f >> 8) & 0xFF);
+            key_f[i] = (ok & (int)(k < fCnt) & (int)(fc < POM_CELLS)) ? ei * EB + P_DIR * POM_CELLS + fc : dump;
+            key_b[i] = (ok & (int)(k < bCnt) & (int)(pb_x(b) < POM_N) & (int)(pb_y(b) < POM_N)) ? ei * EB + P_STRENGTH * POM_CELLS + pb_y(b) * POM_N + pb_x(b) : dump;
+            stage_b[key_f[i]] = (uint8_t)(k + 1);
+            stage_b[key_b[i]] = (uint8_t)(k + 1);
+        }
     }
     POM_NOUNROLL
     for (;;) { /* several slots on one cell: one of their writes landed — the smaller keys write again until the smallest stands */
         obs_lds_order();
-        int low_f[SLOT_IT], low_b[SLOT_IT], again = 0;
+        int low_f[SLOT_ROUNDS], low_b[SLOT_ROUNDS], again = 0;
 #pragma unroll
-        for (int i = 0; i < SLOT_IT; i++) {
-            const int idx = lane + 64 * i;
-            const int key = idx - (E == 1 ? 0 : (idx * 3277) >> 16) * POM_Q + 1;
-            low_f[i] = (int)(key_f[i] != dump) & (int)(stage_b[key_f[i]] > key);
-            low_b[i] = (int)(key_b[i] != dump) & (int)(stage_b[key_b[i]] > key);
-            again |= low_f[i] | low_b[i];
+        for (int i = 0; i < SLOT_ROUNDS; i++) {
+            low_f[i] = low_b[i] = 0;
+            if (i == 0 || tail) {
+                int ei, k, ok;
+                slot(i, ei, k, ok);
+                low_f[i] = (int)(key_f[i] != dump) & (int)(stage_b[key_f[i]] > k + 1);
+                low_b[i] = (int)(key_b[i] != dump) & (int)(stage_b[key_b[i]] > k + 1);
+                again |= low_f[i] | low_b[i];
+            }
         }
         if (!__any(again)) break; /* (the usual case: no two live slots on one cell) */
-        for (int i = 0; i < SLOT_IT; i++) { /* (one or two rounds: unrolled without being asked) */
-            const int idx = lane + 64 * i;
-            const int key = idx - (E == 1 ? 0 : (idx * 3277) >> 16) * POM_Q + 1;
-            stage_b[low_f[i] ? key_f[i] : dump] = (uint8_t)key;
-            stage_b[low_b[i] ? key_b[i] : dump] = (uint8_t)key;
+        for (int i = 0; i < SLOT_ROUNDS; i++) { /* (one or two rounds: unrolled without being asked) */
+            if (i == 0 || tail) {
+                int ei, k, ok;
+                slot(i, ei, k, ok);
+                stage_b[low_f[i] ? key_f[i] : dump] = (uint8_t)(k + 1);
+                stage_b[low_b[i] ? key_b[i] : dump] = (uint8_t)(k + 1);
+            }
         }
     }
     obs_lds_order();
+    if constexpr (CODES) {
+        /* The code planes, a pass = four envs: with the board laid out by cell the four envs' codes of cell c ARE one dword of the tile
+         * (bytes 4q .. 4q + 3 of the cell's 16), so a lane takes a cell and turns four codes into four Item numbers at once (round 5;
+         * until then a lane took two cells of one env, ~22 instructions per cell): the 16-entry table (0 passage, 1 rigid, 3 Item::BOMB,
+         * 6 / 7 / 8 the power-ups, 2 wood with any flag, 10 + i agent i — the small numbers of the reference's Item enum, bboard.hpp:54-71)
+         * is two byte permutes on the codes' low three bits, chosen between by bit 3; every code from 15 up is a flame (4). */
+        static_assert(E == 4, "a pass of the code planes is the four envs that share a dword of every cell");
+        const int q4 = 4 * q;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int c = lane + 64 * i;
+            if (i == 0 || c < POM_CELLS) {
+                const uint32_t d = tile[c * 4 + q];
+                const uint32_t flame = (((d & 0x7F7F7F7Fu) + 0x71717171u) | d) & 0x80808080u; /* the bytes >= 15 */
+                const uint32_t lo3 = d & 0x07070707u;
+                const uint32_t t_lo = __builtin_amdgcn_perm(0x02020807u, 0x06030100u, lo3); /* codes 0 .. 7 */
+                const uint32_t t_hi = __builtin_amdgcn_perm(0x040D0C0Bu, 0x0A020202u, lo3); /* codes 8 .. 14 */
+                const uint32_t b3 = (d >> 3) & 0x01010101u, m3 = (b3 << 8) - b3;            /* 0xFF in the bytes with bit 3 */
+                const uint32_t f1 = flame >> 7, mf = (f1 << 8) - f1;
+                uint32_t v = (t_hi & m3) | (t_lo & ~m3);
+                v = (0x04040404u & mf) | (v & ~mf);
+                stage_b[c] = (uint8_t)v;
+                stage_b[EB + c] = (uint8_t)(v >> 8);
+                stage_b[2 * EB + c] = (uint8_t)(v >> 16);
+                stage_b[3 * EB + c] = (uint8_t)(v >> 24);
+                /* the flame cells among the four: the life of the first live flame spawned at the cell's FLAME_ID (key table above) */
+                uint32_t todo = flame;
+                POM_NOUNROLL
+                while (todo) {
+                    const int ei = __builtin_ctz(todo) >> 3, ec = q4 + ei;
+                    todo &= todo - 1u;
+                    const int code = (int)((d >> (8 * ei)) & 0xFFu);
+                    int origin = code - POM_C_FLAME;
+                    if (code >= POM_C_FLAGGED) origin = pom_flame_origin(code, c); /* (a burnt wood with a power-up under it: rare) */
+                    const int key = stage_b[ei * EB + P_DIR * POM_CELLS + origin];
+                    const int fIdx = (int)(tile[(POM_REC_AGENTS + 6) * 16 + ec] >> 24); /* flames.index: the top byte of agent 3's first word */
+                    const int tl = pom_sext8(tile[(POM_REC_FLAMES + wrap20(fIdx + (key ? key - 1 : 0))) * 16 + ec] >> 16);
+                    stage_b[ei * EB + P_FLAME * POM_CELLS + c] = (uint8_t)((int)(key != 0) & (int)(tl > 0) ? tl : 0);
+                }
+            }
+        }
+    } else
     /* cells: a byte each into the plane its code names (or its Item number into the board plane); flame cells look their flame up.  A lane
      * takes half a dword of the board — two cells — of one env per round: lane -> (env of the pass, unit of two cells), so that every
      * address is a base plus a constant */
@@ -787,21 +855,28 @@ __device__ __forceinline__ void pom_observe_stage(const uint32_t* tile, uint4* s
             }
         }
     }
-    int first[SLOT_IT];
+    int first[SLOT_ROUNDS];
 #pragma unroll
-    for (int i = 0; i < SLOT_IT; i++) {
-        const int idx = lane + 64 * i;
-        first[i] = (int)(key_b[i] != dump) & (int)(stage_b[key_b[i]] == idx - (E == 1 ? 0 : (idx * 3277) >> 16) * POM_Q + 1);
+    for (int i = 0; i < SLOT_ROUNDS; i++) {
+        first[i] = 0;
+        if (i == 0 || tail) {
+            int ei, k, ok;
+            slot(i, ei, k, ok);
+            first[i] = (int)(key_b[i] != dump) & (int)(stage_b[key_b[i]] == k + 1);
+        }
     }
     obs_lds_order();
 #pragma unroll
-    for (int i = 0; i < SLOT_IT; i++) stage_b[key_f[i]] = 0; /* the direction plane is the bombs' again */
+    for (int i = 0; i < SLOT_ROUNDS; i++)
+        if (i == 0 || tail) stage_b[key_f[i]] = 0; /* the direction plane is the bombs' again */
     obs_lds_order();
 #pragma unroll
-    for (int i = 0; i < SLOT_IT; i++) {
-        stage_b[first[i] ? key_b[i] : dump] = (uint8_t)pb_strength(bomb[i]);
-        stage_b[first[i] ? key_b[i] + 1 * POM_CELLS : dump] = (uint8_t)pb_time(bomb[i]);
-        stage_b[first[i] ? key_b[i] + 2 * POM_CELLS : dump] = (uint8_t)pb_dir(bomb[i]);
+    for (int i = 0; i < SLOT_ROUNDS; i++) {
+        if (i == 0 || tail) {
+            stage_b[first[i] ? key_b[i] : dump] = (uint8_t)pb_strength(bomb[i]);
+            stage_b[first[i] ? key_b[i] + 1 * POM_CELLS : dump] = (uint8_t)pb_time(bomb[i]);
+            stage_b[first[i] ? key_b[i] + 2 * POM_CELLS : dump] = (uint8_t)pb_dir(bomb[i]);
+        }
     }
     obs_lds_order();
 }
@@ -811,22 +886,42 @@ __device__ __forceinline__ void pom_observe_stage(const uint32_t* tile, uint4* s
  * as dword stores; the batch's last bytes, where n is no multiple of 4, leave byte by byte. */
 __device__ __forceinline__ void pom_observe_tile_codes(const ObserveParams& p, const uint32_t* tile, uint4* stage, int64_t tile_id, int lane)
 {
-    const uint8_t* stage_b = reinterpret_cast<const uint8_t*>(stage);
+    /* A tile's 16 x 605 bytes start on a 16-byte line if the array does, and pass q's 2,420 bytes 4 q bytes into one: staged that many
+     * bytes into the area, the pass leaves as 16-byte stores of aligned LDS reads (round 5; until then 10 rounds of dword stores), the
+     * up to three dwords before the first and after the last whole line one by one */
+    const bool lines = ((reinterpret_cast<uintptr_t>(p.planes) + (uintptr_t)(tile_id * 16 * OBS_CODE_ENV_BYTES)) & 15u) == 0u;
     for (int q = 0; q < 16 / OBS_CODE_PASS_ENVS; q++) {
         const int64_t e0 = tile_id * 16 + q * OBS_CODE_PASS_ENVS;
         if (e0 >= p.n) break;
-        pom_observe_stage<true>(tile, stage, q, lane);
         const int64_t left = p.n - e0;
-        const int bytes = (int)(left < OBS_CODE_PASS_ENVS ? left : OBS_CODE_PASS_ENVS) * OBS_CODE_ENV_BYTES;
+        const bool fast = lines && left >= OBS_CODE_PASS_ENVS;
+        const int shift = fast ? 4 * q : 0;
+        pom_observe_stage<true>(tile, stage, q, lane, shift);
         uint8_t* out_b = reinterpret_cast<uint8_t*>(p.planes) + e0 * OBS_CODE_ENV_BYTES; /* e0 is a multiple of 4: on a dword */
-        uint32_t* out_w = reinterpret_cast<uint32_t*>(out_b);
         const uint32_t* stage_w = reinterpret_cast<const uint32_t*>(stage);
+        if (fast) {
+            constexpr int DW = OBS_CODE_PASS_ENVS * OBS_CODE_ENV_BYTES / 4; /* 605 */
+            uint4* out_v = reinterpret_cast<uint4*>(out_b - shift);
+            uint32_t* out_w = reinterpret_cast<uint32_t*>(out_b - shift);
+            const int beg = q, end = q + DW, v0 = (beg + 3) >> 2, v1 = end >> 2; /* dwords of the area; whole lines [v0, v1) */
 #pragma unroll
-        for (int i = 0; i < (OBS_CODE_PASS_ENVS * OBS_CODE_ENV_BYTES / 4 + 63) / 64; i++) {
-            const int idx = lane + 64 * i;
-            if (idx < (bytes >> 2)) out_w[idx] = stage_w[idx];
+            for (int i = 0; i < (DW / 4 + 1 + 63) / 64; i++) {
+                const int v = lane + 64 * i;
+                if (v >= v0 && v < v1) out_v[v] = stage[v];
+            }
+            const int dw = lane < 4 ? lane : 4 * v1 + lane - 4;
+            if (lane < 4 ? (dw >= beg && dw < 4 * v0) : (lane < 8 && dw < end)) out_w[dw] = stage_w[dw];
+        } else {
+            const uint8_t* stage_b = reinterpret_cast<const uint8_t*>(stage);
+            const int bytes = (int)(left < OBS_CODE_PASS_ENVS ? left : OBS_CODE_PASS_ENVS) * OBS_CODE_ENV_BYTES;
+            uint32_t* out_w = reinterpret_cast<uint32_t*>(out_b);
+#pragma unroll
+            for (int i = 0; i < (OBS_CODE_PASS_ENVS * OBS_CODE_ENV_BYTES / 4 + 63) / 64; i++) {
+                const int idx = lane + 64 * i;
+                if (idx < (bytes >> 2)) out_w[idx] = stage_w[idx];
+            }
+            if (lane < (bytes & 3)) out_b[(bytes & ~3) + lane] = stage_b[(bytes & ~3) + lane];
         }
-        if (lane < (bytes & 3)) out_b[(bytes & ~3) + lane] = stage_b[(bytes & ~3) + lane];
         obs_lds_order();
     }
 }
