@@ -136,6 +136,13 @@ def test_codes_match_the_oracle(hip_lib, kind, n, ticks):
     got, attrs, eattrs = env.observe(dtype="codes", out=buf[: n * 605].view(n, 5, 11, 11))
     assert np.array_equal(got.cpu().numpy(), want)
     assert (buf[n * 605:] == 0xAB).all()
+    # an array that starts 4 / 8 bytes into a 16-byte line (a dword boundary is what the ABI asks for): the export's dword path —
+    # the 16-byte stores need the lines
+    for off in (4, 8):
+        buf2 = torch.full((n * 605 + 80,), 0xCD, dtype=torch.uint8, device="cuda")
+        got2, _, _ = env.observe(dtype="codes", attrs=False, out=buf2[off: off + n * 605].view(n, 5, 11, 11))
+        assert np.array_equal(got2.cpu().numpy(), want), off
+        assert (buf2[:off] == 0xCD).all() and (buf2[off + n * 605:] == 0xCD).all()
     _, want_attrs, want_env = ob.observe(env.get_state())
     assert np.array_equal(attrs.cpu().numpy(), want_attrs) and np.array_equal(eattrs.cpu().numpy()[:, :2], want_env)
     if kind == "stress" and ticks > 10:
