@@ -140,3 +140,32 @@ def test_ranges_are_whole_tiles(hip_lib):
         env.step_device_range(0, 96, mv)
         env.sync()
         assert env.counters()[CNT_STEPS] == 100
+
+
+def test_a_range_with_the_16_planes_writes_only_its_own_part(hip_lib, oracle):
+    """planes instead of codes; the envs outside the range keep what the array held, their states are not stepped"""
+    import torch
+    from tests.test_observe import _oracle as observe_oracle
+    n, first, count = 208, 64, 96
+    start = pa.make_boards(n, seed=47)
+    ob = observe_oracle()
+    with BatchEnvironment(n, mode=MODE_ENV, auto_reset=RESET_AT_END, max_steps=30) as env:
+        env.make_game(start)
+        rng = np.random.default_rng(3)
+        for _ in range(12):  # some play first, so that bombs and flames are on the boards
+            env.step(rng.integers(0, 6, size=(n, 4)).astype(np.int32))
+        before = env.get_state()
+        planes = torch.full((n, 16, 11, 11), 0xEE, dtype=torch.uint8, device="cuda")
+        mv = torch.from_numpy(rng.integers(0, 6, size=(n, 4)).astype(np.int32)).cuda()
+        env.sync()
+        env.step_device_range(first, count, mv, planes=planes)
+        env.sync()
+        after = env.get_state()
+        inside = np.zeros(n, dtype=bool)
+        inside[first:first + count] = True
+        assert before[~inside].tobytes() == after[~inside].tobytes()
+        assert (after["timeStep"][inside] != before["timeStep"][inside]).all()
+        want, _, _ = ob.observe(after)
+        got = planes.cpu().numpy()
+        assert np.array_equal(got[inside], want[inside])
+        assert (got[~inside] == 0xEE).all()
