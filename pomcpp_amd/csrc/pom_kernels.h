@@ -588,10 +588,11 @@ __device__ __forceinline__ int pom_policy_wave(Store& st, const PomPolicyEnv& E,
  * of the planes 0..11), and stream the area out — for uint8 global views a straight 16-byte copy, fully coalesced; other
  * element types and the per-agent plane order take runs of 4 bytes through a byte funnel, convert and store 4 elements.  HBM-write-bound: 1936 B x elements per env.
  * ------------------------------------------------------------------------------------------- */
-#ifndef POM_OBS_PASS_ENVS
-#define POM_OBS_PASS_ENVS 1 /* envs staged at a time: 1 keeps the wavefront at 9 KB of LDS (17 per CU); 4 needed 15 KB and ran 25 % slower */
-#endif
-enum { OBS_ENV_BYTES = POM_OBS_PLANES * POM_CELLS, OBS_PASS_ENVS = POM_OBS_PASS_ENVS };
+/* Envs staged at a time for the 16 planes (template parameter PE below): the export kernel stages two (9 KB of LDS per wavefront, 18 per
+ * CU; 992 + 544 + 279 instructions per wavefront against 1,248 + 738 + 385 with one, alone 23.7 -> 23.1 us: a pass's fixed work — the
+ * queue slots' phases keep 20 lanes busy per env — is paid half as often), the step kernel's fused export one (two cost it 0.5 us:
+ * it sits at its register and LDS limits); four needed 15 KB and ran 25 % slower. */
+enum { OBS_ENV_BYTES = POM_OBS_PLANES * POM_CELLS, OBS_PASS_ENVS_ALONE = 2, OBS_PASS_ENVS_FUSED = 1 };
 static_assert(OBS_ENV_BYTES % 16 == 0, "an env's planes are a whole number of 16-byte stores");
 
 struct ObserveParams {
@@ -632,12 +633,12 @@ __device__ __forceinline__ void obs_store4<float>(float* dst, uint32_t bytes)
  * group crosses a plane boundary (planes are 121 bytes, and the four agent planes are permuted per view), so it fetches the
  * run starting at its first element and the run ending at its last one and splices them at the boundary.  Plane and offset
  * advance incrementally (64 lanes x 4 elements = 2 planes + 14 per round): no division in the loop. */
-template <class T>
+template <class T, int PE>
 __device__ __forceinline__ void obs_gather_out(const ObserveParams& p, const uint32_t* stage_w, int64_t e0, int lane)
 {
     const int views = p.per_agent ? 4 : 1;
     T* out = reinterpret_cast<T*>(p.planes);
-    for (int ei = 0; ei < OBS_PASS_ENVS && e0 + ei < p.n; ei++) {
+    for (int ei = 0; ei < PE && e0 + ei < p.n; ei++) {
         for (int a = 0; a < views; a++) {
             T* dst = out + ((e0 + ei) * views + a) * (int64_t)OBS_ENV_BYTES;
             int pl = (4 * lane) / POM_CELLS, off = 4 * lane - pl * POM_CELLS; /* of the group's first element */
@@ -670,9 +671,12 @@ enum {
     OBS_CODE_PASS_ENVS = 4,                           /* 4 x 605 B = 605 dwords: a pass's output starts on a dword */
     OBS_CODE_SHIFT_MAX = 12,                          /* a pass is staged 0 / 4 / 8 / 12 bytes into the area: where its output lies relative to a 16-byte line */
     OBS_CODE_STAGE_VECS = (OBS_CODE_PASS_ENVS * OBS_CODE_ENV_BYTES + OBS_CODE_SHIFT_MAX + 8 + 15) / 16,
-    OBS_PLANE_STAGE_VECS = OBS_PASS_ENVS * OBS_ENV_BYTES / 16 + 1, /* + 16 B: the byte funnel reads one dword past a run */
-    OBS_STAGE_VECS = OBS_PLANE_STAGE_VECS > OBS_CODE_STAGE_VECS ? OBS_PLANE_STAGE_VECS : OBS_CODE_STAGE_VECS
 };
+/* uint4s of LDS the export needs with PE envs of planes per pass (+ 16 B: the byte funnel reads one dword past a run) */
+constexpr int obs_stage_vecs(int pe)
+{
+    return pe * OBS_ENV_BYTES / 16 + 1 > OBS_CODE_STAGE_VECS ? pe * OBS_ENV_BYTES / 16 + 1 : (int)OBS_CODE_STAGE_VECS;
+}
 static_assert(POM_OBS_CODE_PLANES == OBS_CODE_PLANES, "pom_batch.h");
 
 /* One pass of the export: E envs of the tile (q-th group of E) into the staging area — the 16 planes of an env (CODES = false,
@@ -690,14 +694,14 @@ static_assert(POM_OBS_CODE_PLANES == OBS_CODE_PLANES, "pom_batch.h");
  * stores to be acknowledged: 16 passes x the store latency — three quarters of the wavefront's life, profiles/r04_observe_pmc.txt.) */
 __device__ __forceinline__ void obs_lds_order() { asm volatile("" ::: "memory"); }
 
-template <bool CODES>
+template <bool CODES, int PE>
 __device__ __forceinline__ void pom_observe_stage(const uint32_t* tile, uint4* stage, int q, int lane, int shift = 0)
 {
-    constexpr int E = CODES ? (int)OBS_CODE_PASS_ENVS : (int)OBS_PASS_ENVS, EB = CODES ? (int)OBS_CODE_ENV_BYTES : (int)OBS_ENV_BYTES;
+    constexpr int E = CODES ? (int)OBS_CODE_PASS_ENVS : PE, EB = CODES ? (int)OBS_CODE_ENV_BYTES : (int)OBS_ENV_BYTES;
     constexpr int P_STRENGTH = CODES ? 1 : 12, P_DIR = P_STRENGTH + 2, P_FLAME = P_STRENGTH + 3;
     constexpr int VECS = (E * EB + (CODES ? (int)OBS_CODE_SHIFT_MAX + 8 : 0) + 15) / 16, SLOT_IT = (E * POM_Q + 63) / 64;
     static_assert((E & (E - 1)) == 0, "lanes per env");
-    static_assert(OBS_STAGE_VECS * 16 >= E * EB + 8 + (CODES ? (int)OBS_CODE_SHIFT_MAX : 0), "eight bytes behind the planes take the writes of lanes that have nothing to write");
+    static_assert(obs_stage_vecs(PE) * 16 >= E * EB + 8 + (CODES ? (int)OBS_CODE_SHIFT_MAX : 0), "eight bytes behind the planes take the writes of lanes that have nothing to write");
     /* The phases below are written without branches where a lane-varying `if` would do (hipcc makes exec-mask forests of those, and
      * the kernel is bound by the instructions it issues, scalar ones included): a lane with nothing to write writes to `dump`. */
     const int dump = E * EB + (lane & 7);
@@ -717,9 +721,10 @@ __device__ __forceinline__ void pom_observe_stage(const uint32_t* tile, uint4* s
             k = i == 0 ? lane & 15 : 16 + (lane & 3);
             ok = i == 0 ? 1 : (int)(lane < 16);
         } else {
-            ei = 0;
-            k = lane;
-            ok = (int)(lane < POM_Q);
+            ei = E == 1 ? 0 : (lane * 3277) >> 16; /* lane / 20 */
+            k = lane - ei * POM_Q;
+            ok = (int)(lane < E * POM_Q);
+            ei = ok ? ei : 0;
         }
     };
     int key_f[SLOT_ROUNDS], key_b[SLOT_ROUNDS], bomb[SLOT_ROUNDS]; /* where a live slot's key goes (byte offset in the staging area; `dump`: not live) */
@@ -896,7 +901,7 @@ __device__ __forceinline__ void pom_observe_tile_codes(const ObserveParams& p, c
         const int64_t left = p.n - e0;
         const bool fast = lines && left >= OBS_CODE_PASS_ENVS;
         const int shift = fast ? 4 * q : 0;
-        pom_observe_stage<true>(tile, stage, q, lane, shift);
+        pom_observe_stage<true, 1>(tile, stage, q, lane, shift);
         uint8_t* out_b = reinterpret_cast<uint8_t*>(p.planes) + e0 * OBS_CODE_ENV_BYTES; /* e0 is a multiple of 4: on a dword */
         const uint32_t* stage_w = reinterpret_cast<const uint32_t*>(stage);
         if (fast) {
@@ -926,29 +931,32 @@ __device__ __forceinline__ void pom_observe_tile_codes(const ObserveParams& p, c
     }
 }
 
+template <int PE>
 __device__ __forceinline__ void pom_observe_tile(const ObserveParams& p, const uint32_t* tile, uint4* stage, int64_t tile_id, int lane)
 {
-    static_assert(OBS_PASS_ENVS == 1, "the plane layout is staged env by env");
+    static_assert(PE * POM_Q <= 64 && 16 % PE == 0, "a pass's queue slots are one round of lanes");
     if (p.dtype == POM_OBS_CODES) pom_observe_tile_codes(p, tile, stage, tile_id, lane);
     else
-    for (int q = 0; q < 16 / OBS_PASS_ENVS; q++) {
-        const int64_t e0 = tile_id * 16 + q * OBS_PASS_ENVS;
+    for (int q = 0; q < 16 / PE; q++) {
+        const int64_t e0 = tile_id * 16 + q * PE;
         if (e0 >= p.n) break;
-        constexpr int VECS = OBS_PASS_ENVS * OBS_ENV_BYTES / 16; /* 121 */
-        pom_observe_stage<false>(tile, stage, q, lane);
+        const int64_t left = p.n - e0;
+        const int VECS = (int)(left < PE ? left : PE) * (OBS_ENV_BYTES / 16); /* 121 per env */
+        constexpr int VECS_MAX = PE * OBS_ENV_BYTES / 16;
+        pom_observe_stage<false, PE>(tile, stage, q, lane);
         if (p.dtype == POM_OBS_U8 && !p.per_agent) {
             uint4* out = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(p.planes) + e0 * OBS_ENV_BYTES);
 #pragma unroll
-            for (int i = 0; i < (VECS + 63) / 64; i++) {
+            for (int i = 0; i < (VECS_MAX + 63) / 64; i++) {
                 const int idx = lane + 64 * i;
-                if (64 * i + 63 < VECS || idx < VECS) out[idx] = stage[idx]; /* (non-temporal stores: 45 us against 40 fused) */
+                if (idx < VECS) out[idx] = stage[idx]; /* (non-temporal stores: 45 us against 40 fused) */
             }
         } else if (p.dtype == POM_OBS_U8) {
-            obs_gather_out<uint8_t>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
+            obs_gather_out<uint8_t, PE>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
         } else if (p.dtype == POM_OBS_F16) {
-            obs_gather_out<_Float16>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
+            obs_gather_out<_Float16, PE>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
         } else {
-            obs_gather_out<float>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
+            obs_gather_out<float, PE>(p, reinterpret_cast<const uint32_t*>(stage), e0, lane);
         }
         obs_lds_order();
     }
@@ -1118,7 +1126,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
      * CU would fit, 16 (all of 65,536 envs resident at once) are needed. */
     /* OBS: the staging area — one env's planes (1,936 + 16 B) or four envs' code planes (2,420 B: 38 rows) — lies over the same
      * scratch rows — the tick is over when the observation begins */
-    constexpr int OBS_ROWS = (OBS_STAGE_VECS * 16 + EPW * 4 - 1) / (EPW * 4);
+    constexpr int OBS_ROWS = (obs_stage_vecs(OBS_PASS_ENVS_FUSED) * 16 + EPW * 4 - 1) / (EPW * 4);
     constexpr int OVERLAY = POLICY ? 44 : OBS ? OBS_ROWS : 0; /* rows behind the record that the policy / the export use when the tick does not */
     constexpr int ROWS = POM_REC_DWORDS + OVERLAY > LDS_ROWS ? POM_REC_DWORDS + OVERLAY : LDS_ROWS;
     static_assert(ROWS >= LDS_ROWS, "the tick's scratch rows fit under the overlay");
@@ -1462,7 +1470,7 @@ __global__ __launch_bounds__(64 * POM_WPB, (POLICY ? 4 : G == 4 ? POM_QUAD_WAVES
         op.env_attrs = p.obs_env_attrs;
         op.dtype = p.obs_dtype;
         op.per_agent = p.obs_per_agent;
-        pom_observe_tile(op, tile, reinterpret_cast<uint4*>(tile + POM_REC_DWORDS * EPW), tile_id, lane);
+        pom_observe_tile<OBS_PASS_ENVS_FUSED>(op, tile, reinterpret_cast<uint4*>(tile + POM_REC_DWORDS * EPW), tile_id, lane);
     }
     if (CHAIN) { /* the record's stores have been acknowledged by the L2 before the word that hands the tile on is written */
         pom_chain_leave(p.tile_seq + tile_id * POM_CHAIN_WORD_STRIDE, lane, cv);
@@ -1714,7 +1722,7 @@ __global__ __launch_bounds__(64) void pom_policy_kernel(PolicyParams p)
 __global__ __launch_bounds__(64) void pom_observe_kernel(ObserveParams p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tile[POM_REC_DWORDS * 16];
-    __shared__ uint4 stage[OBS_STAGE_VECS];
+    __shared__ uint4 stage[obs_stage_vecs(OBS_PASS_ENVS_ALONE)];
     const int lane = threadIdx.x;
     int64_t tile_local;
     {
@@ -1729,7 +1737,7 @@ __global__ __launch_bounds__(64) void pom_observe_kernel(ObserveParams p)
      * 31 of a wavefront's 58 k cycles, profiles/r04_observe_pmc.txt.  0x0F70: vmcnt(0), the other counters left alone. */
     __builtin_amdgcn_s_waitcnt(0x0F70);
     asm volatile("" ::: "memory");
-    pom_observe_tile(p, tile, stage, tile_id, lane);
+    pom_observe_tile<OBS_PASS_ENVS_ALONE>(p, tile, stage, tile_id, lane);
 }
 
 /* every env's first board (episode 0) into its state and snapshot columns, through an LDS tile so that the records leave in
