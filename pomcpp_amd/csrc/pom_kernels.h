@@ -663,7 +663,7 @@ __device__ __forceinline__ void obs_gather_out(const ObserveParams& p, const uin
     }
 }
 
-/* the planes and attributes of one tile's 16 envs, from the tile as it lies in LDS ([row][16] dwords); `stage`: OBS_STAGE_VECS
+/* the planes and attributes of one tile's 16 envs, from the tile as it lies in LDS ([row][16] dwords); `stage`: obs_stage_vecs(PE)
  * uint4 of LDS.  Called by the whole wavefront (one wavefront per workgroup: the barriers only order its own LDS traffic). */
 enum {
     OBS_CODE_PLANES = 5,                              /* POM_OBS_CODES: board codes, bomb strength / life / direction, flame life */
