@@ -93,7 +93,7 @@ static bool chain_setup(PomChain* c, int64_t tiles, hipStream_t stream)
     {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
-            c->wave_slots = (int64_t)cus * 16; /* the step kernel's occupancy: 4 wavefronts per SIMD (registers and LDS tile) */
+            c->wave_slots = (int64_t)cus * 20; /* the step kernel's occupancy: 5 wavefronts per SIMD (84 - 93 registers; the LDS tile would allow 22 per CU) */
     }
 #if defined(POM_CHAIN_DIAG)
     const size_t words = (size_t)tiles * (POM_CHAIN_WORD_STRIDE + 68); /* + 68 diagnostic words per tile */

@@ -26,8 +26,10 @@
 
 /* ---------------------------------------------------------------------------------------------
  * LDS tile of one wavefront, [row][EPW] dwords.  Rows 0..79 mirror the HBM record row for row (pom_packed.h), so the
- * whole record moves in groups of 64/EPW rows; then 5 rows of bomb-destination bytes, 21 rows of
- * explosion frames and 31 rows of per-cell counters: 137 rows = 35.1 / 17.5 / 8.8 KB for 64 / 32 / 16 envs per wavefront.
+ * whole record moves in groups of 64/EPW rows; then 5 rows of bomb-destination bytes and 31 rows that hold loop B's per-cell
+ * counters while it chooses its bombs and the explosion frames (21 rows) from then on — the counters are read for the last time
+ * before the first blast of loop B can push a frame, and a wavefront's envs go through both in step —: 116 rows = 29.7 / 14.8 /
+ * 7.4 KB for 64 / 32 / 16 envs per wavefront (137 rows until round 5: 18 wavefronts of 16 envs per CU; now 22).
  * ------------------------------------------------------------------------------------------- */
 enum {
     ROW_BOARD = POM_REC_BOARD,    /* 31 rows: four 8-bit cells per dword            */
@@ -35,8 +37,8 @@ enum {
     ROW_FLAMES = POM_REC_FLAMES,  /* 20 rows                                        */
     ROW_BDEST = POM_REC_DWORDS,   /*  5 rows: 20 bytes, bomb destination snapshot   */
     ROW_STACK = POM_REC_DWORDS + 5, /* 21 rows: explosion frames                    */
-    ROW_CLAIMS = POM_REC_DWORDS + 26, /* 31 rows: a byte per cell and env, [env][124] (PomStepper::loop_b_todo) */
-    LDS_ROWS = POM_REC_DWORDS + 57
+    ROW_CLAIMS = POM_REC_DWORDS + 5,  /* 31 rows OVER the frames: a byte per cell and env, [env][124] (PomStepper::loop_b_todo) */
+    LDS_ROWS = POM_REC_DWORDS + 36
 };
 static_assert(POM_REC_DWORDS % 2 == 0, "the one-lane shapes move the record in groups of 1 or 2 rows");
 

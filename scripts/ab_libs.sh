@@ -9,4 +9,5 @@ for rep in 1 2 3; do for lib in "$@"; do
   echo -n "$lib rep $rep  stress: "; run --steps 100 --warmup 20 --kind stress --dist stress
   echo -n "$lib rep $rep  simple: "; run --steps 100 --warmup 20 --policy simple
   echo -n "$lib rep $rep  tape: "; run --steps 200 --warmup 20 --policy tape
+  echo -n "$lib rep $rep  262144 envs: "; run --steps 100 --warmup 20 --envs 262144
 done; done

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.a
 sys.path.insert(0, ROOT)
 lib = os.path.join(ROOT, "build", "libpom_batch_chaindiag%s.so" % os.environ.get("POM_TAG", ""))
 if not os.path.exists(lib) or "--build" in sys.argv:
-    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DPOM_CHAIN_DIAG", *os.environ.get("POM_EXTRA_FLAGS", "").split(), "-I" + ROOT + "/include",
+    subprocess.run(["hipcc", "-Os", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DPOM_CHAIN_DIAG", *os.environ.get("POM_EXTRA_FLAGS", "").split(), "-I" + ROOT + "/include",
                     "-I" + ROOT + "/pomcpp_amd/csrc", "-o", lib, ROOT + "/pomcpp_amd/csrc/pom_batch.hip"], check=True)
 if "--build" in sys.argv:
     sys.exit(0)

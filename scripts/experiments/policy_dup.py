@@ -19,7 +19,7 @@ names = {0: "baseline", 1: "prepare (danger map + sets)", 2: "forward_reach", 3:
 res = {}
 for k in names:
     lib = os.path.join(ROOT, "build", f"libpom_dup{k}.so")
-    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", f"-DPOM_POL_DUP={k}", "-I" + ROOT + "/include",
+    subprocess.run(["hipcc", "-Os", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", f"-DPOM_POL_DUP={k}", "-I" + ROOT + "/include",
                     "-I" + ROOT + "/pomcpp_amd/csrc", "-o", lib, ROOT + "/pomcpp_amd/csrc/pom_batch.hip"], check=True)
     env = dict(os.environ, POM_LIB=lib, POM_STREAMS="2")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--policy", "simple", "--envs", str(a.envs), "--steps", str(a.steps),

@@ -22,7 +22,7 @@ a = ap.parse_args()
 lib = os.path.join(ROOT, "build", "libpom_batch_trunc.so")
 if a.build_only or not os.path.exists(lib):
     os.makedirs(os.path.dirname(lib), exist_ok=True)
-    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DPOM_TRUNC", "-I" + ROOT + "/include",
+    subprocess.run(["hipcc", "-Os", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DPOM_TRUNC", "-I" + ROOT + "/include",
                     "-I" + ROOT + "/pomcpp_amd/csrc", "-o", lib, ROOT + "/pomcpp_amd/csrc/pom_batch.hip"], check=True)
     if a.build_only:
         sys.exit(0)

@@ -19,7 +19,7 @@ ap.add_argument("--ticks", type=int, default=200)
 a = ap.parse_args()
 lib = os.path.join(ROOT, "build", "libpom_batch_diag.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
-subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DPOM_DIAG", "-I" + ROOT + "/include",
+subprocess.run(["hipcc", "-Os", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DPOM_DIAG", "-I" + ROOT + "/include",
                 "-I" + ROOT + "/pomcpp_amd/csrc", "-o", lib, ROOT + "/pomcpp_amd/csrc/pom_batch.hip"], check=True)
 import pomcpp_amd.batch as B
 B.library_path = lambda: lib

@@ -13,7 +13,7 @@ ap.add_argument("--lib", default="", help="a prebuilt POM_DIAG library (default:
 a = ap.parse_args()
 lib = a.lib or os.path.join(ROOT, "build", "libpom_batch_diag.so")
 if not a.lib:
-    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DPOM_DIAG", "-I" + ROOT + "/include",
+    subprocess.run(["hipcc", "-Os", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DPOM_DIAG", "-I" + ROOT + "/include",
                     "-I" + ROOT + "/pomcpp_amd/csrc", "-o", lib, ROOT + "/pomcpp_amd/csrc/pom_batch.hip"], check=True)
 import pomcpp_amd.batch as B
 B.library_path = lambda: lib
