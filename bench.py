@@ -934,10 +934,10 @@ def worker(args) -> None:
                 # same clock.  Bytes the kernel does not move — the device record is packed to 320 B — so not a utilisation (it can
                 # pass 1.0); kept because rounds 1-2 reported it as `frac`.
                 "contract_achieved": contract, "contract_frac": contract / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": algo_bytes,
-                "limited_by": ("vector-ALU issue: ~890 VALU instructions per wavefront-tick x 4 cycles x 4,096 wavefronts over 1,024 SIMDs is "
-                               "~6 us of the ~7.8 us a step takes in a long call (671 B moved per env-step: 8 TB/s would be 11.9 G env-steps/s); "
-                               "a 20-step region adds ~43 us of launch / synchronise latency and pipeline fill and drain "
-                               "(profiles/r05_region_sweep.txt): DESIGN.md §5, SQ counters in profiles/r05_headc_summary.txt"
+                "limited_by": ("vector-ALU issue: ~900 VALU instructions per wavefront-tick x 4 cycles x 4,096 wavefronts over 1,024 SIMDs is "
+                               "~6 us of the ~7.5 us a step takes in a long call (671 B moved per env-step: 8 TB/s would be 11.9 G env-steps/s); "
+                               "a 20-step region adds ~43 us: launch / synchronise latency and the lag of the slowest of the 4,096 tile chains "
+                               "behind the average one (profiles/r05_region_sweep.txt): DESIGN.md §5, SQ counters in profiles/r05_headc_summary.txt"
                                if issue == "chain" else
                                "instruction issue and the slowest wavefront of a launch (one round of 4 wavefronts per SIMD), not HBM: "
                                "DESIGN.md §4, SQ / I-cache counters in profiles/"),
