@@ -11,8 +11,9 @@ before the timed region starts; nothing crosses PCIe inside it.
 Multi-GPU: `python bench.py --gpus N` starts N ranks itself (one fresh process per GPU, before anything touches HIP);
 under `torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.  torch.distributed, backend nccl = RCCL; envs are
 sharded contiguously with no data-path collective; the timed region is exactly K steps between two (barrier +
-torch.cuda.synchronize()) pairs; the only collective besides the barriers is the all-reduce of the step counters, read after
-the region (weak scaling: per-GPU batch fixed).  The reference fans out the same way, one env per std::thread
+torch.cuda.synchronize()) pairs — a rank's clock stops when its own device is idle, the closing dist.barrier follows, rank 0
+prints the MAX over ranks; the only collective besides the barriers is the all-reduce of the step counters, issued inside the
+region behind the last step (weak scaling: per-GPU batch fixed).  The reference fans out the same way, one env per std::thread
 (unit_test/bboard/performance_test.cpp:40-50,71-94).
 
 The JSON line carries
@@ -89,10 +90,14 @@ def reduce_max(value: float, device, dist_mod=None) -> float:
     return float(t.item())
 
 
-def timed_region(run_steps, steps: int, barrier, in_region_reduce=None) -> float:
+def timed_region(run_steps, steps: int, barrier, in_region_reduce=None, device_sync=None) -> float:
     """The timed region: exactly `steps` steps between two barriers (each = dist.barrier + torch.cuda.synchronize()).  With
     several ranks `in_region_reduce` — the path's one collective, the all-reduce of the step counters — is issued INSIDE it,
-    behind the last step.  Returns this rank's wall time."""
+    behind the last step.  `device_sync` (torch.cuda.synchronize): the clock stops when THIS rank's device is idle — every stream:
+    the steps, the sub-batches, the side stream's all-reduce — and the closing barrier's dist.barrier follows outside it: a rank
+    reports its own time and rank 0 prints the MAX over ranks, so the wait for the other ranks (and a second collective's latency)
+    is not part of anybody's K steps.  Without it (the CPU rehearsal, tests/stub_rank.py) the clock stops behind the barrier.
+    Returns this rank's wall time."""
     trace = os.environ.get("POM_BENCH_TRACE") == "1"
     barrier()
     t0 = time.perf_counter()
@@ -101,10 +106,15 @@ def timed_region(run_steps, steps: int, barrier, in_region_reduce=None) -> float
     if in_region_reduce is not None:
         in_region_reduce()
     t_b = time.perf_counter()
-    barrier()
-    t1 = time.perf_counter()
+    if device_sync is not None:
+        device_sync()
+        t1 = time.perf_counter()
+        barrier()
+    else:
+        barrier()
+        t1 = time.perf_counter()
     if trace:  # host time of the region's three pieces (the device runs behind the first two)
-        print(f"[trace] steps queued {1e6 * (t_a - t0):.0f} us, reduction queued {1e6 * (t_b - t_a):.0f} us, closing barrier {1e6 * (t1 - t_b):.0f} us",
+        print(f"[trace] steps queued {1e6 * (t_a - t0):.0f} us, reduction queued {1e6 * (t_b - t_a):.0f} us, until the device was idle {1e6 * (t1 - t_b):.0f} us",
               file=sys.stderr, flush=True)
     return t1 - t0
 
@@ -508,8 +518,8 @@ def worker(args) -> None:
             reduce_counters(counters, dist)
 
     env.fork()  # the sub-streams are ordered behind the setup above now, not inside the timed region
-    # (the closing barrier's torch.cuda.synchronize() waits for every stream of the device: the sub-batches' and the side stream too)
-    elapsed = timed_region(run_steps, args.steps, barrier, counters_allreduce if reduce_in_region else None)
+    # (torch.cuda.synchronize() waits for every stream of the device: the sub-batches' and the side stream's all-reduce too)
+    elapsed = timed_region(run_steps, args.steps, barrier, counters_allreduce if reduce_in_region else None, torch.cuda.synchronize)
     elapsed = reduce_max(elapsed, device, dist)
     if not reduce_in_region:  # one GPU: bookkeeping after the region (what the K steps did)
         env.sync()  # (also the check behind chained launches: a tile a wavefront could not play is caught up, and counted, here)
