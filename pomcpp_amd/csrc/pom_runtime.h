@@ -362,6 +362,11 @@ struct PomIssuer {
     int launches = 0, ticks_per_launch = 1, last_ticks = 1;
     bool policy = false;
     hipError_t err = hipSuccess;
+    /* a job of chained launches (launch_many_chain): these parameter blocks, one launch each, on `st` */
+    std::vector<StepParams> chain_q;
+    const void* chain_kernel = nullptr;
+    unsigned chain_grid = 0;
+    int chain_done = 0; /* how many of them were queued */
 };
 
 static void issuer_main(PomBatch* h, PomIssuer* w)
@@ -386,6 +391,22 @@ static void issuer_main(PomBatch* h, PomIssuer* w)
         if (w->quit) return;
         if (!w->has_job) continue;
         w->has_job = false;
+        if (w->chain_kernel) { /* chained launches: which launch plays which tick is the tiles' tickets' business, not the order here */
+            hipError_t cerr = hipSuccess;
+            int done = 0;
+            for (StepParams& q : w->chain_q) {
+                void* args[1] = {&q};
+                cerr = hipExtLaunchKernel(w->chain_kernel, dim3(w->chain_grid), dim3(64 * POM_WPB), args, 0, w->st, nullptr, nullptr, 0);
+                if (cerr != hipSuccess) break;
+                done++;
+            }
+            w->chain_done = done;
+            w->chain_kernel = nullptr;
+            w->err = cerr;
+            w->busy = false;
+            w->cv.notify_all();
+            continue;
+        }
         StepParams p = w->p;
         hipError_t err = hipSuccess;
         for (int i = 0; i < w->launches && err == hipSuccess; i++) {
@@ -813,18 +834,78 @@ static int launch_many_chain(PomBatch* h, const StepParams& p0, int launches, bo
     h->chain_last_use = use;
     int issued = 0;
     hipError_t err = hipSuccess;
-    for (; issued < launches; issued++) {
-        const int part = (int)(c->turn++ % (uint32_t)use);
-        hipStream_t st = part < h->main_part ? h->stream : h->sub[part];
-        const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
-        hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
+    auto params_of = [&](int i) { /* launch number i of the call */
         StepParams q = p;
-        q.chain_rot = back ? (uint32_t)(((uint64_t)(c->visits + (uint32_t)issued) * (uint64_t)(per_xcd - back)) % per_xcd) : 0u;
-        void* args[1] = {&q};
-        err = hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, dim3(64 * POM_WPB), args, 0, st, ev0, ev1, 0);
-        if (err != hipSuccess) break;
-        if (prof) h->prof_n++;
+        q.chain_rot = back ? (uint32_t)(((uint64_t)(c->visits + (uint32_t)i) * (uint64_t)(per_xcd - back)) % per_xcd) : 0u;
+        return q;
+    };
+    const uint32_t turn0 = c->turn;
+    auto part_of = [&](int i) { return (int)((turn0 + (uint32_t)i) % (uint32_t)use); };
+    /* Who issues: the first launch of every stream the calling thread, at once; then the sub-streams' remaining launches their helper
+     * threads (the ones sub-batch launches use: created on first use, spinning for a millisecond after pom_batch_fork / a job) while the
+     * calling thread issues its own stream's.  A launch costs the host 2.5 - 3 us, sometimes 6 - 9: with one thread a 20-step call is
+     * queued in 50 - 60 us on most runs and in 120 - 180 us on one in five, late enough for the device to wait for its launches
+     * (profiles/r05_issue_helpers.txt).  Any interleaving is fine: the tiles' tickets order the ticks, not the launches' order. */
+    static const bool helpers_on = !(getenv("POM_CHAIN_HELPERS") && atoi(getenv("POM_CHAIN_HELPERS")) == 0);
+    const bool helpers = helpers_on && !h->profiling && use >= 2 && launches >= 3 * use && !h->issuers_failed;
+    if (!helpers) {
+        for (; issued < launches; issued++) {
+            const int part = part_of(issued);
+            hipStream_t st = part < h->main_part ? h->stream : h->sub[part];
+            const bool prof = h->profiling && h->prof_n < PomBatch::PROF_RING;
+            hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
+            StepParams q = params_of(issued);
+            void* args[1] = {&q};
+            err = hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, dim3(64 * POM_WPB), args, 0, st, ev0, ev1, 0);
+            if (err != hipSuccess) break;
+            if (prof) h->prof_n++;
+        }
+    } else {
+        auto launch_here = [&](int i) {
+            const int part = part_of(i);
+            StepParams q = params_of(i);
+            void* args[1] = {&q};
+            const hipError_t e = hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, dim3(64 * POM_WPB), args, 0,
+                                                    part < h->main_part ? h->stream : h->sub[part], nullptr, nullptr, 0);
+            if (e == hipSuccess) issued++;
+            else if (err == hipSuccess) err = e;
+        };
+        for (int i = 0; i < use && err == hipSuccess; i++) launch_here(i); /* every stream's first launch: now */
+        PomIssuer* started[PomBatch::MAX_PARTS] = {};
+        for (int part = h->main_part; part < use && err == hipSuccess; part++) {
+            PomIssuer* w = issuer_for(h, part);
+            if (!w) continue; /* (no thread to be had: this thread issues that stream's launches below) */
+            {
+                std::lock_guard<std::mutex> g(w->mu);
+                w->chain_q.clear();
+                for (int i = use; i < launches; i++)
+                    if (part_of(i) == part) w->chain_q.push_back(params_of(i));
+                w->chain_kernel = reinterpret_cast<const void*>(kernel);
+                w->chain_grid = grid.x;
+                w->chain_done = 0;
+                w->st = h->sub[part];
+                w->err = hipSuccess;
+                w->busy = true;
+                w->has_job = true;
+                w->posted.fetch_add(1, std::memory_order_release);
+            }
+            w->cv.notify_all();
+            started[part] = w;
+        }
+        for (int i = use; i < launches && err == hipSuccess; i++) { /* the caller's own stream(s), and those without a helper */
+            const int part = part_of(i);
+            if (part < h->main_part || !started[part]) launch_here(i);
+        }
+        for (int part = 0; part < use; part++) { /* everything is queued when the call returns */
+            PomIssuer* w = started[part];
+            if (!w) continue;
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [w] { return !w->busy; });
+            issued += w->chain_done;
+            if (w->err != hipSuccess && err == hipSuccess) err = w->err;
+        }
     }
+    c->turn = turn0 + (uint32_t)launches;
     /* what was issued is accounted for even if a launch failed half-way: the tiles' words, the log and the host's tick agree */
     if (issued > 0) {
         if (continues && !c->log.empty() && c->log.back().visit0 + c->log.back().launches == c->visits && c->log.back().policy == policy) {
