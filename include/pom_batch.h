@@ -94,8 +94,10 @@ enum {
                               consecutive launches go to different internal HIP streams (two in a short call, three from 50 ticks
                               up), and a ticket word per 16-env tile orders that tile's ticks — a tile's next tick waits for the
                               same tile's previous tick only, not for the slowest wavefront of the launch before.  Asynchronous
-                              like the other modes: the call returns when its launches are queued; every other call of this API
-                              joins the streams.  pom_batch_create probes the device once (workgroup -> XCD round-robin over
+                              like the other modes: the call returns when its launches are queued — by the calling thread and, in a
+                              call of six launches or more, by the helper threads of the internal sub-streams (created on first
+                              use, joined by pom_batch_destroy; environment POM_CHAIN_HELPERS=0: the calling thread alone); every
+                              other call of this API joins the streams.  pom_batch_create probes the device once (workgroup -> XCD round-robin over
                               eight XCDs); where that does not hold, and for shapes without a chained twin (one lane per env,
                               several ticks per launch, one stream), launches are issued as with POM_ISSUE_THREADS.  A wavefront
                               that cannot play its tile (its predecessor did not show up within 2 s of wall-clock time) leaves
